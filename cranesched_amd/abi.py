@@ -1,0 +1,296 @@
+"""ctypes mirror of include/crane_gpu/node_select.h (the C ABI of the engine).
+
+Host-side containers (numpy SoA) for the three tables that cross the boundary of
+CraneCtld's `SchedulerAlgo::NodeSelect` (reference: src/CraneCtld/JobScheduler.h:260-263):
+the node snapshot (CranedMeta, src/CraneCtld/Node/NodeDefs.h:59-81), the running jobs
+(RnJobInScheduler, JobScheduler.h:57-90) and the pending jobs (PdJobInScheduler,
+JobScheduler.h:92-170), plus the placement result.  Pure plumbing: no scheduling logic here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import numpy as np
+
+CNS_ABI_VERSION = 1
+MAX_GRES_CLASSES = 8
+MAX_GRES_NAMES = 4
+MAX_NODE_TYPES = 64
+NODE_NONE = 0xFFFFFFFF
+
+REASON_NONE, REASON_PRIORITY, REASON_RESOURCE, REASON_RESOURCE_RESERVED, \
+    REASON_PARTITION_NOT_FOUND, REASON_SKIPPED = range(6)
+# cns_reason <-> the reference's reason strings (JobScheduler.cpp:6750-6831, JobScheduler.h:198)
+REASON_STR = {
+    REASON_NONE: "", REASON_PRIORITY: "Priority", REASON_RESOURCE: "Resource",
+    REASON_RESOURCE_RESERVED: "Resource Reserved",
+    REASON_PARTITION_NOT_FOUND: "Partition Not Found", REASON_SKIPPED: "<caller-set>",
+}
+
+STATUS_STR = {0: "CNS_OK", -1: "CNS_ERR_INVALID_ARG", -2: "CNS_ERR_NO_DEVICE", -3: "CNS_ERR_HIP",
+              -4: "CNS_ERR_UNSUPPORTED", -5: "CNS_ERR_STATE", -6: "CNS_ERR_DEVICE_FAULT"}
+
+
+class CnsConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32),
+                ("scheduled_batch_size", C.c_uint64), ("max_job_num_per_node", C.c_uint32),
+                ("reserved0", C.c_uint32), ("max_time_window_sec", C.c_int64)]
+
+
+class CnsGresLayout(C.Structure):
+    _fields_ = [("num_classes", C.c_uint32), ("class_name", C.c_uint8 * MAX_GRES_CLASSES),
+                ("class_shift", C.c_uint8 * MAX_GRES_CLASSES),
+                ("class_width", C.c_uint8 * MAX_GRES_CLASSES)]
+
+
+_P = C.c_void_p
+
+
+class CnsNodeSoa(C.Structure):
+    _fields_ = [("num_nodes", C.c_uint32), ("num_partitions", C.c_uint32),
+                ("cpu_total_raw", _P), ("mem_total", _P), ("core_lo", _P), ("core_hi", _P),
+                ("gres_slots", _P), ("schedulable", _P), ("part_offsets", _P), ("part_nodes", _P),
+                ("gres", CnsGresLayout)]
+
+
+class CnsRunningSoa(C.Structure):
+    _fields_ = [("num_jobs", C.c_uint32), ("num_allocs", C.c_uint32), ("end_sec", _P),
+                ("alloc_offsets", _P), ("alloc_node", _P), ("alloc_cpu_raw", _P), ("alloc_mem", _P),
+                ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P)]
+
+
+class CnsJobSoa(C.Structure):
+    _fields_ = [("num_jobs", C.c_uint64), ("partition", _P), ("time_limit_sec", _P),
+                ("node_cpu_raw", _P), ("node_mem", _P), ("task_cpu_raw", _P), ("task_mem", _P),
+                ("node_num", _P), ("ntasks", _P), ("ntasks_per_node_min", _P),
+                ("ntasks_per_node_max", _P), ("exclusive", _P), ("gres_total", _P),
+                ("gres_spec", _P), ("incl_offsets", _P), ("incl_nodes", _P), ("excl_offsets", _P),
+                ("excl_nodes", _P), ("skip", _P)]
+
+
+class CnsPlacementSoa(C.Structure):
+    _fields_ = [("place_capacity", C.c_uint64), ("start_sec", _P), ("reason", _P),
+                ("place_offsets", _P), ("node_idx", _P), ("ntasks", _P), ("cpu_raw", _P),
+                ("mem", _P), ("core_lo", _P), ("core_hi", _P), ("gres", _P)]
+
+
+class CnsTiming(C.Structure):
+    _fields_ = [("h2d_ms", C.c_double), ("init_ms", C.c_double), ("select_ms", C.c_double),
+                ("d2h_ms", C.c_double), ("jobs_ordered", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64)]
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_P)
+
+
+def _arr(x, dtype, n=None):
+    a = np.ascontiguousarray(x, dtype=dtype)
+    if n is not None and a.shape[0] != n:
+        raise ValueError(f"expected leading dim {n}, got {a.shape}")
+    return a
+
+
+@dataclass
+class GresLayout:
+    """(name,type) classes of the 64-bit GRES slot mask."""
+    class_name: list = field(default_factory=list)   # name-group id per class
+    class_shift: list = field(default_factory=list)
+    class_width: list = field(default_factory=list)
+
+    def to_c(self) -> CnsGresLayout:
+        g = CnsGresLayout()
+        g.num_classes = len(self.class_name)
+        for i, (a, s, w) in enumerate(zip(self.class_name, self.class_shift, self.class_width)):
+            g.class_name[i], g.class_shift[i], g.class_width[i] = a, s, w
+        return g
+
+    def class_mask(self, g: int) -> int:
+        return ((1 << self.class_width[g]) - 1) << self.class_shift[g]
+
+
+@dataclass
+class Cluster:
+    """Per-cycle node snapshot (cns_node_soa)."""
+    cpu_total_raw: np.ndarray
+    mem_total: np.ndarray
+    core_lo: np.ndarray
+    core_hi: np.ndarray
+    gres_slots: np.ndarray
+    part_offsets: np.ndarray
+    part_nodes: np.ndarray
+    gres: GresLayout = field(default_factory=GresLayout)
+    schedulable: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        n = len(self.cpu_total_raw)
+        self.cpu_total_raw = _arr(self.cpu_total_raw, np.int64)
+        self.mem_total = _arr(self.mem_total, np.uint64, n)
+        self.core_lo = _arr(self.core_lo, np.uint64, n)
+        self.core_hi = _arr(self.core_hi, np.uint64, n)
+        self.gres_slots = _arr(self.gres_slots, np.uint64, n)
+        self.part_offsets = _arr(self.part_offsets, np.uint32)
+        self.part_nodes = _arr(self.part_nodes, np.uint32)
+        if self.schedulable is not None:
+            self.schedulable = _arr(self.schedulable, np.uint8, n)
+
+    @property
+    def num_nodes(self):
+        return len(self.cpu_total_raw)
+
+    @property
+    def num_partitions(self):
+        return len(self.part_offsets) - 1
+
+    def to_c(self) -> CnsNodeSoa:
+        s = CnsNodeSoa()
+        s.num_nodes, s.num_partitions = self.num_nodes, self.num_partitions
+        s.cpu_total_raw, s.mem_total = _ptr(self.cpu_total_raw), _ptr(self.mem_total)
+        s.core_lo, s.core_hi, s.gres_slots = _ptr(self.core_lo), _ptr(self.core_hi), _ptr(self.gres_slots)
+        s.schedulable = _ptr(self.schedulable)
+        s.part_offsets, s.part_nodes = _ptr(self.part_offsets), _ptr(self.part_nodes)
+        s.gres = self.gres.to_c()
+        return s
+
+
+@dataclass
+class Running:
+    """Running jobs' allocations (cns_running_soa)."""
+    end_sec: np.ndarray
+    alloc_offsets: np.ndarray
+    alloc_node: np.ndarray
+    alloc_cpu_raw: np.ndarray
+    alloc_mem: np.ndarray
+    alloc_core_lo: np.ndarray
+    alloc_core_hi: np.ndarray
+    alloc_gres: np.ndarray
+
+    def __post_init__(self):
+        self.end_sec = _arr(self.end_sec, np.int64)
+        self.alloc_offsets = _arr(self.alloc_offsets, np.uint32, len(self.end_sec) + 1)
+        m = int(self.alloc_offsets[-1]) if len(self.alloc_offsets) else 0
+        self.alloc_node = _arr(self.alloc_node, np.uint32, m)
+        self.alloc_cpu_raw = _arr(self.alloc_cpu_raw, np.int64, m)
+        self.alloc_mem = _arr(self.alloc_mem, np.uint64, m)
+        self.alloc_core_lo = _arr(self.alloc_core_lo, np.uint64, m)
+        self.alloc_core_hi = _arr(self.alloc_core_hi, np.uint64, m)
+        self.alloc_gres = _arr(self.alloc_gres, np.uint64, m)
+
+    def to_c(self) -> CnsRunningSoa:
+        s = CnsRunningSoa()
+        s.num_jobs, s.num_allocs = len(self.end_sec), len(self.alloc_node)
+        s.end_sec, s.alloc_offsets, s.alloc_node = _ptr(self.end_sec), _ptr(self.alloc_offsets), _ptr(self.alloc_node)
+        s.alloc_cpu_raw, s.alloc_mem = _ptr(self.alloc_cpu_raw), _ptr(self.alloc_mem)
+        s.alloc_core_lo, s.alloc_core_hi, s.alloc_gres = _ptr(self.alloc_core_lo), _ptr(self.alloc_core_hi), _ptr(self.alloc_gres)
+        return s
+
+
+@dataclass
+class Jobs:
+    """Pending jobs in priority order (cns_job_soa)."""
+    partition: np.ndarray
+    time_limit_sec: np.ndarray
+    node_mem: np.ndarray
+    task_cpu_raw: np.ndarray
+    task_mem: np.ndarray
+    node_num: np.ndarray
+    ntasks: np.ndarray
+    ntasks_per_node_min: np.ndarray
+    ntasks_per_node_max: np.ndarray
+    node_cpu_raw: Optional[np.ndarray] = None
+    exclusive: Optional[np.ndarray] = None
+    gres_total: Optional[np.ndarray] = None   # [J, 4] uint8
+    gres_spec: Optional[np.ndarray] = None    # [J, 8] uint8
+    incl_offsets: Optional[np.ndarray] = None
+    incl_nodes: Optional[np.ndarray] = None
+    excl_offsets: Optional[np.ndarray] = None
+    excl_nodes: Optional[np.ndarray] = None
+    skip: Optional[np.ndarray] = None
+
+    def __post_init__(self):
+        j = len(self.partition)
+        self.partition = _arr(self.partition, np.uint32)
+        self.time_limit_sec = _arr(self.time_limit_sec, np.int64, j)
+        self.node_mem = _arr(self.node_mem, np.uint64, j)
+        self.task_cpu_raw = _arr(self.task_cpu_raw, np.int64, j)
+        self.task_mem = _arr(self.task_mem, np.uint64, j)
+        self.node_num = _arr(self.node_num, np.uint32, j)
+        self.ntasks = _arr(self.ntasks, np.uint32, j)
+        self.ntasks_per_node_min = _arr(self.ntasks_per_node_min, np.uint32, j)
+        self.ntasks_per_node_max = _arr(self.ntasks_per_node_max, np.uint32, j)
+        for name, dt in (("node_cpu_raw", np.int64), ("exclusive", np.uint8), ("skip", np.uint8)):
+            v = getattr(self, name)
+            if v is not None:
+                setattr(self, name, _arr(v, dt, j))
+        if self.gres_total is not None:
+            self.gres_total = _arr(self.gres_total, np.uint8, j).reshape(j, MAX_GRES_NAMES)
+        if self.gres_spec is not None:
+            self.gres_spec = _arr(self.gres_spec, np.uint8, j).reshape(j, MAX_GRES_CLASSES)
+        for off, lst in (("incl_offsets", "incl_nodes"), ("excl_offsets", "excl_nodes")):
+            if getattr(self, off) is not None:
+                setattr(self, off, _arr(getattr(self, off), np.uint64, j + 1))
+                setattr(self, lst, _arr(getattr(self, lst), np.uint32))
+
+    @property
+    def num_jobs(self):
+        return len(self.partition)
+
+    def total_places(self) -> int:
+        return int(self.node_num.astype(np.uint64).sum())
+
+    def to_c(self) -> CnsJobSoa:
+        s = CnsJobSoa()
+        s.num_jobs = self.num_jobs
+        for f, _ in CnsJobSoa._fields_[1:]:
+            setattr(s, f, _ptr(getattr(self, f)))
+        return s
+
+
+class Placements:
+    """Caller-allocated result arrays (cns_placement_soa)."""
+
+    def __init__(self, num_jobs: int, capacity: int):
+        self.num_jobs, self.capacity = num_jobs, capacity
+        cap = max(capacity, 1)
+        self.start_sec = np.zeros(max(num_jobs, 1), np.int64)
+        self.reason = np.zeros(max(num_jobs, 1), np.uint8)
+        self.place_offsets = np.zeros(num_jobs + 1, np.uint64)
+        self.node_idx = np.full(cap, NODE_NONE, np.uint32)
+        self.ntasks = np.zeros(cap, np.uint32)
+        self.cpu_raw = np.zeros(cap, np.int64)
+        self.mem = np.zeros(cap, np.uint64)
+        self.core_lo = np.zeros(cap, np.uint64)
+        self.core_hi = np.zeros(cap, np.uint64)
+        self.gres = np.zeros(cap, np.uint64)
+
+    def to_c(self) -> CnsPlacementSoa:
+        s = CnsPlacementSoa()
+        s.place_capacity = self.capacity
+        for f, _ in CnsPlacementSoa._fields_[1:]:
+            setattr(s, f, _ptr(getattr(self, f)))
+        return s
+
+    FIELDS = ("start_sec", "reason", "place_offsets", "node_idx", "ntasks", "cpu_raw", "mem",
+              "core_lo", "core_hi", "gres")
+
+    def trimmed(self):
+        """Dict of result arrays cut to their logical lengths (for comparisons / hashing)."""
+        j, c = self.num_jobs, self.capacity
+        return {"start_sec": self.start_sec[:j], "reason": self.reason[:j],
+                "place_offsets": self.place_offsets[:j + 1], "node_idx": self.node_idx[:c],
+                "ntasks": self.ntasks[:c], "cpu_raw": self.cpu_raw[:c], "mem": self.mem[:c],
+                "core_lo": self.core_lo[:c], "core_hi": self.core_hi[:c], "gres": self.gres[:c]}
+
+    def diff(self, other: "Placements"):
+        """First differing (field, index) between two results, or None if bit-identical."""
+        a, b = self.trimmed(), other.trimmed()
+        for k in self.FIELDS:
+            if a[k].shape != b[k].shape:
+                return (k, "shape", a[k].shape, b[k].shape)
+            ne = np.nonzero(a[k] != b[k])[0]
+            if len(ne):
+                i = int(ne[0])
+                return (k, i, a[k][i].item(), b[k][i].item(), f"{len(ne)} mismatches")
+        return None

@@ -1,0 +1,120 @@
+"""Frozen synthetic queues C1..C5 (SURVEY.md §8d / BASELINE.md §3).
+
+PRNG = splitmix64, seed 0x43524E45 ^ config index; draw f of job j is
+mix(seed + GAMMA*(j*NF + f + 1)).  No running jobs, now = 1_700_000_000, FIFO order.
+The reference has no workload generator; these distributions are the ones
+BASELINE.md records for this project and are the same for the oracle and the engine.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .abi import Cluster, GresLayout, Jobs, MAX_GRES_CLASSES, MAX_GRES_NAMES
+
+NOW = 1_700_000_000
+SEED0 = 0x43524E45
+GAMMA = np.uint64(0x9E3779B97F4A7C15)
+GIB = 1 << 30
+NF = 8  # random draws per job
+
+CONFIGS = {
+    # name: (index, J, N, P, gres, slot quantum, max L multiples)
+    "C1": dict(idx=1, J=1_000, N=128, P=1, gres=False, Q=600, LM=24),
+    "C2": dict(idx=2, J=100_000, N=4_096, P=1, gres=False, Q=600, LM=24),
+    "C3": dict(idx=3, J=1_000_000, N=16_384, P=1, gres=True, Q=600, LM=24),
+    "C4": dict(idx=4, J=1_000_000, N=65_536, P=8, gres=True, Q=600, LM=24),
+    "C5": dict(idx=5, J=1_000_000, N=65_536, P=8, gres=False, Q=675, LM=32),
+}
+
+
+def splitmix64(seed: int, n: int) -> np.ndarray:
+    """n outputs of splitmix64 started at `seed` (vectorised)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed) + GAMMA * np.arange(1, n + 1, dtype=np.uint64)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def gres_layout_gpu_npu() -> GresLayout:
+    # class 0 = gpu:mi300 (name 0) bits 0..7 ; class 1 = npu:a910 (name 1) bits 8..15
+    return GresLayout(class_name=[0, 1], class_shift=[0, 8], class_width=[8, 8])
+
+
+def make_cluster(N: int, P: int, gres: bool) -> Cluster:
+    """Nodes: without GRES all 64c/256GiB; with GRES node i%4 in {0,1}: 64c/256GiB,
+    2: 96c/1TiB + 8 x gpu:mi300, 3: 96c/1TiB + 8 x npu:a910.  P disjoint contiguous partitions."""
+    idx = np.arange(N)
+    kind = (idx % 4) if gres else np.zeros(N, np.int64)
+    big = kind >= 2
+    cores = np.where(big, 96, 64)
+    cpu_total_raw = (cores * 256).astype(np.int64)
+    mem_total = np.where(big, 1024 * GIB, 256 * GIB).astype(np.uint64)
+    core_lo = np.full(N, np.uint64(0xFFFFFFFFFFFFFFFF), np.uint64)
+    core_hi = np.where(big, np.uint64(0xFFFFFFFF), np.uint64(0)).astype(np.uint64)
+    gres_slots = np.where(kind == 2, np.uint64(0xFF), np.where(kind == 3, np.uint64(0xFF00), np.uint64(0))).astype(np.uint64)
+    assert N % P == 0
+    per = N // P
+    part_offsets = (np.arange(P + 1) * per).astype(np.uint32)
+    part_nodes = idx.astype(np.uint32)
+    return Cluster(cpu_total_raw, mem_total, core_lo, core_hi, gres_slots, part_offsets, part_nodes,
+                   gres=gres_layout_gpu_npu() if gres else GresLayout())
+
+
+def make_jobs(J: int, P: int, gres: bool, seed: int, Q: int, LM: int) -> Jobs:
+    r = splitmix64(seed, J * NF).reshape(J, NF) >> np.uint64(11)
+    cpus = np.array([1, 2, 4, 8], np.int64)[(r[:, 0] % np.uint64(4)).astype(np.int64)]
+    L = (Q * (1 + (r[:, 1] % np.uint64(LM)).astype(np.int64))).astype(np.int64)
+    partition = (r[:, 2] % np.uint64(P)).astype(np.uint32)
+    if gres:
+        kd = (r[:, 3] % np.uint64(30)).astype(np.int64)          # 27/30 -> k=1, 1/30 each -> 2,4,8
+        k = np.where(kd < 27, 1, np.where(kd == 27, 2, np.where(kd == 28, 4, 8))).astype(np.uint32)
+        cls = (r[:, 4] % np.uint64(10)).astype(np.int64)         # 0..6 cpu-only, 7,8 gpu, 9 npu
+        cnt = np.array([1, 2, 4, 8], np.uint8)[(r[:, 5] % np.uint64(4)).astype(np.int64)]
+        typed = (r[:, 6] % np.uint64(2)).astype(bool)
+        gres_total = np.zeros((J, MAX_GRES_NAMES), np.uint8)
+        gres_spec = np.zeros((J, MAX_GRES_CLASSES), np.uint8)
+        is_gpu, is_npu = (cls == 7) | (cls == 8), cls == 9
+        gres_total[is_gpu, 0] = cnt[is_gpu]
+        gres_total[is_npu, 1] = cnt[is_npu]
+        gres_spec[is_gpu & typed, 0] = cnt[is_gpu & typed]
+        gres_spec[is_npu & typed, 1] = cnt[is_npu & typed]
+    else:
+        k = np.ones(J, np.uint32)
+        gres_total = gres_spec = None
+    ones = np.ones(J, np.uint32)
+    return Jobs(partition=partition, time_limit_sec=L, node_mem=np.zeros(J, np.uint64),
+                task_cpu_raw=cpus * 256, task_mem=(cpus * 2 * GIB).astype(np.uint64),
+                node_num=k, ntasks=k.copy(), ntasks_per_node_min=ones, ntasks_per_node_max=ones.copy(),
+                gres_total=gres_total, gres_spec=gres_spec)
+
+
+def make_config(name: str, J: int | None = None, N: int | None = None, P: int | None = None):
+    """Returns (cluster, jobs, now) of config `name`, optionally scaled to J jobs / N nodes / P partitions
+    (same distributions and seed; used for parity cases the CPU oracle finishes in seconds)."""
+    c = CONFIGS[name]
+    J = c["J"] if J is None else J
+    N = c["N"] if N is None else N
+    P = c["P"] if P is None else P
+    cluster = make_cluster(N, P, c["gres"])
+    jobs = make_jobs(J, P, c["gres"], SEED0 ^ c["idx"], c["Q"], c["LM"])
+    return cluster, jobs, NOW
+
+
+def select_partitions(cluster: Cluster, jobs: Jobs, parts: list[int]):
+    """Shard of a queue: the jobs (order preserved) and node lists of `parts` only, with node and
+    partition indices unchanged.  Used to job-shard disjoint partitions across GPUs."""
+    keep = np.isin(jobs.partition, np.asarray(parts, np.uint32))
+    idx = np.nonzero(keep)[0]
+
+    def take(a):
+        return None if a is None else a[idx]
+
+    sub = Jobs(partition=jobs.partition[idx], time_limit_sec=jobs.time_limit_sec[idx],
+               node_mem=jobs.node_mem[idx], task_cpu_raw=jobs.task_cpu_raw[idx], task_mem=jobs.task_mem[idx],
+               node_num=jobs.node_num[idx], ntasks=jobs.ntasks[idx],
+               ntasks_per_node_min=jobs.ntasks_per_node_min[idx],
+               ntasks_per_node_max=jobs.ntasks_per_node_max[idx], node_cpu_raw=take(jobs.node_cpu_raw),
+               exclusive=take(jobs.exclusive), gres_total=take(jobs.gres_total), gres_spec=take(jobs.gres_spec),
+               skip=take(jobs.skip))
+    return sub, idx

@@ -1,0 +1,218 @@
+/*
+ * crane_gpu/node_select.h — C ABI of the MI355X node-selection engine.
+ *
+ * This is the drop-in boundary for CraneCtld's pending-job x node matching
+ * hot path.  Everything here is plain C: pointers, sizes, fixed-width ints.
+ * No torch / HIP types appear in any signature (streams are `void*`).
+ *
+ * What it replaces in the reference (paths relative to the CraneSched tree):
+ *   - SchedulerAlgo::NodeSelect            src/CraneCtld/JobScheduler.cpp:6507-6836
+ *     (declared src/CraneCtld/JobScheduler.h:260-263, called once per cycle
+ *      from JobScheduler::ScheduleThread_, JobScheduler.cpp:1441)
+ *   - LocalScheduler::GetNodesAndTrySchedule_ / Backfill_
+ *                                          src/CraneCtld/JobScheduler.cpp:6147-6376
+ *   - NodeState / NodeSelector / MinCpuTimeRatioFirst
+ *                                          src/CraneCtld/JobScheduler.h:41-55,272-595
+ *   - ResourceView::GetFeasibleResourceInNode, ResourceInNodeV3::Ckmin, <=, +=, -=
+ *                                          src/Utilities/PublicHeader/PublicHeader.cpp:519-599,781-827,886-890
+ *
+ * The reference has no FFI for this path (SchedulerAlgo is a concrete C++
+ * class); the C++ adapter in cranesched_amd/host/ exposes `INodeSelectionAlgo`
+ * with the reference's NodeSelect signature and calls these entry points.
+ * INTEGRATION.md shows the binding a CraneCtld maintainer would add.
+ *
+ * Canonical integer model:
+ *   cpu    : int64 raw fixed point, value*256   (cpu_t = fpm::fixed<int64,__int128,8>,
+ *            src/Utilities/PublicHeader/include/crane/PublicHeader.h:44)
+ *   mem    : uint64 bytes (mem_sw is never tested on this path and is not carried)
+ *   cores  : 128-bit mask over core ids 0..127 (core_lo = ids 0..63, core_hi = 64..127)
+ *   gres   : 64-bit slot mask; class g = (name,type) owns bits
+ *            [class_shift[g], class_shift[g]+class_width[g]); bit order inside a
+ *            class = lexicographic order of the slot's device path (the order of
+ *            std::set<SlotId>, PublicHeader.h:425-428)
+ *   time   : int64 seconds; "now" is whole seconds (JobScheduler.cpp:1351)
+ *   node   : dense index 0..num_nodes-1; cost ties break on the ascending dense
+ *            index (canonical replacement for the reference's pointer order,
+ *            JobScheduler.h:594)
+ *
+ * Threading: one caller thread per handle, not re-entrant (matches
+ * ScheduleThread, JobScheduler.cpp:1322).  All functions return 0 on success
+ * and a negative cns_status on error; they never throw and never abort.
+ * There is NO CPU fallback: if no HIP device is usable cns_create fails.
+ */
+#ifndef CRANE_GPU_NODE_SELECT_H_
+#define CRANE_GPU_NODE_SELECT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CNS_ABI_VERSION 1u
+#define CNS_MAX_GRES_CLASSES 8u
+#define CNS_MAX_GRES_NAMES 4u
+#define CNS_MAX_NODE_TYPES 64u /* distinct res_total records per cycle */
+#define CNS_NODE_NONE 0xFFFFFFFFu
+#define CNS_TIME_INFINITE_FUTURE INT64_MAX /* absl::InfiniteFuture(), JobScheduler.h:302 */
+
+typedef enum cns_status {
+  CNS_OK = 0,
+  CNS_ERR_INVALID_ARG = -1,
+  CNS_ERR_NO_DEVICE = -2,   /* no usable HIP device: the engine never falls back to CPU */
+  CNS_ERR_HIP = -3,         /* a HIP runtime call failed; see cns_last_error */
+  CNS_ERR_UNSUPPORTED = -4, /* input outside the engine's documented limits */
+  CNS_ERR_STATE = -5,       /* call order violated (e.g. select before set_nodes) */
+  CNS_ERR_DEVICE_FAULT = -6 /* kernel reported an internal invariant violation */
+} cns_status;
+
+/* Pending reason codes <-> the reference's reason strings
+ * (JobScheduler.h:133,138; values set at JobScheduler.cpp:6750-6831, JobScheduler.h:198). */
+typedef enum cns_reason {
+  CNS_REASON_NONE = 0,               /* ""  : is_scheduled(), starts now            */
+  CNS_REASON_PRIORITY = 1,           /* "Priority"                                   */
+  CNS_REASON_RESOURCE = 2,           /* "Resource"                                   */
+  CNS_REASON_RESOURCE_RESERVED = 3,  /* "Resource Reserved" (needs reservations)     */
+  CNS_REASON_PARTITION_NOT_FOUND = 4,/* "Partition Not Found"                        */
+  CNS_REASON_SKIPPED = 5             /* caller pre-set a reason (e.g. "License")     */
+} cns_reason;
+
+/* Scheduler constants (JobScheduler.h:266-270, CtldPublicDefs.h:82-83). */
+typedef struct cns_config {
+  uint32_t abi_version;           /* must be CNS_ABI_VERSION                          */
+  int32_t device;                 /* HIP device ordinal                               */
+  uint64_t scheduled_batch_size;  /* g_config.ScheduledBatchSize; 0 = unlimited       */
+  uint32_t max_job_num_per_node;  /* kAlgoMaxJobNumPerNode; 0 -> 1000                 */
+  uint32_t reserved0;
+  int64_t max_time_window_sec;    /* kAlgoMaxTimeWindow; 0 -> 7*24*3600               */
+} cns_config;
+
+/* (name,type) -> slot-bit layout of the 64-bit GRES mask; fixed per handle cycle. */
+typedef struct cns_gres_layout {
+  uint32_t num_classes;                       /* <= CNS_MAX_GRES_CLASSES              */
+  uint8_t class_name[CNS_MAX_GRES_CLASSES];   /* name-group id < CNS_MAX_GRES_NAMES   */
+  uint8_t class_shift[CNS_MAX_GRES_CLASSES];
+  uint8_t class_width[CNS_MAX_GRES_CLASSES];  /* classes must not overlap             */
+} cns_gres_layout;
+
+/* Per-cycle node snapshot = what NodeSelect's prologue copies out of
+ * CranedMetaContainer (JobScheduler.cpp:6563-6617; CranedMeta NodeDefs.h:59-81). */
+typedef struct cns_node_soa {
+  uint32_t num_nodes;
+  uint32_t num_partitions;
+  const int64_t* cpu_total_raw;   /* [num_nodes] res_total cpu_count raw             */
+  const uint64_t* mem_total;      /* [num_nodes]                                     */
+  const uint64_t* core_lo;        /* [num_nodes] res_total core ids 0..63            */
+  const uint64_t* core_hi;        /* [num_nodes] core ids 64..127 (may be NULL = 0)  */
+  const uint64_t* gres_slots;     /* [num_nodes] may be NULL = 0                     */
+  const uint8_t* schedulable;     /* [num_nodes] alive && !drain (JobScheduler.cpp:6595); NULL = all */
+  const uint32_t* part_offsets;   /* [num_partitions+1] CSR into part_nodes          */
+  const uint32_t* part_nodes;     /* node indices, ascending inside each partition   */
+  cns_gres_layout gres;
+} cns_node_soa;
+
+/* Running jobs' per-node allocations (RnJobInScheduler, JobScheduler.h:57-90;
+ * folded at JobScheduler.cpp:6513-6514,6681-6709). Order is significant: the
+ * initial fp64 cost is accumulated in this order (JobScheduler.h:508-510). */
+typedef struct cns_running_soa {
+  uint32_t num_jobs;
+  uint32_t num_allocs;
+  const int64_t* end_sec;         /* [num_jobs] end_time                             */
+  const uint32_t* alloc_offsets;  /* [num_jobs+1] CSR into alloc_*                   */
+  const uint32_t* alloc_node;
+  const int64_t* alloc_cpu_raw;
+  const uint64_t* alloc_mem;
+  const uint64_t* alloc_core_lo;
+  const uint64_t* alloc_core_hi;  /* may be NULL */
+  const uint64_t* alloc_gres;     /* may be NULL */
+} cns_running_soa;
+
+/* Pending jobs in priority order (PdJobInScheduler, JobScheduler.h:92-170).
+ * FIFO = ascending job id = input order (BasicPriority, JobScheduler.h:183-201). */
+typedef struct cns_job_soa {
+  uint64_t num_jobs;
+  const uint32_t* partition;        /* [J] partition index; >= num_partitions => "Partition Not Found" */
+  const int64_t* time_limit_sec;    /* [J] > 0                                       */
+  const int64_t* node_cpu_raw;      /* [J] req_node_res_view cpu (reference asserts 0, JobScheduler.cpp:7047); NULL = 0 */
+  const uint64_t* node_mem;         /* [J] req_node_res_view mem                     */
+  const int64_t* task_cpu_raw;      /* [J] req_task_res_view cpu                     */
+  const uint64_t* task_mem;         /* [J] req_task_res_view mem                     */
+  const uint32_t* node_num;         /* [J] >= 1                                      */
+  const uint32_t* ntasks;           /* [J] >= node_num                               */
+  const uint32_t* ntasks_per_node_min; /* [J] >= 1 (finalised, JobScheduler.cpp:7125-7139) */
+  const uint32_t* ntasks_per_node_max; /* [J] >= min                                 */
+  const uint8_t* exclusive;         /* [J] NULL = 0                                  */
+  const uint8_t* gres_total;        /* [J][CNS_MAX_GRES_NAMES] per-name GresCount.total of req_node_res_view; NULL = none */
+  const uint8_t* gres_spec;         /* [J][CNS_MAX_GRES_CLASSES] per-class GresCount.specified; NULL = none */
+  const uint64_t* incl_offsets;     /* [J+1] CSR included_nodes; NULL = none         */
+  const uint32_t* incl_nodes;
+  const uint64_t* excl_offsets;     /* [J+1] CSR excluded_nodes; NULL = none         */
+  const uint32_t* excl_nodes;
+  const uint8_t* skip;              /* [J] non-zero: reason already set by the caller (JobScheduler.cpp:6744); NULL = 0 */
+} cns_job_soa;
+
+/* Results, caller-allocated. Job j owns records [place_offsets[j], place_offsets[j+1]),
+ * place_offsets = exclusive prefix sum of node_num (the engine fills it).  Records of
+ * one job are sorted by ascending node_idx; unused records carry CNS_NODE_NONE.
+ * For a job whose reason is RESOURCE with start_sec == 0 nothing was committed. */
+typedef struct cns_placement_soa {
+  uint64_t place_capacity;   /* >= sum(node_num)                                    */
+  int64_t* start_sec;        /* [J] 0 if no start time was found                    */
+  uint8_t* reason;           /* [J] cns_reason                                      */
+  uint64_t* place_offsets;   /* [J+1]                                               */
+  uint32_t* node_idx;        /* [place_capacity]                                    */
+  uint32_t* ntasks;          /* craned_id_to_task_num                               */
+  int64_t* cpu_raw;          /* allocated_res per node                              */
+  uint64_t* mem;
+  uint64_t* core_lo;
+  uint64_t* core_hi;
+  uint64_t* gres;
+} cns_placement_soa;
+
+/* Timing of the last cns_select / cns_run_resident (HIP events on the engine's stream). */
+typedef struct cns_timing {
+  double h2d_ms;          /* job table pack + upload                                 */
+  double init_ms;         /* node-state init kernel(s)                               */
+  double select_ms;       /* the persistent selection kernel                         */
+  double d2h_ms;          /* placement download                                      */
+  uint64_t jobs_ordered;  /* jobs given to the ordered loop (JobScheduler.cpp:6743)  */
+  uint64_t algorithmic_bytes; /* sum over ordered jobs of N_p*S_node + S_job + S_out */
+} cns_timing;
+
+typedef struct cns_engine cns_handle;
+
+int cns_abi_version(void);
+/* Human readable message of the last error on this handle (or of the last failed cns_create when h==NULL). */
+const char* cns_last_error(const cns_handle* h);
+
+int cns_create(const cns_config* cfg, cns_handle** out);
+void cns_destroy(cns_handle* h);
+
+/* Per-cycle snapshot. Copies everything; the caller keeps ownership of its buffers. */
+int cns_set_nodes(cns_handle* h, const cns_node_soa* nodes);
+int cns_set_running(cns_handle* h, const cns_running_soa* running); /* NULL or num_jobs==0: none */
+
+/* One scheduling cycle: pack+upload jobs, init node state, select, download placements.
+ * Equivalent of SchedulerAlgo::NodeSelect(now, running_jobs, pending_jobs). */
+int cns_select(cns_handle* h, int64_t now_sec, const cns_job_soa* jobs, cns_placement_soa* out);
+
+/* Split form used by the benchmark so that the timed region starts with inputs resident in HBM. */
+int cns_upload_jobs(cns_handle* h, const cns_job_soa* jobs);
+int cns_run_resident(cns_handle* h, int64_t now_sec);          /* init + select on device, synchronous */
+int cns_download(cns_handle* h, cns_placement_soa* out);
+/* Device pointer + byte size of the packed placement buffer of the last run (for RCCL allgather). */
+int cns_device_results(cns_handle* h, void** dptr, uint64_t* bytes);
+
+int cns_get_timing(const cns_handle* h, cns_timing* t);
+
+/* Parity / debugging: final per-node cost (fp64 bit patterns) and time-availability map. */
+int cns_debug_get_costs(cns_handle* h, double* cost_by_part_slot /* [len(part_nodes)] */);
+int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint32_t* len,
+                           int64_t* t, int64_t* cpu_raw, uint64_t* mem, uint64_t* core_lo,
+                           uint64_t* core_hi, uint64_t* gres);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRANE_GPU_NODE_SELECT_H_ */

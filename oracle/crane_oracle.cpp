@@ -1,0 +1,238 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see res_algebra.hpp). C entry points over the
+// templated restatement so that tests/, smoke() and bench.py's cpu_baseline leg can drive
+// it through ctypes with the very same SoA structs as the engine's C ABI
+// (include/crane_gpu/node_select.h).  Build: oracle/Makefile  ->  oracle/liboracle.so
+#include <chrono>
+#include <cstring>
+#include <string>
+
+#include "sched_oracle.hpp"
+
+using namespace ora;
+
+namespace {
+
+GresLayout layout_from(const cns_gres_layout& g) {
+  GresLayout L;
+  L.num_classes = g.num_classes;
+  for (u32 i = 0; i < CNS_MAX_GRES_CLASSES; ++i) {
+    L.class_name[i] = g.class_name[i];
+    L.class_shift[i] = g.class_shift[i];
+    L.class_width[i] = g.class_width[i];
+  }
+  return L;
+}
+
+struct OracleRun {
+  GresLayout layout;
+  std::unique_ptr<SchedOracle<MaskAlgebra>> mask;
+  std::unique_ptr<SchedOracle<LitAlgebra>> lit;
+  std::vector<std::vector<u32>> part_nodes;
+  double seconds = 0;
+  u64 jobs_ordered = 0;
+};
+
+template <class O>
+void emit(O& orc, std::vector<PdJob>& jobs, cns_placement_soa* out) {
+  u64 off = 0;
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    const PdJob& job = jobs[j];
+    out->place_offsets[j] = off;
+    out->start_sec[j] = job.start_time;
+    out->reason[j] = (uint8_t)job.reason;
+    u64 k = 0;
+    for (const auto& [nid, r] : job.allocated_res) {  // std::map: ascending node index
+      u64 q = off + k++;
+      out->node_idx[q] = nid;
+      out->ntasks[q] = job.craned_id_to_task_num.at(nid);
+      out->cpu_raw[q] = r.cpu;
+      out->mem[q] = r.mem;
+      out->core_lo[q] = r.clo;
+      out->core_hi[q] = r.chi;
+      out->gres[q] = r.gres;
+    }
+    for (; k < job.node_num; ++k) {
+      u64 q = off + k;
+      out->node_idx[q] = CNS_NODE_NONE;
+      out->ntasks[q] = 0;
+      out->cpu_raw[q] = 0;
+      out->mem[q] = 0;
+      out->core_lo[q] = out->core_hi[q] = out->gres[q] = 0;
+    }
+    off += job.node_num;
+  }
+  out->place_offsets[jobs.size()] = off;
+  (void)orc;
+}
+
+}  // namespace
+
+extern "C" {
+
+struct ora_res { int64_t cpu; uint64_t mem, clo, chi, gres; };
+struct ora_req { int64_t cpu; uint64_t mem; uint8_t gtot[CNS_MAX_GRES_NAMES]; uint8_t gspec[CNS_MAX_GRES_CLASSES]; };
+
+static MaskRes to_m(const ora_res& r) { MaskRes m; m.cpu = r.cpu; m.mem = r.mem; m.clo = r.clo; m.chi = r.chi; m.gres = r.gres; return m; }
+static ora_res from_m(const MaskRes& m) { return ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres}; }
+static ReqView to_v(const ora_req& q) {
+  ReqView v; v.cpu = q.cpu; v.mem = q.mem;
+  memcpy(v.gtot, q.gtot, sizeof v.gtot); memcpy(v.gspec, q.gspec, sizeof v.gspec);
+  return v;
+}
+
+// ---- resource-algebra primitives (algebra: 0 = mask, 1 = literal containers) -------------
+int ora_feasible(const cns_gres_layout* gl, int algebra, const ora_req* req, const ora_res* avail, ora_res* out) {
+  GresLayout L = layout_from(*gl);
+  if (algebra == 0) {
+    MaskAlgebra A(&L); MaskRes o;
+    bool ok = A.feasible(to_v(*req), to_m(*avail), &o);
+    if (ok) *out = from_m(o);
+    return ok;
+  }
+  LitAlgebra A(&L); LitRes o;
+  bool ok = A.feasible(to_v(*req), A.from_mask(to_m(*avail)), &o);
+  if (ok) *out = from_m(A.to_mask(o));
+  return ok;
+}
+int ora_binop(const cns_gres_layout* gl, int algebra, int op, const ora_res* a, const ora_res* b, ora_res* out) {
+  // op: 0 ckmin, 1 add, 2 sub, 3 le (returns bool)
+  GresLayout L = layout_from(*gl);
+  auto run = [&](auto A) -> int {
+    auto x = A.from_mask(to_m(*a));
+    auto y = A.from_mask(to_m(*b));
+    int ret = 0;
+    switch (op) {
+      case 0: A.ckmin(x, y); break;
+      case 1: A.add(x, y); break;
+      case 2: A.sub(x, y); break;
+      case 3: ret = A.le(x, y); break;
+    }
+    if (out) *out = from_m(A.to_mask(x));
+    return ret;
+  };
+  return algebra == 0 ? run(MaskAlgebra(&L)) : run(LitAlgebra(&L));
+}
+
+// ---- one scheduling cycle ---------------------------------------------------------------
+// Returns an opaque run handle through *run_out (free with ora_free) for the debug getters.
+int ora_select(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
+               int64_t now, const cns_job_soa* jobs, cns_placement_soa* out, int algebra,
+               void** run_out) {
+  auto run = std::make_unique<OracleRun>();
+  run->layout = layout_from(nodes->gres);
+  u32 maxjobs = cfg && cfg->max_job_num_per_node ? cfg->max_job_num_per_node : 1000;
+  i64 window = cfg && cfg->max_time_window_sec ? cfg->max_time_window_sec : 7 * 24 * 3600;
+  u64 batch = cfg ? cfg->scheduled_batch_size : 0;
+
+  std::vector<MaskRes> total(nodes->num_nodes);
+  std::vector<uint8_t> sched(nodes->num_nodes, 1);
+  for (u32 n = 0; n < nodes->num_nodes; ++n) {
+    total[n].cpu = nodes->cpu_total_raw[n];
+    total[n].mem = nodes->mem_total[n];
+    total[n].clo = nodes->core_lo ? nodes->core_lo[n] : 0;
+    total[n].chi = nodes->core_hi ? nodes->core_hi[n] : 0;
+    total[n].gres = nodes->gres_slots ? nodes->gres_slots[n] : 0;
+    if (nodes->schedulable) sched[n] = nodes->schedulable[n];
+  }
+  run->part_nodes.resize(nodes->num_partitions);
+  for (u32 p = 0; p < nodes->num_partitions; ++p)
+    for (u32 i = nodes->part_offsets[p]; i < nodes->part_offsets[p + 1]; ++i)
+      run->part_nodes[p].push_back(nodes->part_nodes[i]);
+
+  std::vector<RnJob> rn;
+  if (running) {
+    rn.resize(running->num_jobs);
+    for (u32 r = 0; r < running->num_jobs; ++r) {
+      rn[r].end_time = running->end_sec[r];
+      for (u32 a = running->alloc_offsets[r]; a < running->alloc_offsets[r + 1]; ++a) {
+        MaskRes m;
+        m.cpu = running->alloc_cpu_raw[a];
+        m.mem = running->alloc_mem[a];
+        m.clo = running->alloc_core_lo ? running->alloc_core_lo[a] : 0;
+        m.chi = running->alloc_core_hi ? running->alloc_core_hi[a] : 0;
+        m.gres = running->alloc_gres ? running->alloc_gres[a] : 0;
+        rn[r].allocs.push_back({running->alloc_node[a], m});
+      }
+    }
+  }
+
+  std::vector<PdJob> pd(jobs->num_jobs);
+  for (u64 j = 0; j < jobs->num_jobs; ++j) {
+    PdJob& q = pd[j];
+    q.partition = jobs->partition[j];
+    q.time_limit = jobs->time_limit_sec[j];
+    q.req_node.cpu = jobs->node_cpu_raw ? jobs->node_cpu_raw[j] : 0;
+    q.req_node.mem = jobs->node_mem[j];
+    q.req_task.cpu = jobs->task_cpu_raw[j];
+    q.req_task.mem = jobs->task_mem[j];
+    if (jobs->gres_total) memcpy(q.req_node.gtot, jobs->gres_total + j * CNS_MAX_GRES_NAMES, CNS_MAX_GRES_NAMES);
+    if (jobs->gres_spec) memcpy(q.req_node.gspec, jobs->gres_spec + j * CNS_MAX_GRES_CLASSES, CNS_MAX_GRES_CLASSES);
+    q.node_num = jobs->node_num[j];
+    q.ntasks = jobs->ntasks[j];
+    q.tpn_min = jobs->ntasks_per_node_min[j];
+    q.tpn_max = jobs->ntasks_per_node_max[j];
+    q.exclusive = jobs->exclusive ? jobs->exclusive[j] != 0 : false;
+    if (jobs->incl_offsets)
+      for (u64 i = jobs->incl_offsets[j]; i < jobs->incl_offsets[j + 1]; ++i) q.included_nodes.insert(jobs->incl_nodes[i]);
+    if (jobs->excl_offsets)
+      for (u64 i = jobs->excl_offsets[j]; i < jobs->excl_offsets[j + 1]; ++i) q.excluded_nodes.insert(jobs->excl_nodes[i]);
+    q.skip = jobs->skip ? jobs->skip[j] != 0 : false;
+  }
+
+  auto t0 = std::chrono::steady_clock::now();  // the reference's own bracket, JobScheduler.cpp:1439-1447
+  if (algebra == 0) {
+    run->mask = std::make_unique<SchedOracle<MaskAlgebra>>(MaskAlgebra(&run->layout), maxjobs, window);
+    run->mask->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch);
+    run->jobs_ordered = run->mask->jobs_ordered();
+  } else {
+    run->lit = std::make_unique<SchedOracle<LitAlgebra>>(LitAlgebra(&run->layout), maxjobs, window);
+    run->lit->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch);
+    run->jobs_ordered = run->lit->jobs_ordered();
+  }
+  run->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+  if (out) {
+    if (run->mask) emit(*run->mask, pd, out);
+    else emit(*run->lit, pd, out);
+  }
+  if (run_out) *run_out = run.release();
+  return 0;
+}
+
+double ora_seconds(void* h) { return static_cast<OracleRun*>(h)->seconds; }
+uint64_t ora_jobs_ordered(void* h) { return static_cast<OracleRun*>(h)->jobs_ordered; }
+
+int ora_get_costs(void* h, double* cost_by_part_slot) {
+  auto* run = static_cast<OracleRun*>(h);
+  size_t q = 0;
+  for (u32 p = 0; p < run->part_nodes.size(); ++p)
+    for (u32 n : run->part_nodes[p]) {
+      bool has = run->mask ? run->mask->HasNode(n) : run->lit->HasNode(n);
+      cost_by_part_slot[q++] = !has ? 0.0 : (run->mask ? run->mask->CostOf(p, n) : run->lit->CostOf(p, n));
+    }
+  return 0;
+}
+
+int ora_get_timeline(void* h, uint32_t node, uint32_t capacity, uint32_t* len, int64_t* t,
+                     int64_t* cpu_raw, uint64_t* mem, uint64_t* core_lo, uint64_t* core_hi,
+                     uint64_t* gres) {
+  auto* run = static_cast<OracleRun*>(h);
+  auto dump = [&](auto& orc) {
+    if (!orc.HasNode(node)) { *len = 0; return 0; }
+    const auto& tl = orc.Timeline(node);
+    *len = (uint32_t)tl.size();
+    uint32_t i = 0;
+    for (const auto& [time, res] : tl) {
+      if (i >= capacity) break;
+      MaskRes m = orc.alg().to_mask(res);
+      t[i] = time; cpu_raw[i] = m.cpu; mem[i] = m.mem; core_lo[i] = m.clo; core_hi[i] = m.chi; gres[i] = m.gres;
+      ++i;
+    }
+    return 0;
+  };
+  return run->mask ? dump(*run->mask) : dump(*run->lit);
+}
+
+void ora_free(void* h) { delete static_cast<OracleRun*>(h); }
+
+}  // extern "C"

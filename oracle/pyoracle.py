@@ -1,0 +1,141 @@
+"""ctypes driver of the CPU oracle (oracle/liboracle.so).
+
+ORACLE = TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg, never from cranesched_amd/ (the product).  See
+oracle/res_algebra.hpp for what it restates and for its "parity unpinned" status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from cranesched_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MASK, LITERAL = 0, 1
+
+
+class OraRes(C.Structure):
+    _fields_ = [("cpu", C.c_int64), ("mem", C.c_uint64), ("clo", C.c_uint64), ("chi", C.c_uint64),
+                ("gres", C.c_uint64)]
+
+    def tup(self):
+        return (self.cpu, self.mem, self.clo, self.chi, self.gres)
+
+
+class OraReq(C.Structure):
+    _fields_ = [("cpu", C.c_int64), ("mem", C.c_uint64), ("gtot", C.c_uint8 * abi.MAX_GRES_NAMES),
+                ("gspec", C.c_uint8 * abi.MAX_GRES_CLASSES)]
+
+
+def build(force: bool = False) -> str:
+    path = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp")]
+    srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "node_select.h"))
+    stale = force or not os.path.exists(path) or any(
+        os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
+    if stale:
+        subprocess.run(["make", "-C", _HERE, "-B", "liboracle.so"], check=True, capture_output=True)
+    return path
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.ora_seconds.restype = C.c_double
+        _LIB.ora_jobs_ordered.restype = C.c_uint64
+        _LIB.ora_free.restype = None
+    return _LIB
+
+
+def make_req(cpu=0, mem=0, gtot=(), gspec=()) -> OraReq:
+    q = OraReq()
+    q.cpu, q.mem = cpu, mem
+    for i, v in enumerate(gtot):
+        q.gtot[i] = v
+    for i, v in enumerate(gspec):
+        q.gspec[i] = v
+    return q
+
+
+def make_res(cpu=0, mem=0, clo=0, chi=0, gres=0) -> OraRes:
+    return OraRes(cpu, mem, clo, chi, gres)
+
+
+def feasible(layout: abi.GresLayout, algebra: int, req: OraReq, avail: OraRes):
+    out = OraRes()
+    gl = layout.to_c()
+    ok = lib().ora_feasible(C.byref(gl), algebra, C.byref(req), C.byref(avail), C.byref(out))
+    return (bool(ok), out.tup() if ok else None)
+
+
+def binop(layout: abi.GresLayout, algebra: int, op: str, a: OraRes, b: OraRes):
+    code = {"ckmin": 0, "add": 1, "sub": 2, "le": 3}[op]
+    out = OraRes()
+    gl = layout.to_c()
+    ret = lib().ora_binop(C.byref(gl), algebra, code, C.byref(a), C.byref(b), C.byref(out))
+    return bool(ret) if op == "le" else out.tup()
+
+
+class OracleRun:
+    """Result of one oracle cycle; keeps the C++ state alive for cost / timeline queries."""
+
+    def __init__(self, handle, placements, cluster):
+        self._h, self.placements, self._cluster = handle, placements, cluster
+
+    @property
+    def seconds(self) -> float:
+        return lib().ora_seconds(self._h)
+
+    @property
+    def jobs_ordered(self) -> int:
+        return lib().ora_jobs_ordered(self._h)
+
+    def costs(self) -> np.ndarray:
+        c = np.zeros(len(self._cluster.part_nodes), np.float64)
+        lib().ora_get_costs(self._h, c.ctypes.data_as(C.c_void_p))
+        return c
+
+    def timeline(self, node: int, cap: int = 1100):
+        n = C.c_uint32(0)
+        t = np.zeros(cap, np.int64); cpu = np.zeros(cap, np.int64)
+        mem = np.zeros(cap, np.uint64); lo = np.zeros(cap, np.uint64)
+        hi = np.zeros(cap, np.uint64); g = np.zeros(cap, np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        lib().ora_get_timeline(self._h, C.c_uint32(node), C.c_uint32(cap), C.byref(n), p(t), p(cpu), p(mem),
+                               p(lo), p(hi), p(g))
+        k = n.value
+        return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k]}
+
+    def close(self):
+        if self._h:
+            lib().ora_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running | None = None,
+           algebra: int = MASK, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0,
+           max_time_window_sec: int = 0) -> OracleRun:
+    cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, 0, scheduled_batch_size, max_job_num_per_node, 0,
+                        max_time_window_sec)
+    out = abi.Placements(jobs.num_jobs, jobs.total_places())
+    cn, cj, co = cluster.to_c(), jobs.to_c(), out.to_c()
+    cr = running.to_c() if running is not None else None
+    h = C.c_void_p()
+    rc = lib().ora_select(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
+                          C.c_int64(now), C.byref(cj), C.byref(co), algebra, C.byref(h))
+    if rc != 0:
+        raise RuntimeError(f"ora_select failed: {rc}")
+    return OracleRun(h, out, cluster)
