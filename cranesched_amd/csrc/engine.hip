@@ -1,0 +1,635 @@
+// Host side of the C ABI (include/crane_gpu/node_select.h): validation, SoA packing, HBM residency,
+// kernel launches and timing.  No scheduling decision is taken on the host and there is no CPU
+// fallback: without a usable HIP device cns_create fails with CNS_ERR_NO_DEVICE.
+//
+// Reference counterparts of the host-side packing (all in src/CraneCtld/JobScheduler.cpp):
+//   split of the pending queue by partition            :6516-6530
+//   partition -> node list, skip !alive || drain       :6569-6617
+//   running jobs' per-node allocations                 :6681-6709
+//   BasicPriority truncation to ScheduledBatchSize     JobScheduler.h:185-200
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/crane_gpu/node_select.h"
+#include "engine_params.h"
+#include "select_kernels.hip"  // single translation unit: kernels + their launches (no -fgpu-rdc needed)
+
+using namespace cns;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes ? bytes : 16;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+struct cns_engine {
+  cns_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+
+  // cluster (host copies)
+  u32 N = 0, P = 0, S = 0, T = 0, max_np = 0;
+  bool big_nodes = false;  // any GRES or > 64 cores (48-byte node record in the traffic model)
+  std::vector<u32> part_off, slot_node, orig_pos_slot;  // orig_pos_slot: caller's part_nodes position -> slot or kNone
+  std::vector<u32> node_slot;
+  GresDev gres{};
+  bool have_nodes = false, have_jobs = false, have_run = false;
+
+  // device buffers
+  DevBuf d_part_off, d_slot_node, d_total, d_avail0, d_ntype, d_type_total, d_tl, d_tl_len, d_cost, d_fcpu,
+      d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_fault;
+  DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results;
+  // job table
+  u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
+  std::vector<u64> place_off;
+  struct JobPtrs {
+    size_t orig, L, ncpu, nmem, tcpu, tmem, k, ntasks, tmin, tmax, flags, gtot, gspec, incl_off, excl_off, place;
+  } jo{};
+  struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, total; } ro{};
+  cns_timing timing{};
+  i64 last_now = 0;
+};
+
+namespace {
+
+int fail(cns_engine* h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+#define HIPCHK(h, call)                                                                         \
+  do {                                                                                          \
+    hipError_t _e = (call);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return fail(h, CNS_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_e));           \
+  } while (0)
+
+template <class T>
+int upload(cns_engine* h, DevBuf& b, const std::vector<T>& v) {
+  HIPCHK(h, b.ensure(v.size() * sizeof(T)));
+  if (!v.empty()) HIPCHK(h, hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+size_t align16(size_t x) { return (x + 15) & ~size_t(15); }
+
+int build_gres(cns_engine* h, const cns_gres_layout& g) {
+  GresDev d{};
+  if (g.num_classes > CNS_MAX_GRES_CLASSES) return fail(h, CNS_ERR_INVALID_ARG, "gres.num_classes > 8");
+  d.num_classes = g.num_classes;
+  u64 seen = 0;
+  for (u32 c = 0; c < g.num_classes; ++c) {
+    if (g.class_name[c] >= CNS_MAX_GRES_NAMES) return fail(h, CNS_ERR_INVALID_ARG, "gres class name id >= 4");
+    if (g.class_width[c] == 0 || g.class_shift[c] + g.class_width[c] > 64)
+      return fail(h, CNS_ERR_INVALID_ARG, "gres class bit range outside 64-bit mask");
+    u64 w = g.class_width[c] >= 64 ? ~0ull : ((1ull << g.class_width[c]) - 1ull);
+    u64 m = w << g.class_shift[c];
+    if (seen & m) return fail(h, CNS_ERR_INVALID_ARG, "gres classes overlap");
+    seen |= m;
+    d.class_mask[c] = m;
+    d.class_name_packed |= (u32)g.class_name[c] << (4 * c);
+    d.name_mask[g.class_name[c]] |= m;
+    d.name_bytes[g.class_name[c]] |= 0xFFull << (8 * c);
+  }
+  h->gres = d;
+  return 0;
+}
+
+void fill_params(cns_engine* h, KParams& K, i64 now) {
+  memset(&K, 0, sizeof K);
+  K.num_nodes = h->N; K.num_parts = h->P; K.num_slots = h->S; K.num_types = h->T;
+  K.tl_cap = kTlCap;
+  K.max_jobs_per_node = h->cfg.max_job_num_per_node;
+  K.now = now;
+  K.max_window = h->cfg.max_time_window_sec;
+  K.part_off = h->d_part_off.as<u32>();
+  K.slot_node = h->d_slot_node.as<u32>();
+  K.total = h->d_total.as<Res>();
+  K.avail0 = h->d_avail0.as<Res>();
+  K.ntype = h->d_ntype.as<uint8_t>();
+  K.type_total = h->d_type_total.as<Res>();
+  K.tl = h->d_tl.as<TlEntry>();
+  K.tl_len = h->d_tl_len.as<u32>();
+  K.cost = h->d_cost.as<double>();
+  K.f_cpu = h->d_fcpu.as<int>();
+  K.f_mem = h->d_fmem.as<u32>();
+  K.f_cnt = h->d_fcnt.as<u64>();
+  K.rn_off = h->d_rn_off.as<u32>();
+  K.rn_end = h->d_rn_end.as<i64>();
+  K.rn_res = h->d_rn_res.as<Res>();
+  K.pj_off = h->d_pj_off.as<u64>();
+  char* jb = h->d_jobs.as<char>();
+  K.j_orig = (const u32*)(jb + h->jo.orig);
+  K.j_L = (const i64*)(jb + h->jo.L);
+  K.j_ncpu = (const i64*)(jb + h->jo.ncpu);
+  K.j_nmem = (const u64*)(jb + h->jo.nmem);
+  K.j_tcpu = (const i64*)(jb + h->jo.tcpu);
+  K.j_tmem = (const u64*)(jb + h->jo.tmem);
+  K.j_k = (const u32*)(jb + h->jo.k);
+  K.j_ntasks = (const u32*)(jb + h->jo.ntasks);
+  K.j_tmin = (const u32*)(jb + h->jo.tmin);
+  K.j_tmax = (const u32*)(jb + h->jo.tmax);
+  K.j_flags = (const u32*)(jb + h->jo.flags);
+  K.j_gtot = (const u32*)(jb + h->jo.gtot);
+  K.j_gspec = (const u64*)(jb + h->jo.gspec);
+  K.j_incl_off = (const u64*)(jb + h->jo.incl_off);
+  K.j_excl_off = (const u64*)(jb + h->jo.excl_off);
+  K.j_place_off = (const u64*)(jb + h->jo.place);
+  K.incl_nodes = h->d_incl.as<u32>();
+  K.excl_nodes = h->d_excl.as<u32>();
+  char* rb = h->d_results.as<char>();
+  K.o_start = (i64*)(rb + h->ro.start);
+  K.o_cpu = (i64*)(rb + h->ro.cpu);
+  K.o_mem = (u64*)(rb + h->ro.mem);
+  K.o_clo = (u64*)(rb + h->ro.clo);
+  K.o_chi = (u64*)(rb + h->ro.chi);
+  K.o_gres = (u64*)(rb + h->ro.gres);
+  K.o_node = (u32*)(rb + h->ro.node);
+  K.o_ntasks = (u32*)(rb + h->ro.ntasks);
+  K.o_reason = (uint8_t*)(rb + h->ro.reason);
+  K.heap = h->d_heap.as<HeapEnt>();
+  K.bf_j = h->d_bfj.as<u32>();
+  K.fault = h->d_fault.as<u32>();
+  K.gres = h->gres;
+}
+
+template <int NPL>
+void launch_select(cns_engine* h, const KParams& K) {
+  hipLaunchKernelGGL((k_select<NPL>), dim3(h->P), dim3(kBlock), 0, h->stream, K);
+}
+
+}  // namespace
+
+extern "C" {
+
+int cns_abi_version(void) { return (int)CNS_ABI_VERSION; }
+
+const char* cns_last_error(const cns_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int cns_create(const cns_config* cfg, cns_handle** out) {
+  if (!cfg || !out) return fail(nullptr, CNS_ERR_INVALID_ARG, "cns_create: null argument");
+  if (cfg->abi_version != CNS_ABI_VERSION) return fail(nullptr, CNS_ERR_INVALID_ARG, "cns_create: ABI version mismatch");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    return fail(nullptr, CNS_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e) +
+                                                " (the engine has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, CNS_ERR_INVALID_ARG, "cns_create: bad device ordinal");
+  cns_engine* h = new (std::nothrow) cns_engine();
+  if (!h) return fail(nullptr, CNS_ERR_HIP, "out of host memory");
+  h->cfg = *cfg;
+  if (h->cfg.max_job_num_per_node == 0) h->cfg.max_job_num_per_node = 1000;  // kAlgoMaxJobNumPerNode
+  if (h->cfg.max_time_window_sec == 0) h->cfg.max_time_window_sec = 7 * 24 * 3600;  // kAlgoMaxTimeWindow
+  if (h->cfg.max_job_num_per_node + 2 > kTlCap) {
+    delete h;
+    return fail(nullptr, CNS_ERR_UNSUPPORTED, "max_job_num_per_node > 1006");
+  }
+  h->device = cfg->device;
+  if ((e = hipSetDevice(h->device)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess) {
+    std::string m = hipGetErrorString(e);
+    delete h;
+    return fail(nullptr, CNS_ERR_HIP, "device/stream init: " + m);
+  }
+  for (auto& ev : h->ev)
+    if ((e = hipEventCreate(&ev)) != hipSuccess) {
+      std::string m = hipGetErrorString(e);
+      cns_destroy(h);
+      return fail(nullptr, CNS_ERR_HIP, "hipEventCreate: " + m);
+    }
+  *out = h;
+  return CNS_OK;
+}
+
+void cns_destroy(cns_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_total, &h->d_avail0, &h->d_ntype, &h->d_type_total,
+                    &h->d_tl, &h->d_tl_len, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
+                    &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_fault, &h->d_pj_off, &h->d_jobs,
+                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results})
+    b->release();
+  for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
+  if (!h || !nd) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_nodes: null argument");
+  if (!nd->cpu_total_raw || !nd->mem_total || !nd->core_lo || !nd->part_offsets || (!nd->part_nodes && nd->part_offsets[nd->num_partitions]))
+    return fail(h, CNS_ERR_INVALID_ARG, "cns_set_nodes: missing array");
+  if (nd->num_nodes == 0 || nd->num_partitions == 0) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_nodes: empty cluster");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = build_gres(h, nd->gres)) return rc;
+  h->have_nodes = h->have_jobs = h->have_run = false;
+  const u32 N = nd->num_nodes, P = nd->num_partitions;
+  std::vector<Res> total(N);
+  u64 all_gres = 0;
+  for (u32 c = 0; c < h->gres.num_classes; ++c) all_gres |= h->gres.class_mask[c];
+  bool big = false;
+  for (u32 n = 0; n < N; ++n) {
+    total[n].cpu = nd->cpu_total_raw[n];
+    total[n].mem = nd->mem_total[n];
+    total[n].clo = nd->core_lo[n];
+    total[n].chi = nd->core_hi ? nd->core_hi[n] : 0;
+    total[n].gres = nd->gres_slots ? nd->gres_slots[n] : 0;
+    if (total[n].gres & ~all_gres) return fail(h, CNS_ERR_INVALID_ARG, "node GRES slot outside every class");
+    if (total[n].gres || total[n].chi) big = true;
+  }
+  // partitions: schedulable nodes only, ascending dense index (= canonical cost tie-break), disjoint
+  std::vector<u32> part_off(P + 1, 0), slot_node, node_slot(N, kNone);
+  const u32 total_pos = nd->part_offsets[P];
+  std::vector<u32> orig_pos_slot(total_pos, kNone);
+  u32 max_np = 0;
+  for (u32 p = 0; p < P; ++p) {
+    if (nd->part_offsets[p + 1] < nd->part_offsets[p]) return fail(h, CNS_ERR_INVALID_ARG, "part_offsets not monotone");
+    std::vector<std::pair<u32, u32>> lst;  // (node, original position)
+    for (u32 i = nd->part_offsets[p]; i < nd->part_offsets[p + 1]; ++i) {
+      u32 n = nd->part_nodes[i];
+      if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "part_nodes entry >= num_nodes");
+      if (nd->schedulable && !nd->schedulable[n]) continue;  // JobScheduler.cpp:6595
+      lst.emplace_back(n, i);
+    }
+    std::sort(lst.begin(), lst.end());
+    part_off[p] = (u32)slot_node.size();
+    for (auto& [n, pos] : lst) {
+      if (node_slot[n] != kNone)
+        return fail(h, CNS_ERR_UNSUPPORTED,
+                    "node " + std::to_string(n) + " belongs to more than one partition (overlapping partitions "
+                    "share a NodeState; not supported by this engine yet)");
+      if (total[n].cpu <= 0 || total[n].cpu >= 0x7FFFFFFEll)
+        return fail(h, CNS_ERR_UNSUPPORTED, "node cpu_total_raw must be in (0, 2^31-2)");
+      node_slot[n] = (u32)slot_node.size();
+      orig_pos_slot[pos] = (u32)slot_node.size();
+      slot_node.push_back(n);
+    }
+    max_np = std::max<u32>(max_np, (u32)lst.size());
+  }
+  part_off[P] = (u32)slot_node.size();
+  const u32 S = (u32)slot_node.size();
+  if (max_np > (u32)(kBlock - 64) * 18u)
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than 17280 schedulable nodes");
+  // node types = distinct res_total records
+  std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
+  std::vector<Res> type_total;
+  std::vector<uint8_t> ntype(N, 0);
+  for (u32 q = 0; q < S; ++q) {
+    const Res& r = total[slot_node[q]];
+    auto key = std::make_tuple(r.cpu, r.mem, r.clo, r.chi, r.gres);
+    auto it = tmap.find(key);
+    if (it == tmap.end()) {
+      if (type_total.size() >= CNS_MAX_NODE_TYPES)
+        return fail(h, CNS_ERR_UNSUPPORTED, "more than 64 distinct node res_total records");
+      it = tmap.emplace(key, (u32)type_total.size()).first;
+      type_total.push_back(r);
+    }
+    ntype[slot_node[q]] = (uint8_t)it->second;
+  }
+  h->N = N; h->P = P; h->S = S; h->T = (u32)type_total.size(); h->max_np = max_np; h->big_nodes = big;
+  h->part_off = part_off; h->slot_node = slot_node; h->node_slot = node_slot; h->orig_pos_slot = orig_pos_slot;
+
+  if (int rc = upload(h, h->d_part_off, part_off)) return rc;
+  if (int rc = upload(h, h->d_slot_node, slot_node)) return rc;
+  if (int rc = upload(h, h->d_total, total)) return rc;
+  if (int rc = upload(h, h->d_ntype, ntype)) return rc;
+  if (int rc = upload(h, h->d_type_total, type_total)) return rc;
+  HIPCHK(h, h->d_avail0.ensure((size_t)N * sizeof(Res)));
+  HIPCHK(h, h->d_tl.ensure((size_t)N * kTlCap * sizeof(TlEntry)));
+  HIPCHK(h, h->d_tl_len.ensure((size_t)N * sizeof(u32)));
+  HIPCHK(h, hipMemsetAsync(h->d_tl_len.p, 0, (size_t)N * sizeof(u32), h->stream));
+  HIPCHK(h, h->d_cost.ensure((size_t)std::max<u32>(S, 1) * sizeof(double)));
+  HIPCHK(h, h->d_fcpu.ensure((size_t)std::max<u32>(S, 1) * sizeof(int)));
+  HIPCHK(h, h->d_fmem.ensure((size_t)std::max<u32>(S, 1) * sizeof(u32)));
+  HIPCHK(h, h->d_fcnt.ensure((size_t)std::max<u32>(S, 1) * sizeof(u64)));
+  HIPCHK(h, h->d_heap.ensure((size_t)(S + P + 1) * sizeof(HeapEnt)));
+  HIPCHK(h, h->d_bfj.ensure((size_t)std::max<u32>(S, 1) * sizeof(u32)));
+  HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
+  // no running jobs until cns_set_running
+  std::vector<u32> rn_off(N + 1, 0);
+  if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
+  HIPCHK(h, h->d_rn_end.ensure(16));
+  HIPCHK(h, h->d_rn_res.ensure(sizeof(Res)));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->have_nodes = true;
+  return CNS_OK;
+}
+
+int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_running: null handle");
+  if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_set_running before cns_set_nodes");
+  HIPCHK(h, hipSetDevice(h->device));
+  const u32 N = h->N;
+  std::vector<u32> rn_off(N + 1, 0);
+  std::vector<i64> rn_end;
+  std::vector<Res> rn_res;
+  if (rn && rn->num_jobs) {
+    if (!rn->end_sec || !rn->alloc_offsets || !rn->alloc_node || !rn->alloc_cpu_raw || !rn->alloc_mem || !rn->alloc_core_lo)
+      return fail(h, CNS_ERR_INVALID_ARG, "cns_set_running: missing array");
+    const u32 A = rn->alloc_offsets[rn->num_jobs];
+    if (A != rn->num_allocs) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_running: num_allocs mismatch");
+    for (u32 a = 0; a < A; ++a) {
+      u32 n = rn->alloc_node[a];
+      if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "running allocation on node >= num_nodes");
+      if (h->node_slot[n] != kNone) rn_off[n + 1]++;  // allocations on unschedulable nodes are ignored (:6685-6686)
+    }
+    for (u32 n = 0; n < N; ++n) {
+      if (rn_off[n + 1] + 2 > kTlCap) return fail(h, CNS_ERR_UNSUPPORTED, "more than 1006 running allocations on one node");
+      rn_off[n + 1] += rn_off[n];
+    }
+    rn_end.resize(rn_off[N]);
+    rn_res.resize(rn_off[N]);
+    std::vector<u32> cur(rn_off.begin(), rn_off.end() - 1);
+    for (u32 j = 0; j < rn->num_jobs; ++j)  // stable: per node, input order (cost accumulation order)
+      for (u32 a = rn->alloc_offsets[j]; a < rn->alloc_offsets[j + 1]; ++a) {
+        u32 n = rn->alloc_node[a];
+        if (h->node_slot[n] == kNone) continue;
+        u32 d = cur[n]++;
+        rn_end[d] = rn->end_sec[j];
+        Res r;
+        r.cpu = rn->alloc_cpu_raw[a];
+        r.mem = rn->alloc_mem[a];
+        r.clo = rn->alloc_core_lo[a];
+        r.chi = rn->alloc_core_hi ? rn->alloc_core_hi[a] : 0;
+        r.gres = rn->alloc_gres ? rn->alloc_gres[a] : 0;
+        rn_res[d] = r;
+      }
+  }
+  if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
+  if (rn_end.empty()) { rn_end.push_back(0); rn_res.push_back(Res{0, 0, 0, 0, 0}); }
+  if (int rc = upload(h, h->d_rn_end, rn_end)) return rc;
+  if (int rc = upload(h, h->d_rn_res, rn_res)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->have_run = false;
+  return CNS_OK;
+}
+
+int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
+  if (!h || !jb) return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: null argument");
+  if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_upload_jobs before cns_set_nodes");
+  const u64 J = jb->num_jobs;
+  if (J && (!jb->partition || !jb->time_limit_sec || !jb->node_mem || !jb->task_cpu_raw || !jb->task_mem ||
+            !jb->node_num || !jb->ntasks || !jb->ntasks_per_node_min || !jb->ntasks_per_node_max))
+    return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: missing array");
+  if (J > 0xFFFFFFF0ull) return fail(h, CNS_ERR_UNSUPPORTED, "more than 2^32-16 jobs");
+  HIPCHK(h, hipSetDevice(h->device));
+  hipEvent_t e0 = h->ev[0], e1 = h->ev[1];
+  HIPCHK(h, hipEventRecord(e0, h->stream));
+  h->have_jobs = h->have_run = false;
+  const u64 batch = h->cfg.scheduled_batch_size ? std::min<u64>(h->cfg.scheduled_batch_size, J) : J;
+  // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761)
+  std::vector<uint8_t> reason(std::max<u64>(J, 1), CNS_REASON_NONE);
+  std::vector<u64> pj_cnt(h->P + 1, 0);
+  h->place_off.assign(J + 1, 0);
+  u64 places = 0, algo = 0;
+  const u64 s_node = h->big_nodes ? 48 : 32;
+  for (u64 j = 0; j < J; ++j) {
+    h->place_off[j] = places;
+    const u32 k = jb->node_num[j];
+    if (k == 0 || jb->ntasks[j] < k || jb->ntasks_per_node_min[j] == 0 ||
+        jb->ntasks_per_node_max[j] < jb->ntasks_per_node_min[j] || jb->time_limit_sec[j] <= 0 ||
+        jb->task_cpu_raw[j] < 0 || (jb->node_cpu_raw && jb->node_cpu_raw[j] < 0))
+      return fail(h, CNS_ERR_INVALID_ARG, "job " + std::to_string(j) + ": invalid node_num/ntasks/time_limit/cpu");
+    places += k;
+    if (j >= batch) { reason[j] = CNS_REASON_PRIORITY; continue; }
+    if (jb->skip && jb->skip[j]) { reason[j] = CNS_REASON_SKIPPED; continue; }
+    if (jb->partition[j] >= h->P) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
+    const u32 p = jb->partition[j];
+    pj_cnt[p + 1]++;
+    algo += (u64)(h->part_off[p + 1] - h->part_off[p]) * s_node + 64 + 16 + 24ull * k;
+  }
+  h->place_off[J] = places;
+  std::vector<u64> pj_off(h->P + 1, 0);
+  for (u32 p = 0; p < h->P; ++p) pj_off[p + 1] = pj_off[p] + pj_cnt[p + 1];
+  const u64 Jg = pj_off[h->P];
+  // one host staging buffer, SoA sections (16-byte aligned)
+  cns_engine::JobPtrs& o = h->jo;
+  size_t off = 0;
+  auto sec = [&](size_t elem, u64 n) { size_t r = off; off = align16(off + elem * (size_t)std::max<u64>(n, 1)); return r; };
+  o.orig = sec(4, Jg); o.L = sec(8, Jg); o.ncpu = sec(8, Jg); o.nmem = sec(8, Jg); o.tcpu = sec(8, Jg);
+  o.tmem = sec(8, Jg); o.k = sec(4, Jg); o.ntasks = sec(4, Jg); o.tmin = sec(4, Jg); o.tmax = sec(4, Jg);
+  o.flags = sec(4, Jg); o.gtot = sec(4, Jg); o.gspec = sec(8, Jg); o.incl_off = sec(8, Jg + 1);
+  o.excl_off = sec(8, Jg + 1); o.place = sec(8, Jg);
+  std::vector<char> stage(off, 0);
+  auto at = [&](size_t base, size_t elem, u64 i) { return stage.data() + base + elem * (size_t)i; };
+  std::vector<u64> cur(pj_off.begin(), pj_off.end() - 1);
+  std::vector<u32> incl, excl;
+  // pass 1: slots; include/exclude lists are appended in grouped order afterwards
+  std::vector<u32> grouped((size_t)Jg);
+  for (u64 j = 0; j < batch; ++j) {
+    if (reason[j] != CNS_REASON_NONE) continue;
+    grouped[(size_t)cur[jb->partition[j]]++] = (u32)j;
+  }
+  for (u64 i = 0; i < Jg; ++i) {
+    const u64 j = grouped[(size_t)i];
+    u32 flags = 0;
+    *(u32*)at(o.orig, 4, i) = (u32)j;
+    *(i64*)at(o.L, 8, i) = jb->time_limit_sec[j];
+    *(i64*)at(o.ncpu, 8, i) = jb->node_cpu_raw ? jb->node_cpu_raw[j] : 0;
+    *(u64*)at(o.nmem, 8, i) = jb->node_mem[j];
+    *(i64*)at(o.tcpu, 8, i) = jb->task_cpu_raw[j];
+    *(u64*)at(o.tmem, 8, i) = jb->task_mem[j];
+    *(u32*)at(o.k, 4, i) = jb->node_num[j];
+    *(u32*)at(o.ntasks, 4, i) = jb->ntasks[j];
+    *(u32*)at(o.tmin, 4, i) = jb->ntasks_per_node_min[j];
+    *(u32*)at(o.tmax, 4, i) = jb->ntasks_per_node_max[j];
+    u32 gtot = 0;
+    u64 gspec = 0;
+    if (jb->gres_total) memcpy(&gtot, jb->gres_total + j * CNS_MAX_GRES_NAMES, 4);
+    if (jb->gres_spec) memcpy(&gspec, jb->gres_spec + j * CNS_MAX_GRES_CLASSES, 8);
+    for (u32 c = h->gres.num_classes; c < CNS_MAX_GRES_CLASSES; ++c)
+      if ((gspec >> (8 * c)) & 0xFF) return fail(h, CNS_ERR_INVALID_ARG, "job requests an undefined GRES class");
+    if (gtot | gspec) flags |= kJfGres;
+    *(u32*)at(o.gtot, 4, i) = gtot;
+    *(u64*)at(o.gspec, 8, i) = gspec;
+    if (jb->exclusive && jb->exclusive[j]) flags |= kJfExclusive;
+    *(u64*)at(o.incl_off, 8, i) = incl.size();
+    *(u64*)at(o.excl_off, 8, i) = excl.size();
+    if (jb->incl_offsets && jb->incl_offsets[j + 1] > jb->incl_offsets[j]) {
+      flags |= kJfIncl;
+      incl.insert(incl.end(), jb->incl_nodes + jb->incl_offsets[j], jb->incl_nodes + jb->incl_offsets[j + 1]);
+    }
+    if (jb->excl_offsets && jb->excl_offsets[j + 1] > jb->excl_offsets[j]) {
+      flags |= kJfExcl;
+      excl.insert(excl.end(), jb->excl_nodes + jb->excl_offsets[j], jb->excl_nodes + jb->excl_offsets[j + 1]);
+    }
+    *(u32*)at(o.flags, 4, i) = flags;
+    *(u64*)at(o.place, 8, i) = h->place_off[j];
+  }
+  *(u64*)at(o.incl_off, 8, Jg) = incl.size();
+  *(u64*)at(o.excl_off, 8, Jg) = excl.size();
+  if (incl.empty()) incl.push_back(0);
+  if (excl.empty()) excl.push_back(0);
+
+  if (int rc = upload(h, h->d_pj_off, pj_off)) return rc;
+  if (int rc = upload(h, h->d_jobs, stage)) return rc;
+  if (int rc = upload(h, h->d_incl, incl)) return rc;
+  if (int rc = upload(h, h->d_excl, excl)) return rc;
+  if (int rc = upload(h, h->d_reason_init, reason)) return rc;
+  // results: one contiguous HBM buffer (also what an RCCL allgather ships)
+  cns_engine::ResOff& r = h->ro;
+  size_t ro = 0;
+  auto rsec = [&](size_t elem, u64 n) { size_t x = ro; ro = align16(ro + elem * (size_t)std::max<u64>(n, 1)); return x; };
+  r.start = rsec(8, J); r.cpu = rsec(8, places); r.mem = rsec(8, places); r.clo = rsec(8, places);
+  r.chi = rsec(8, places); r.gres = rsec(8, places); r.node = rsec(4, places); r.ntasks = rsec(4, places);
+  r.reason = rsec(1, J); r.total = ro;
+  HIPCHK(h, h->d_results.ensure(ro));
+  HIPCHK(h, hipEventRecord(e1, h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+  h->timing = cns_timing{};
+  h->timing.h2d_ms = ms;
+  h->J = J; h->Jg = Jg; h->places = places; h->jobs_ordered = batch; h->algo_bytes = algo;
+  h->have_jobs = true;
+  return CNS_OK;
+}
+
+int cns_run_resident(cns_handle* h, int64_t now) {
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_run_resident: null handle");
+  if (!h->have_nodes || !h->have_jobs) return fail(h, CNS_ERR_STATE, "cns_run_resident before set_nodes/upload_jobs");
+  HIPCHK(h, hipSetDevice(h->device));
+  KParams K;
+  fill_params(h, K, now);
+  char* rb = h->d_results.as<char>();
+  const u64 pl = std::max<u64>(h->places, 1), J = std::max<u64>(h->J, 1);
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(h, hipMemsetAsync(rb + h->ro.start, 0, h->ro.node - h->ro.start, h->stream));  // start + 8-byte records
+  HIPCHK(h, hipMemsetAsync(rb + h->ro.node, 0xFF, 4 * pl, h->stream));                  // CNS_NODE_NONE
+  HIPCHK(h, hipMemsetAsync(rb + h->ro.ntasks, 0, 4 * pl, h->stream));
+  HIPCHK(h, hipMemcpyAsync(rb + h->ro.reason, h->d_reason_init.p, J, hipMemcpyDeviceToDevice, h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_fault.p, 0, 16, h->stream));
+  if (h->S) hipLaunchKernelGGL(k_init_nodes, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, K);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  if (h->Jg) {
+    const u32 np = h->max_np;
+    if (np <= 960) launch_select<1>(h, K);
+    else if (np <= 1920) launch_select<2>(h, K);
+    else if (np <= 2880) launch_select<3>(h, K);
+    else if (np <= 4800) launch_select<5>(h, K);
+    else if (np <= 8640) launch_select<9>(h, K);
+    else launch_select<18>(h, K);
+    HIPCHK(h, hipGetLastError());
+  }
+  HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  float a = 0, b = 0;
+  HIPCHK(h, hipEventElapsedTime(&a, h->ev[0], h->ev[1]));
+  HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
+  h->timing.init_ms = a;
+  h->timing.select_ms = b;
+  h->timing.jobs_ordered = h->jobs_ordered;
+  h->timing.algorithmic_bytes = h->algo_bytes;
+  u32 fault[4] = {0, 0, 0, 0};
+  HIPCHK(h, hipMemcpy(fault, h->d_fault.p, 16, hipMemcpyDeviceToHost));
+  h->last_now = now;
+  if (fault[0])
+    return fail(h, CNS_ERR_DEVICE_FAULT, "device invariant violated: code " + std::to_string(fault[0]) + " job " +
+                                             std::to_string(fault[1]) + " aux " + std::to_string(fault[2]) + "," +
+                                             std::to_string(fault[3]));
+  h->have_run = true;
+  return CNS_OK;
+}
+
+int cns_download(cns_handle* h, cns_placement_soa* out) {
+  if (!h || !out) return fail(h, CNS_ERR_INVALID_ARG, "cns_download: null argument");
+  if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_download before a successful run");
+  if (out->place_capacity < h->places) return fail(h, CNS_ERR_INVALID_ARG, "cns_download: place_capacity too small");
+  if (!out->start_sec || !out->reason || !out->place_offsets || !out->node_idx || !out->ntasks || !out->cpu_raw ||
+      !out->mem || !out->core_lo || !out->core_hi || !out->gres)
+    return fail(h, CNS_ERR_INVALID_ARG, "cns_download: missing result array");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+  const char* rb = h->d_results.as<char>();
+  auto get = [&](void* dst, size_t off, size_t bytes) -> hipError_t {
+    return bytes ? hipMemcpyAsync(dst, rb + off, bytes, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+  };
+  const size_t J = (size_t)h->J, pl = (size_t)h->places;
+  HIPCHK(h, get(out->start_sec, h->ro.start, 8 * J));
+  HIPCHK(h, get(out->reason, h->ro.reason, J));
+  HIPCHK(h, get(out->cpu_raw, h->ro.cpu, 8 * pl));
+  HIPCHK(h, get(out->mem, h->ro.mem, 8 * pl));
+  HIPCHK(h, get(out->core_lo, h->ro.clo, 8 * pl));
+  HIPCHK(h, get(out->core_hi, h->ro.chi, 8 * pl));
+  HIPCHK(h, get(out->gres, h->ro.gres, 8 * pl));
+  HIPCHK(h, get(out->node_idx, h->ro.node, 4 * pl));
+  HIPCHK(h, get(out->ntasks, h->ro.ntasks, 4 * pl));
+  HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memcpy(out->place_offsets, h->place_off.data(), 8 * (J + 1));
+  float ms = 0;
+  HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  h->timing.d2h_ms = ms;
+  return CNS_OK;
+}
+
+int cns_select(cns_handle* h, int64_t now, const cns_job_soa* jobs, cns_placement_soa* out) {
+  if (int rc = cns_upload_jobs(h, jobs)) return rc;
+  if (int rc = cns_run_resident(h, now)) return rc;
+  return cns_download(h, out);
+}
+
+int cns_device_results(cns_handle* h, void** dptr, uint64_t* bytes) {
+  if (!h || !dptr || !bytes) return fail(h, CNS_ERR_INVALID_ARG, "cns_device_results: null argument");
+  if (!h->have_jobs) return fail(h, CNS_ERR_STATE, "cns_device_results before cns_upload_jobs");
+  *dptr = h->d_results.p;
+  *bytes = h->ro.total;
+  return CNS_OK;
+}
+
+int cns_get_timing(const cns_handle* h, cns_timing* t) {
+  if (!h || !t) return CNS_ERR_INVALID_ARG;
+  *t = h->timing;
+  return CNS_OK;
+}
+
+int cns_debug_get_costs(cns_handle* h, double* out) {
+  if (!h || !out) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_costs: null argument");
+  if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_costs before a successful run");
+  HIPCHK(h, hipSetDevice(h->device));
+  std::vector<double> c(std::max<u32>(h->S, 1));
+  HIPCHK(h, hipMemcpy(c.data(), h->d_cost.p, (size_t)h->S * sizeof(double), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < h->orig_pos_slot.size(); ++i) out[i] = h->orig_pos_slot[i] == kNone ? 0.0 : c[h->orig_pos_slot[i]];
+  return CNS_OK;
+}
+
+int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint32_t* len, int64_t* t,
+                           int64_t* cpu_raw, uint64_t* mem, uint64_t* core_lo, uint64_t* core_hi, uint64_t* gres) {
+  if (!h || !len) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_timeline: null argument");
+  if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_timeline before a successful run");
+  if (node >= h->N) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_timeline: node out of range");
+  HIPCHK(h, hipSetDevice(h->device));
+  u32 n = 0;
+  HIPCHK(h, hipMemcpy(&n, h->d_tl_len.as<u32>() + node, 4, hipMemcpyDeviceToHost));
+  *len = n;
+  u32 m = std::min(n, capacity);
+  std::vector<TlEntry> e(std::max<u32>(m, 1));
+  if (m) HIPCHK(h, hipMemcpy(e.data(), h->d_tl.as<TlEntry>() + (size_t)node * kTlCap, (size_t)m * sizeof(TlEntry), hipMemcpyDeviceToHost));
+  for (u32 i = 0; i < m; ++i) {
+    t[i] = e[i].t; cpu_raw[i] = e[i].r.cpu; mem[i] = e[i].r.mem; core_lo[i] = e[i].r.clo; core_hi[i] = e[i].r.chi; gres[i] = e[i].r.gres;
+  }
+  return CNS_OK;
+}
+
+}  // extern "C"

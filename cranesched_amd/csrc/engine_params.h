@@ -1,0 +1,82 @@
+// Kernel parameter block shared by the host side of the C ABI (engine.hip) and the gfx950 kernels
+// (select_kernels.hip).  All pointers are HBM device pointers.  Layout in HBM:
+//   node tables  : SoA / small AoS records indexed by dense node index n or by partition slot q
+//   timelines    : tl[n * tl_cap + i], sorted array form of NodeState::time_avail_res_map
+//   job table    : SoA, grouped by partition, queue order preserved inside a partition
+//   results      : SoA in the caller's original job order
+#pragma once
+#include "pq_emul.h"
+#include "res_dev.h"
+
+namespace cns {
+
+constexpr int kBlock = 1024;         // threads of the per-partition workgroup (16 wave64)
+constexpr int kWaves = kBlock / 64;
+constexpr int kMaxNpl = 16;          // nodes per lane held in registers -> <= 16384 nodes per partition
+constexpr u32 kTlCap = 1008;         // >= kAlgoMaxJobNumPerNode - 1 + 2 entries per node
+constexpr int kMaxUpd = 32;          // per-job owner updates broadcast through LDS
+constexpr int kLdsHeap = 33;         // heap / pick entries kept in LDS when node_num < this
+constexpr i64 kInf = INT64_MAX;      // absl::InfiniteFuture()
+constexpr u32 kNone = 0xFFFFFFFFu;
+
+enum JobFlags : u32 { kJfExclusive = 1, kJfIncl = 2, kJfExcl = 4, kJfGres = 8 };
+
+struct KParams {
+  // ---- cluster -------------------------------------------------------------------------
+  u32 num_nodes, num_parts, num_slots, num_types;
+  u32 tl_cap, max_jobs_per_node;
+  i64 now, max_window;
+  const u32* part_off;     // [P+1] slot range of each partition
+  const u32* slot_node;    // [S]   dense node index of slot q (ascending inside a partition)
+  const Res* total;        // [N]   res_total
+  Res* avail0;             // [N]   cycle-start res_avail (JobScheduler.h:287,313), written by init
+  const uint8_t* ntype;    // [N]   node type id (index into type_total)
+  const Res* type_total;   // [T]   distinct res_total records
+  TlEntry* tl;             // [N*tl_cap]
+  u32* tl_len;             // [N]
+  double* cost;            // [S]   NodeRater::cost (JobScheduler.h:514)
+  int* f_cpu;              // [S]   front (t = now) summary: cpu raw, exact
+  u32* f_mem;              // [S]   front mem in MiB, rounded up (conservative)
+  u64* f_cnt;              // [S]   front GRES popcount per class, byte g
+  // running allocations grouped by node, input order preserved
+  const u32* rn_off;       // [N+1]
+  const i64* rn_end;       // [A]
+  const Res* rn_res;       // [A]
+  // ---- jobs, grouped by partition --------------------------------------------------------
+  const u64* pj_off;       // [P+1]
+  const u32* j_orig;       // original index in the caller's queue
+  const i64* j_L;          // time_limit
+  const i64* j_ncpu;       // req_node_res_view cpu
+  const u64* j_nmem;
+  const i64* j_tcpu;       // req_task_res_view cpu
+  const u64* j_tmem;
+  const u32* j_k;          // node_num
+  const u32* j_ntasks;
+  const u32* j_tmin;
+  const u32* j_tmax;
+  const u32* j_flags;
+  const u32* j_gtot;
+  const u64* j_gspec;
+  const u64* j_incl_off;   // [Jp+1] (valid when any job has the flag)
+  const u32* incl_nodes;
+  const u64* j_excl_off;
+  const u32* excl_nodes;
+  const u64* j_place_off;  // offset of the job's placement records
+  // ---- results ---------------------------------------------------------------------------
+  i64* o_start;
+  uint8_t* o_reason;
+  u32* o_node;
+  u32* o_ntasks;
+  i64* o_cpu;
+  u64* o_mem;
+  u64* o_clo;
+  u64* o_chi;
+  u64* o_gres;
+  // ---- scratch ---------------------------------------------------------------------------
+  HeapEnt* heap;           // [S + P] partition p uses [part_off[p] + p, ...) of size n_p + 1
+  u32* bf_j;               // [S] backfill cursor per selected node
+  u32* fault;              // [4] != 0: an internal invariant failed (code, job, aux, aux)
+  GresDev gres;
+};
+
+}  // namespace cns

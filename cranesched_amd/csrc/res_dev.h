@@ -1,0 +1,198 @@
+// Resource algebra of the node-selection engine on bit masks, usable from HIP device code
+// (gfx950) and — for the CPU unit tests of these helpers — from plain host C++.
+//
+// Reference semantics implemented (paths relative to the CraneSched tree):
+//   ResourceView::GetFeasibleResourceInNode   src/Utilities/PublicHeader/PublicHeader.cpp:519-599
+//   ResourceInNodeV3::Ckmin                   src/Utilities/PublicHeader/PublicHeader.cpp:815-827
+//   operator<=(ResourceInNodeV3, ...)         src/Utilities/PublicHeader/PublicHeader.cpp:886-890
+//   ResourceInNodeV3 += / -=                  src/Utilities/PublicHeader/PublicHeader.cpp:781-796
+//   get_max_tasks lambda                      src/CraneCtld/JobScheduler.cpp:6171-6186
+// in the canonical integer model of include/crane_gpu/node_select.h.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CNS_HD __host__ __device__ __forceinline__
+#else
+#define CNS_HD inline
+#endif
+
+namespace cns {
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+constexpr int kMaxClasses = 8;
+constexpr int kMaxNames = 4;
+
+// ResourceInNodeV3 in mask form: cpu raw (x256), mem bytes, 128 core bits, 64 GRES slot bits.
+struct Res {
+  i64 cpu;
+  u64 mem;
+  u64 clo, chi;
+  u64 gres;
+};
+
+// One entry of a node's time -> available-resource map (std::map<absl::Time, ResourceInNodeV3>,
+// src/CraneCtld/JobScheduler.h:245), stored as a sorted array in HBM.
+struct TlEntry {
+  i64 t;
+  Res r;
+};
+
+// ResourceView of a request: cpu raw, mem, per-name GresCount.total (4 x u8) and per-class
+// GresCount.specified (8 x u8), PublicHeader.h:505-523,695-761.
+struct Req {
+  i64 cpu;
+  u64 mem;
+  u32 gtot;   // byte a = total of name a
+  u64 gspec;  // byte g = specified count of class g
+};
+
+// Device copy of cns_gres_layout with the masks precomputed.
+struct GresDev {
+  u32 num_classes;
+  u32 class_name_packed;  // nibble g = name id of class g
+  u64 class_mask[kMaxClasses];
+  u64 name_mask[kMaxNames];
+  u64 name_bytes[kMaxNames];  // 0xFF in byte g for every class g of the name
+};
+
+CNS_HD int popc64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __popcll(x);
+#else
+  return __builtin_popcountll(x);
+#endif
+}
+
+// The n lowest set bits of x (all of x if it has fewer).
+CNS_HD u64 lowest_n(u64 x, int n) {
+  u64 y = x;
+  for (int i = 0; i < n && y; ++i) y &= y - 1;
+  return x ^ y;
+}
+
+CNS_HD u32 byte_of(u64 v, int i) { return (u32)((v >> (8 * i)) & 0xFF); }
+CNS_HD bool cores_empty(const Res& r) { return (r.clo | r.chi) == 0; }
+
+CNS_HD void res_sub(Res& a, const Res& b) {  // PublicHeader.cpp:789-796,758-766 (tolerant core erase)
+  a.clo &= ~b.clo;
+  a.chi &= ~b.chi;
+  a.cpu -= b.cpu;
+  a.mem -= b.mem;
+  a.gres &= ~b.gres;
+}
+CNS_HD void res_add(Res& a, const Res& b) {  // PublicHeader.cpp:781-787
+  a.clo |= b.clo;
+  a.chi |= b.chi;
+  a.cpu += b.cpu;
+  a.mem += b.mem;
+  a.gres |= b.gres;
+}
+CNS_HD bool res_le(const Res& a, const Res& b) {  // PublicHeader.cpp:886-890 (core ids not compared)
+  return a.cpu <= b.cpu && a.mem <= b.mem && (a.gres & ~b.gres) == 0;
+}
+CNS_HD void res_ckmin(Res& a, const Res& b) {  // PublicHeader.cpp:815-827
+  a.cpu = a.cpu < b.cpu ? a.cpu : b.cpu;
+  if (!cores_empty(a) && !cores_empty(b)) {
+    a.clo &= b.clo;
+    a.chi &= b.chi;
+  }
+  a.mem = a.mem < b.mem ? a.mem : b.mem;
+  a.gres &= b.gres;
+}
+
+// req_node_res_view + req_task_res_view * n (PublicHeader.cpp:473-481,601-611); the task view has no GRES.
+CNS_HD Req compose(const Req& node, i64 task_cpu, u64 task_mem, u32 n) {
+  Req r = node;
+  r.cpu = node.cpu + task_cpu * (i64)n;
+  r.mem = node.mem + task_mem * (u64)n;
+  return r;
+}
+
+// GetFeasibleResourceInNode, PublicHeader.cpp:519-599.
+CNS_HD bool feasible(const Req& q, const Res& a, Res& out, const GresDev& L) {
+  if (q.cpu > a.cpu) return false;  // :522
+  if (q.mem > a.mem) return false;  // :523
+  Res c;
+  c.cpu = q.cpu;
+  c.mem = q.mem;
+  c.clo = 0;
+  c.chi = 0;
+  c.gres = 0;
+  i64 req_int = q.cpu / 256;                                        // :528
+  bool is_int = (req_int * 256 == q.cpu) && !cores_empty(a);        // :529-530
+  if (is_int) {
+    int nlo = popc64(a.clo);
+    if ((u32)(nlo + popc64(a.chi)) < (u32)req_int) return false;    // :534
+    int n = (int)req_int;
+    if (n <= nlo) {
+      c.clo = lowest_n(a.clo, n);
+    } else {
+      c.clo = a.clo;
+      c.chi = lowest_n(a.chi, n - nlo);
+    }
+  }
+  if (q.gtot | q.gspec) {
+    for (int name = 0; name < kMaxNames; ++name) {                  // :549
+      u32 tot = (q.gtot >> (8 * name)) & 0xFF;
+      u64 spec_b = q.gspec & L.name_bytes[name];
+      if (tot == 0 && spec_b == 0) continue;
+      if ((a.gres & L.name_mask[name]) == 0) return false;          // :550-551
+      u32 spec_sum = 0;
+      for (int g = 0; g < kMaxClasses; ++g) spec_sum += byte_of(spec_b, g);
+      u32 untyped = tot > spec_sum ? tot - spec_sum : 0;             // :556-559
+      for (int g = 0; g < (int)L.num_classes; ++g) {                // specified types, ascending :564
+        u32 cnt = byte_of(spec_b, g);
+        if (!cnt) continue;
+        u64 slots = a.gres & L.class_mask[g];
+        if (slots == 0) return false;                                // :566
+        if ((u32)popc64(slots) < cnt) return false;                  // :569
+        u64 take = lowest_n(slots, (int)cnt);
+        u64 rest = slots ^ take;
+        u64 extra = lowest_n(rest, (int)(untyped < 64 ? untyped : 64));  // :577-578
+        untyped -= (u32)popc64(extra);
+        c.gres |= take | extra;
+      }
+      if (untyped > 0) {                                             // :582-592 other types ascending
+        for (int g = 0; g < (int)L.num_classes && untyped > 0; ++g) {
+          if (((L.class_name_packed >> (4 * g)) & 0xF) != (u32)name) continue;
+          if (byte_of(spec_b, g)) continue;
+          u64 slots = a.gres & L.class_mask[g];
+          u64 extra = lowest_n(slots, (int)(untyped < 64 ? untyped : 64));
+          untyped -= (u32)popc64(extra);
+          c.gres |= extra;
+        }
+      }
+      if (untyped != 0) return false;                                // :594
+    }
+  }
+  out = c;
+  return true;
+}
+
+// get_max_tasks, JobScheduler.cpp:6171-6186: 0 if the minimum view does not fit, else tpn_min plus
+// the number of further single tasks that fit one at a time, capped at tpn_max.
+CNS_HD int max_tasks(const Req& min_view, i64 task_cpu, u64 task_mem, u32 tpn_min, u32 tpn_max,
+                     const Res& on_node, const GresDev& L) {
+  Res f;
+  if (!feasible(min_view, on_node, f, L)) return 0;
+  int n = (int)tpn_min;
+  if (n >= (int)tpn_max) return n;
+  Res left = on_node;
+  res_sub(left, f);
+  Req task;
+  task.cpu = task_cpu;
+  task.mem = task_mem;
+  task.gtot = 0;
+  task.gspec = 0;
+  while (n < (int)tpn_max && feasible(task, left, f, L)) {
+    ++n;
+    res_sub(left, f);
+  }
+  return n;
+}
+
+}  // namespace cns

@@ -1,0 +1,151 @@
+"""ctypes binding of the engine's C ABI (include/crane_gpu/node_select.h).
+
+`GpuNodeSelector` is the Python mirror of the reference's `SchedulerAlgo` plugin surface
+(src/CraneCtld/JobScheduler.h:233-263): one object per controller, `node_select(now, running,
+pending)` once per scheduling cycle.  The work happens in the HIP shared library; this module
+fails loudly if that library is missing or no MI355X is visible — there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+# torch first: its wheel bundles its own HIP/HSA runtime (SONAME libamdhip64.so.7).  Loading it before
+# the engine makes the dynamic loader hand the SAME runtime to libcrane_gpu_nodeselect.so; two HIP
+# runtimes in one process leave the second one without devices (hipGetDeviceCount -> "no ROCm-capable
+# device").  torch is plumbing here (device memory for RCCL, torch.distributed), never on the hot path.
+import torch  # noqa: F401  (must precede the CDLL below)
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcrane_gpu_nodeselect.so")
+_LIB = None
+
+# every symbol include/crane_gpu/node_select.h declares
+ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
+               "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
+               "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline")
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"{abi.STATUS_STR.get(status, status)}: {msg}")
+        self.status = status
+
+
+def lib():
+    """Load the HIP engine. Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(
+                f"{LIB_PATH} is missing: the HIP engine is not built and there is no CPU fallback. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+        L = C.CDLL(LIB_PATH)
+        L.cns_last_error.restype = C.c_char_p
+        L.cns_last_error.argtypes = [C.c_void_p]
+        L.cns_destroy.restype = None
+        L.cns_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+class GpuNodeSelector:
+    """One engine handle on one MI355X (one process per GPU)."""
+
+    def __init__(self, device: int = 0, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0,
+                 max_time_window_sec: int = 0):
+        self._L = lib()
+        self._h = C.c_void_p()
+        cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, device, scheduled_batch_size, max_job_num_per_node, 0,
+                            max_time_window_sec)
+        rc = self._L.cns_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = self._L.cns_last_error(None)
+            self._h = C.c_void_p()
+            raise EngineError(rc, msg.decode() if msg else "")
+        self._cluster = None
+        self._jobs = None
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._L.cns_last_error(self._h)
+            raise EngineError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if self._h:
+            self._L.cns_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- per-cycle snapshot -----------------------------------------------------------------------
+    def set_nodes(self, cluster: abi.Cluster):
+        c = cluster.to_c()
+        self._check(self._L.cns_set_nodes(self._h, C.byref(c)))
+        self._cluster = cluster
+
+    def set_running(self, running: abi.Running | None):
+        if running is None:
+            self._check(self._L.cns_set_running(self._h, None))
+        else:
+            r = running.to_c()
+            self._check(self._L.cns_set_running(self._h, C.byref(r)))
+
+    # -- NodeSelect --------------------------------------------------------------------------------
+    def node_select(self, now: int, jobs: abi.Jobs) -> abi.Placements:
+        """SchedulerAlgo::NodeSelect(now, running_jobs, pending_jobs) in one call."""
+        out = abi.Placements(jobs.num_jobs, jobs.total_places())
+        cj, co = jobs.to_c(), out.to_c()
+        self._check(self._L.cns_select(self._h, C.c_int64(now), C.byref(cj), C.byref(co)))
+        self._jobs = jobs
+        return out
+
+    # split form: inputs resident in HBM before the timed region (bench.py)
+    def upload_jobs(self, jobs: abi.Jobs):
+        cj = jobs.to_c()
+        self._check(self._L.cns_upload_jobs(self._h, C.byref(cj)))
+        self._jobs = jobs
+
+    def run_resident(self, now: int):
+        self._check(self._L.cns_run_resident(self._h, C.c_int64(now)))
+
+    def download(self) -> abi.Placements:
+        out = abi.Placements(self._jobs.num_jobs, self._jobs.total_places())
+        co = out.to_c()
+        self._check(self._L.cns_download(self._h, C.byref(co)))
+        return out
+
+    def device_results(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self._check(self._L.cns_device_results(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def timing(self) -> dict:
+        t = abi.CnsTiming()
+        self._check(self._L.cns_get_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in abi.CnsTiming._fields_}
+
+    # -- parity helpers ------------------------------------------------------------------------------
+    def costs(self) -> np.ndarray:
+        c = np.zeros(len(self._cluster.part_nodes), np.float64)
+        self._check(self._L.cns_debug_get_costs(self._h, c.ctypes.data_as(C.c_void_p)))
+        return c
+
+    def timeline(self, node: int, cap: int = 1100):
+        n = C.c_uint32(0)
+        t = np.zeros(cap, np.int64); cpu = np.zeros(cap, np.int64)
+        mem = np.zeros(cap, np.uint64); lo = np.zeros(cap, np.uint64)
+        hi = np.zeros(cap, np.uint64); g = np.zeros(cap, np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self._check(self._L.cns_debug_get_timeline(self._h, C.c_uint32(node), C.c_uint32(cap), C.byref(n),
+                                                   p(t), p(cpu), p(mem), p(lo), p(hi), p(g)))
+        k = min(n.value, cap)
+        return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k]}

@@ -1,0 +1,65 @@
+"""GPU parity proper: the HIP engine through the C ABI vs the CPU oracle, bit for bit."""
+import numpy as np
+import pytest
+
+from cranesched_amd import synth
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(engine_cls, cluster, jobs, now, running=None, tag="", **cfg):
+    from oracle import pyoracle
+    eng = engine_cls(device=0, **cfg)
+    try:
+        eng.set_nodes(cluster)
+        if running is not None:
+            eng.set_running(running)
+        got = eng.node_select(now, jobs)
+        ref = pyoracle.select(cluster, jobs, now, running=running, **cfg)
+        helpers.assert_same(eng, got, ref, cluster, tag=tag)
+        return got, eng.timing()
+    finally:
+        eng.close()
+
+
+def test_c1_full(engine_cls):
+    c, j, now = synth.make_config("C1")
+    got, _ = _run(engine_cls, c, j, now, tag="C1")
+    assert (got.reason[:j.num_jobs] == 0).all()
+
+
+@pytest.mark.parametrize("name,J,N,P", [("C2", 20000, 1024, 1), ("C3", 12000, 1536, 1), ("C4", 20000, 2048, 8),
+                                        ("C5", 30000, 1024, 8)])
+def test_scaled_configs(engine_cls, name, J, N, P):
+    c, j, now = synth.make_config(name, J=J, N=N, P=P)
+    got, t = _run(engine_cls, c, j, now, tag=f"{name} scaled")
+    r = got.reason[:J]
+    assert (r == 1).sum() > 0, "scenario must exercise backfill"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_heterogeneous(engine_cls, seed):
+    c, j, now, run = helpers.random_case(seed)
+    _run(engine_cls, c, j, now, running=run, tag=f"random{seed}")
+
+
+@pytest.mark.parametrize("seed", [100, 101])
+def test_random_tight_limits(engine_cls, seed):
+    # kAlgoMaxJobNumPerNode and kAlgoMaxTimeWindow reached: nodes drop out (:6194), backfill gives up (h:815)
+    c, j, now, run = helpers.random_case(seed, N=24, J=900, P=1, running=10)
+    _run(engine_cls, c, j, now, running=run, tag=f"tight{seed}", max_job_num_per_node=12,
+         max_time_window_sec=6 * 3600)
+
+
+def test_batch_limit(engine_cls):
+    c, j, now = synth.make_config("C1")
+    got, _ = _run(engine_cls, c, j, now, tag="batch", scheduled_batch_size=400)
+    assert (got.reason[400:1000] == 1).all()
+
+
+@pytest.mark.parametrize("N", [900, 1800, 2800, 4500, 8192, 10000])
+def test_tile_widths(engine_cls, N):
+    # every register-tile width (nodes per scanner lane 1,2,3,5,9,18)
+    c, j, now = synth.make_config("C3", J=3000, N=(N // 4) * 4, P=1)
+    _run(engine_cls, c, j, now, tag=f"tile N={N}")
