@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py — scheduling decisions/s of the MI355X node-selection engine.
+
+A "step" is one whole NodeSelect cycle (SchedulerAlgo::NodeSelect, reference
+src/CraneCtld/JobScheduler.cpp:6507-6836, bracket :1439-1447) over the synthetic C4 queue:
+1 M pending jobs x 64 k nodes in 8 disjoint partitions, CPU+mem+GRES requests,
+with the job table and node snapshot already resident in HBM when the timed region starts.
+At N > 1 the queue is job-sharded by partition (rank r owns partitions p % N == r) and each step
+ends with one RCCL all-gather of the packed placement buffers; total work is fixed ("strong").
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_select) with the ALGORITHMIC
+bytes of SURVEY.md §8(d) (N_p*S_node + S_job + S_out per decision) over its HIP-event duration;
+`cpu_baseline` times the CPU oracle (a port of the reference algorithm; the reference itself cannot
+be built offline) on a bounded prefix of the same queue, single thread like the reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="C4")
+    ap.add_argument("--jobs", type=int, default=None, help="override J (debug only; invalid as a headline)")
+    ap.add_argument("--nodes", type=int, default=None, help="override N (debug only)")
+    ap.add_argument("--cpu-sample-jobs", type=int, default=200_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from cranesched_amd import sharding, synth
+    from cranesched_amd.engine import GpuNodeSelector
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    cluster, jobs, now = synth.make_config(args.config, J=args.jobs, N=args.nodes)
+    my_jobs, my_idx = sharding.shard(cluster, jobs, rank, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))
+
+    eng = GpuNodeSelector(device=local_rank)
+    eng.set_nodes(cluster)
+    eng.upload_jobs(my_jobs)           # inputs resident in HBM before the timed region
+    h2d_ms = eng.timing()["h2d_ms"]
+
+    gather_in = gather_out = None
+    if world > 1:
+        ptr, nbytes = eng.device_results()
+        mx = torch.tensor([nbytes], device=dev, dtype=torch.int64)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        pad = int(mx.item())
+        src = sharding.device_bytes_tensor(ptr, nbytes, dev)
+        gather_in = torch.zeros(pad, dtype=torch.uint8, device=dev)
+        gather_out = torch.empty(pad * world, dtype=torch.uint8, device=dev)
+
+    def step():
+        eng.run_resident(now)                      # init kernel + persistent selection kernel (synchronous)
+        if world > 1:                              # merge per-shard node claims: one all-gather over xGMI
+            gather_in[:nbytes].copy_(src)
+            dist.all_gather_into_tensor(gather_out, gather_in)
+
+    for _ in range(args.warmup):
+        step()
+    sel_ms, init_ms = [], []
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        t = eng.timing()
+        sel_ms.append(t["select_ms"])
+        init_ms.append(t["init_ms"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tm = eng.timing()
+    ordered = torch.tensor([tm["jobs_ordered"]], device=dev, dtype=torch.int64)
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ordered, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    total_jobs = int(ordered.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = total_jobs * args.steps / elapsed
+        avg_sel_ms = float(np.mean(sel_ms))
+        achieved = tm["algorithmic_bytes"] / (avg_sel_ms * 1e-3) / 1e9
+        got = eng.download()
+        r = got.reason[:my_jobs.num_jobs]
+        line = {
+            "metric": "scheduling decisions/sec at 1M pending x 64k nodes",
+            "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "int64", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {jobs.num_jobs} pending jobs x {cluster.num_nodes} nodes, "
+                                   f"{cluster.num_partitions} disjoint partitions, CPU+mem+GRES(gpu/npu), FIFO, "
+                                   f"seed 0x43524E45^{synth.CONFIGS[args.config]['idx']}",
+                       "jobs": jobs.num_jobs, "nodes": cluster.num_nodes, "partitions": cluster.num_partitions,
+                       "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else "single GPU, one workgroup per partition",
+                       "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),
+                                         "resource": int((r == 2).sum())},
+                       "kernel_ms": {"k_select": avg_sel_ms, "k_init_nodes+fill": float(np.mean(init_ms))},
+                       "h2d_job_table_ms": h2d_ms},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_select", "algorithmic_bytes_per_launch": tm["algorithmic_bytes"],
+                         "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); "
+                                 "the node tile is register-resident, so HBM traffic is far below this"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle import pyoracle  # CPU oracle = the checker, timed here only as the reported baseline
+            ns = min(args.cpu_sample_jobs, jobs.num_jobs)
+            cj = synth.make_config(args.config, J=ns, N=args.nodes)[1]
+            ref = pyoracle.select(cluster, cj, now)
+            line["cpu_baseline"] = {
+                "value": ns / ref.seconds, "unit": "decisions/s", "cores": 1, "kind": "port",
+                "sample": f"first {ns} jobs of the same queue on the full {cluster.num_nodes}-node cluster, "
+                          f"{ref.seconds:.1f} s, single thread (the reference path is single-threaded); a prefix is "
+                          "cheaper per decision than the full queue (cluster still filling), so this favours the CPU",
+                "host_cpus": os.cpu_count()}
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

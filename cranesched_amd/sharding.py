@@ -1,0 +1,89 @@
+"""Job-sharding of the pending queue across the GPUs of one node.
+
+Each partition has its own LocalScheduler, node set and cost order in the reference
+(src/CraneCtld/JobScheduler.cpp:6723-6732, :6746-6761), so jobs of different partitions never
+interact when the partitions' node sets are disjoint.  Rank r therefore owns the partitions
+{p : p % world == r}: their node lists and their slice of the queue (order preserved), runs the
+engine on that shard alone, and one RCCL all-gather of the packed placement buffers leaves every
+rank with the merged claim list.  With disjoint partitions there is no claim to resolve, so the
+replay step is a no-op (overlapping partitions are rejected by cns_set_nodes).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abi, synth
+
+
+def partition_plan(num_parts: int, world: int) -> list[list[int]]:
+    return [[p for p in range(num_parts) if p % world == r] for r in range(world)]
+
+
+def shard(cluster: abi.Cluster, jobs: abi.Jobs, rank: int, world: int):
+    """(jobs of this rank's partitions, their indices in the global queue)."""
+    parts = partition_plan(cluster.num_partitions, world)[rank]
+    return synth.select_partitions(cluster, jobs, parts)
+
+
+def _align16(x: int) -> int:
+    return (x + 15) & ~15
+
+
+def results_layout(num_jobs: int, places: int) -> dict:
+    """Byte offsets of the packed result buffer (mirror of cns_upload_jobs in csrc/engine.hip)."""
+    off, lay = 0, {}
+    for name, elem, n in (("start_sec", 8, num_jobs), ("cpu_raw", 8, places), ("mem", 8, places),
+                          ("core_lo", 8, places), ("core_hi", 8, places), ("gres", 8, places),
+                          ("node_idx", 4, places), ("ntasks", 4, places), ("reason", 1, num_jobs)):
+        lay[name] = (off, elem, n)
+        off = _align16(off + elem * max(n, 1))
+    lay["total"] = off
+    return lay
+
+
+_DT = {"start_sec": np.int64, "cpu_raw": np.int64, "mem": np.uint64, "core_lo": np.uint64, "core_hi": np.uint64,
+       "gres": np.uint64, "node_idx": np.uint32, "ntasks": np.uint32, "reason": np.uint8}
+
+
+def unpack_results(buf: np.ndarray, jobs: abi.Jobs) -> abi.Placements:
+    """Packed result bytes of one shard -> Placements (host side of the merge)."""
+    J, places = jobs.num_jobs, jobs.total_places()
+    lay = results_layout(J, places)
+    out = abi.Placements(J, places)
+    for name, dt in _DT.items():
+        off, elem, n = lay[name]
+        getattr(out, name)[:n] = np.frombuffer(buf, dtype=dt, count=n, offset=off)
+    out.place_offsets[:] = np.concatenate([[0], np.cumsum(jobs.node_num.astype(np.uint64))])
+    return out
+
+
+def merge(jobs: abi.Jobs, shards: list[tuple[abi.Placements, np.ndarray]]) -> abi.Placements:
+    """Scatter per-shard placements (with their global job indices) back into global queue order.
+    Jobs owned by no shard (unknown partition, beyond the batch limit) keep what their shard
+    reported — every job belongs to exactly one shard by construction of `shard`."""
+    J, places = jobs.num_jobs, jobs.total_places()
+    out = abi.Placements(J, places)
+    goff = np.concatenate([[0], np.cumsum(jobs.node_num.astype(np.uint64))]).astype(np.uint64)
+    out.place_offsets[:] = goff
+    for pl, idx in shards:
+        out.start_sec[idx] = pl.start_sec[:len(idx)]
+        out.reason[idx] = pl.reason[:len(idx)]
+        k = jobs.node_num[idx].astype(np.int64)
+        if len(idx) == 0:
+            continue
+        # destination record index of every shard record
+        starts = goff[idx].astype(np.int64)
+        rep = np.repeat(starts - np.concatenate([[0], np.cumsum(k)[:-1]]), k) + np.arange(int(k.sum()))
+        for f in ("node_idx", "ntasks", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+            getattr(out, f)[rep] = getattr(pl, f)[:len(rep)]
+    return out
+
+
+def device_bytes_tensor(ptr: int, nbytes: int, device):
+    """uint8 torch tensor aliasing `nbytes` of HBM at `ptr` (for torch.distributed / RCCL)."""
+    import torch
+
+    class _Raw:
+        __cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 3}
+
+    return torch.as_tensor(_Raw(), device=device)

@@ -105,9 +105,9 @@ def random_case(seed: int, N: int = 96, J: int = 600, P: int = 2, running: int =
     incl_off = [0]; incl = []; excl_off = [0]; exn = []
     for j in range(J):
         if lists and rng.random() < 0.05:
-            incl += list(rng.choice(N, size=rng.integers(1, 12), replace=False))
+            incl += list(rng.choice(N, size=rng.integers(1, min(12, N)), replace=False))
         if lists and rng.random() < 0.05:
-            exn += list(rng.choice(N, size=rng.integers(1, 30), replace=False))
+            exn += list(rng.choice(N, size=rng.integers(1, min(30, N)), replace=False))
         incl_off.append(len(incl)); excl_off.append(len(exn))
     jobs = abi.Jobs(partition=partition, time_limit_sec=L, node_mem=node_mem, task_cpu_raw=task_cpu_raw,
                     task_mem=task_mem, node_num=k, ntasks=ntasks, ntasks_per_node_min=tmin,
