@@ -59,15 +59,12 @@ struct cns_engine {
   bool have_nodes = false, have_jobs = false, have_run = false;
 
   // device buffers
-  DevBuf d_part_off, d_slot_node, d_total, d_avail0, d_ntype, d_type_total, d_tl, d_tl_len, d_cost, d_fcpu,
-      d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_fault;
-  DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results;
+  DevBuf d_part_off, d_slot_node, d_total, d_ntype, d_type_total, d_blocks, d_cost, d_fcpu,
+      d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
+  DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results, d_params, d_prof;
   // job table
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
   std::vector<u64> place_off;
-  struct JobPtrs {
-    size_t orig, L, ncpu, nmem, tcpu, tmem, k, ntasks, tmin, tmax, flags, gtot, gspec, incl_off, excl_off, place;
-  } jo{};
   struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, total; } ro{};
   cns_timing timing{};
   i64 last_now = 0;
@@ -127,11 +124,10 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.part_off = h->d_part_off.as<u32>();
   K.slot_node = h->d_slot_node.as<u32>();
   K.total = h->d_total.as<Res>();
-  K.avail0 = h->d_avail0.as<Res>();
   K.ntype = h->d_ntype.as<uint8_t>();
   K.type_total = h->d_type_total.as<Res>();
-  K.tl = h->d_tl.as<TlEntry>();
-  K.tl_len = h->d_tl_len.as<u32>();
+  K.blocks = h->d_blocks.as<char>();
+  K.block_stride = kBlockStride;
   K.cost = h->d_cost.as<double>();
   K.f_cpu = h->d_fcpu.as<int>();
   K.f_mem = h->d_fmem.as<u32>();
@@ -140,23 +136,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.rn_end = h->d_rn_end.as<i64>();
   K.rn_res = h->d_rn_res.as<Res>();
   K.pj_off = h->d_pj_off.as<u64>();
-  char* jb = h->d_jobs.as<char>();
-  K.j_orig = (const u32*)(jb + h->jo.orig);
-  K.j_L = (const i64*)(jb + h->jo.L);
-  K.j_ncpu = (const i64*)(jb + h->jo.ncpu);
-  K.j_nmem = (const u64*)(jb + h->jo.nmem);
-  K.j_tcpu = (const i64*)(jb + h->jo.tcpu);
-  K.j_tmem = (const u64*)(jb + h->jo.tmem);
-  K.j_k = (const u32*)(jb + h->jo.k);
-  K.j_ntasks = (const u32*)(jb + h->jo.ntasks);
-  K.j_tmin = (const u32*)(jb + h->jo.tmin);
-  K.j_tmax = (const u32*)(jb + h->jo.tmax);
-  K.j_flags = (const u32*)(jb + h->jo.flags);
-  K.j_gtot = (const u32*)(jb + h->jo.gtot);
-  K.j_gspec = (const u64*)(jb + h->jo.gspec);
-  K.j_incl_off = (const u64*)(jb + h->jo.incl_off);
-  K.j_excl_off = (const u64*)(jb + h->jo.excl_off);
-  K.j_place_off = (const u64*)(jb + h->jo.place);
+  K.jobrec = h->d_jobs.as<u32>();
   K.incl_nodes = h->d_incl.as<u32>();
   K.excl_nodes = h->d_excl.as<u32>();
   char* rb = h->d_results.as<char>();
@@ -171,13 +151,15 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.o_reason = (uint8_t*)(rb + h->ro.reason);
   K.heap = h->d_heap.as<HeapEnt>();
   K.bf_j = h->d_bfj.as<u32>();
+  K.g_upd = h->d_gupd.as<UpdRec>();
   K.fault = h->d_fault.as<u32>();
+  K.prof = h->d_prof.as<u64>();
   K.gres = h->gres;
 }
 
 template <int NPL>
 void launch_select(cns_engine* h, const KParams& K) {
-  hipLaunchKernelGGL((k_select<NPL>), dim3(h->P), dim3(kBlock), 0, h->stream, K);
+  hipLaunchKernelGGL((k_select<NPL>), dim3(h->P), dim3(kBlock), 0, h->stream, K, h->d_params.as<KParams>());
 }
 
 }  // namespace
@@ -225,10 +207,10 @@ int cns_create(const cns_config* cfg, cns_handle** out) {
 void cns_destroy(cns_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_total, &h->d_avail0, &h->d_ntype, &h->d_type_total,
-                    &h->d_tl, &h->d_tl_len, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
-                    &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_fault, &h->d_pj_off, &h->d_jobs,
-                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results})
+  for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_total, &h->d_ntype, &h->d_type_total,
+                    &h->d_blocks, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
+                    &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_gupd, &h->d_fault, &h->d_pj_off, &h->d_jobs,
+                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof})
     b->release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -314,17 +296,16 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   if (int rc = upload(h, h->d_total, total)) return rc;
   if (int rc = upload(h, h->d_ntype, ntype)) return rc;
   if (int rc = upload(h, h->d_type_total, type_total)) return rc;
-  HIPCHK(h, h->d_avail0.ensure((size_t)N * sizeof(Res)));
-  HIPCHK(h, h->d_tl.ensure((size_t)N * kTlCap * sizeof(TlEntry)));
-  HIPCHK(h, h->d_tl_len.ensure((size_t)N * sizeof(u32)));
-  HIPCHK(h, hipMemsetAsync(h->d_tl_len.p, 0, (size_t)N * sizeof(u32), h->stream));
+  HIPCHK(h, h->d_blocks.ensure((size_t)std::max<u32>(S, 1) * kBlockStride));  // 48.5 KB per node: HBM is plentiful
   HIPCHK(h, h->d_cost.ensure((size_t)std::max<u32>(S, 1) * sizeof(double)));
   HIPCHK(h, h->d_fcpu.ensure((size_t)std::max<u32>(S, 1) * sizeof(int)));
   HIPCHK(h, h->d_fmem.ensure((size_t)std::max<u32>(S, 1) * sizeof(u32)));
   HIPCHK(h, h->d_fcnt.ensure((size_t)std::max<u32>(S, 1) * sizeof(u64)));
   HIPCHK(h, h->d_heap.ensure((size_t)(S + P + 1) * sizeof(HeapEnt)));
   HIPCHK(h, h->d_bfj.ensure((size_t)std::max<u32>(S, 1) * sizeof(u32)));
+  HIPCHK(h, h->d_gupd.ensure((size_t)std::max<u32>(S, 1) * sizeof(UpdRec)));
   HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
+  HIPCHK(h, h->d_prof.ensure((size_t)P * 32 * sizeof(u64)));
   // no running jobs until cns_set_running
   std::vector<u32> rn_off(N + 1, 0);
   if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
@@ -422,37 +403,25 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   std::vector<u64> pj_off(h->P + 1, 0);
   for (u32 p = 0; p < h->P; ++p) pj_off[p + 1] = pj_off[p] + pj_cnt[p + 1];
   const u64 Jg = pj_off[h->P];
-  // one host staging buffer, SoA sections (16-byte aligned)
-  cns_engine::JobPtrs& o = h->jo;
-  size_t off = 0;
-  auto sec = [&](size_t elem, u64 n) { size_t r = off; off = align16(off + elem * (size_t)std::max<u64>(n, 1)); return r; };
-  o.orig = sec(4, Jg); o.L = sec(8, Jg); o.ncpu = sec(8, Jg); o.nmem = sec(8, Jg); o.tcpu = sec(8, Jg);
-  o.tmem = sec(8, Jg); o.k = sec(4, Jg); o.ntasks = sec(4, Jg); o.tmin = sec(4, Jg); o.tmax = sec(4, Jg);
-  o.flags = sec(4, Jg); o.gtot = sec(4, Jg); o.gspec = sec(8, Jg); o.incl_off = sec(8, Jg + 1);
-  o.excl_off = sec(8, Jg + 1); o.place = sec(8, Jg);
-  std::vector<char> stage(off, 0);
-  auto at = [&](size_t base, size_t elem, u64 i) { return stage.data() + base + elem * (size_t)i; };
+  // 32-dword job records, grouped by partition in queue order (lane-striped fetch on the device)
+  std::vector<u32> stage((size_t)std::max<u64>(Jg, 1) * kJobRecDwords, 0);
   std::vector<u64> cur(pj_off.begin(), pj_off.end() - 1);
   std::vector<u32> incl, excl;
-  // pass 1: slots; include/exclude lists are appended in grouped order afterwards
   std::vector<u32> grouped((size_t)Jg);
   for (u64 j = 0; j < batch; ++j) {
     if (reason[j] != CNS_REASON_NONE) continue;
     grouped[(size_t)cur[jb->partition[j]]++] = (u32)j;
   }
+  auto put64 = [](u32* rec, u32 f, u64 v) { rec[f] = (u32)v; rec[f + 1] = (u32)(v >> 32); };
   for (u64 i = 0; i < Jg; ++i) {
     const u64 j = grouped[(size_t)i];
+    u32* rec = stage.data() + (size_t)i * kJobRecDwords;
     u32 flags = 0;
-    *(u32*)at(o.orig, 4, i) = (u32)j;
-    *(i64*)at(o.L, 8, i) = jb->time_limit_sec[j];
-    *(i64*)at(o.ncpu, 8, i) = jb->node_cpu_raw ? jb->node_cpu_raw[j] : 0;
-    *(u64*)at(o.nmem, 8, i) = jb->node_mem[j];
-    *(i64*)at(o.tcpu, 8, i) = jb->task_cpu_raw[j];
-    *(u64*)at(o.tmem, 8, i) = jb->task_mem[j];
-    *(u32*)at(o.k, 4, i) = jb->node_num[j];
-    *(u32*)at(o.ntasks, 4, i) = jb->ntasks[j];
-    *(u32*)at(o.tmin, 4, i) = jb->ntasks_per_node_min[j];
-    *(u32*)at(o.tmax, 4, i) = jb->ntasks_per_node_max[j];
+    put64(rec, 0, (u64)jb->time_limit_sec[j]);
+    put64(rec, 2, (u64)(jb->node_cpu_raw ? jb->node_cpu_raw[j] : 0));
+    put64(rec, 4, jb->node_mem[j]);
+    put64(rec, 6, (u64)jb->task_cpu_raw[j]);
+    put64(rec, 8, jb->task_mem[j]);
     u32 gtot = 0;
     u64 gspec = 0;
     if (jb->gres_total) memcpy(&gtot, jb->gres_total + j * CNS_MAX_GRES_NAMES, 4);
@@ -460,24 +429,29 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
     for (u32 c = h->gres.num_classes; c < CNS_MAX_GRES_CLASSES; ++c)
       if ((gspec >> (8 * c)) & 0xFF) return fail(h, CNS_ERR_INVALID_ARG, "job requests an undefined GRES class");
     if (gtot | gspec) flags |= kJfGres;
-    *(u32*)at(o.gtot, 4, i) = gtot;
-    *(u64*)at(o.gspec, 8, i) = gspec;
+    put64(rec, 10, gspec);
+    rec[12] = jb->node_num[j];
+    rec[13] = jb->ntasks[j];
+    rec[14] = jb->ntasks_per_node_min[j];
+    rec[15] = jb->ntasks_per_node_max[j];
+    rec[17] = gtot;
+    rec[18] = (u32)j;
+    put64(rec, 20, h->place_off[j]);
     if (jb->exclusive && jb->exclusive[j]) flags |= kJfExclusive;
-    *(u64*)at(o.incl_off, 8, i) = incl.size();
-    *(u64*)at(o.excl_off, 8, i) = excl.size();
+    put64(rec, 22, incl.size());
     if (jb->incl_offsets && jb->incl_offsets[j + 1] > jb->incl_offsets[j]) {
       flags |= kJfIncl;
       incl.insert(incl.end(), jb->incl_nodes + jb->incl_offsets[j], jb->incl_nodes + jb->incl_offsets[j + 1]);
     }
+    put64(rec, 24, incl.size());
+    put64(rec, 26, excl.size());
     if (jb->excl_offsets && jb->excl_offsets[j + 1] > jb->excl_offsets[j]) {
       flags |= kJfExcl;
       excl.insert(excl.end(), jb->excl_nodes + jb->excl_offsets[j], jb->excl_nodes + jb->excl_offsets[j + 1]);
     }
-    *(u32*)at(o.flags, 4, i) = flags;
-    *(u64*)at(o.place, 8, i) = h->place_off[j];
+    put64(rec, 28, excl.size());
+    rec[16] = flags;
   }
-  *(u64*)at(o.incl_off, 8, Jg) = incl.size();
-  *(u64*)at(o.excl_off, 8, Jg) = excl.size();
   if (incl.empty()) incl.push_back(0);
   if (excl.empty()) excl.push_back(0);
 
@@ -519,7 +493,10 @@ int cns_run_resident(cns_handle* h, int64_t now) {
   HIPCHK(h, hipMemsetAsync(rb + h->ro.ntasks, 0, 4 * pl, h->stream));
   HIPCHK(h, hipMemcpyAsync(rb + h->ro.reason, h->d_reason_init.p, J, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_fault.p, 0, 16, h->stream));
-  if (h->S) hipLaunchKernelGGL(k_init_nodes, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, K);
+  HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, (size_t)h->P * 32 * sizeof(u64), h->stream));
+  HIPCHK(h, h->d_params.ensure(sizeof(KParams)));
+  HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+  if (h->S) hipLaunchKernelGGL(k_init_nodes, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_params.as<KParams>());
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   if (h->Jg) {
@@ -614,18 +591,32 @@ int cns_debug_get_costs(cns_handle* h, double* out) {
   return CNS_OK;
 }
 
+int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity) {
+  // cycle counters of the last run, 32 per partition; all zero unless the library was built with -DCNS_PROF
+  if (!h || !out) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_prof: null argument");
+  if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_prof before a successful run");
+  HIPCHK(h, hipSetDevice(h->device));
+  const size_t n = std::min<size_t>((size_t)h->P * 32, capacity);
+  HIPCHK(h, hipMemcpy(out, h->d_prof.p, n * sizeof(u64), hipMemcpyDeviceToHost));
+  return CNS_OK;
+}
+
 int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint32_t* len, int64_t* t,
                            int64_t* cpu_raw, uint64_t* mem, uint64_t* core_lo, uint64_t* core_hi, uint64_t* gres) {
   if (!h || !len) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_timeline: null argument");
   if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_timeline before a successful run");
   if (node >= h->N) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_timeline: node out of range");
   HIPCHK(h, hipSetDevice(h->device));
-  u32 n = 0;
-  HIPCHK(h, hipMemcpy(&n, h->d_tl_len.as<u32>() + node, 4, hipMemcpyDeviceToHost));
+  const u32 slot = h->node_slot[node];
+  if (slot == kNone) { *len = 0; return CNS_OK; }  // not schedulable / in no partition: no NodeState (cpp:6595)
+  const char* blk = h->d_blocks.as<char>() + (size_t)slot * kBlockStride;
+  NodeHdr hd;
+  HIPCHK(h, hipMemcpy(&hd, blk, sizeof hd, hipMemcpyDeviceToHost));
+  const u32 n = hd.len;
   *len = n;
   u32 m = std::min(n, capacity);
   std::vector<TlEntry> e(std::max<u32>(m, 1));
-  if (m) HIPCHK(h, hipMemcpy(e.data(), h->d_tl.as<TlEntry>() + (size_t)node * kTlCap, (size_t)m * sizeof(TlEntry), hipMemcpyDeviceToHost));
+  if (m) HIPCHK(h, hipMemcpy(e.data(), blk + sizeof(NodeHdr), (size_t)m * sizeof(TlEntry), hipMemcpyDeviceToHost));
   for (u32 i = 0; i < m; ++i) {
     t[i] = e[i].t; cpu_raw[i] = e[i].r.cpu; mem[i] = e[i].r.mem; core_lo[i] = e[i].r.clo; core_hi[i] = e[i].r.chi; gres[i] = e[i].r.gres;
   }

@@ -18,6 +18,32 @@ constexpr int kMaxUpd = 32;          // per-job owner updates broadcast through 
 constexpr int kLdsHeap = 33;         // heap / pick entries kept in LDS when node_num < this
 constexpr i64 kInf = INT64_MAX;      // absl::InfiniteFuture()
 constexpr u32 kNone = 0xFFFFFFFFu;
+#define CNS_MAX_NODE_TYPES_DEV 64
+
+// Per-slot node block in HBM: everything the worker needs about one node in ONE contiguous read.
+//   header : time-map length, dense node index, node type, cycle-start res_avail (JobScheduler.h:287,313)
+//            and res_total
+//   entries: sorted-array form of NodeState::time_avail_res_map (JobScheduler.h:245,291)
+struct NodeHdr {
+  u32 len, node, type, pad;
+  Res avail0;
+  Res total;
+};
+static_assert(sizeof(NodeHdr) == 96, "NodeHdr = 2 TlEntry slots");
+static_assert(sizeof(TlEntry) == 48, "TlEntry layout");
+constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * sizeof(TlEntry);
+
+constexpr u32 kJobRecDwords = 32;
+
+struct UpdRec {  // what the owning scanner lane must refresh after a commit
+  u32 p, len;
+  double cost;
+  int fcpu;
+  u32 fmem;
+  u64 fcnt;
+  u32 has_front;
+  u32 pad;
+};
 
 enum JobFlags : u32 { kJfExclusive = 1, kJfIncl = 2, kJfExcl = 4, kJfGres = 8 };
 
@@ -28,12 +54,11 @@ struct KParams {
   i64 now, max_window;
   const u32* part_off;     // [P+1] slot range of each partition
   const u32* slot_node;    // [S]   dense node index of slot q (ascending inside a partition)
-  const Res* total;        // [N]   res_total
-  Res* avail0;             // [N]   cycle-start res_avail (JobScheduler.h:287,313), written by init
+  const Res* total;        // [N]   res_total (input of k_init_nodes)
   const uint8_t* ntype;    // [N]   node type id (index into type_total)
   const Res* type_total;   // [T]   distinct res_total records
-  TlEntry* tl;             // [N*tl_cap]
-  u32* tl_len;             // [N]
+  char* blocks;            // [S]   one NodeBlock per partition slot: NodeHdr + tl_cap TlEntry
+  u64 block_stride;        //       bytes per NodeBlock
   double* cost;            // [S]   NodeRater::cost (JobScheduler.h:514)
   int* f_cpu;              // [S]   front (t = now) summary: cpu raw, exact
   u32* f_mem;              // [S]   front mem in MiB, rounded up (conservative)
@@ -42,26 +67,11 @@ struct KParams {
   const u32* rn_off;       // [N+1]
   const i64* rn_end;       // [A]
   const Res* rn_res;       // [A]
-  // ---- jobs, grouped by partition --------------------------------------------------------
+  // ---- jobs, grouped by partition: 32-dword records (JobRecField in select_kernels.hip) ---------
   const u64* pj_off;       // [P+1]
-  const u32* j_orig;       // original index in the caller's queue
-  const i64* j_L;          // time_limit
-  const i64* j_ncpu;       // req_node_res_view cpu
-  const u64* j_nmem;
-  const i64* j_tcpu;       // req_task_res_view cpu
-  const u64* j_tmem;
-  const u32* j_k;          // node_num
-  const u32* j_ntasks;
-  const u32* j_tmin;
-  const u32* j_tmax;
-  const u32* j_flags;
-  const u32* j_gtot;
-  const u64* j_gspec;
-  const u64* j_incl_off;   // [Jp+1] (valid when any job has the flag)
-  const u32* incl_nodes;
-  const u64* j_excl_off;
+  const u32* jobrec;       // [Jg * 32]
+  const u32* incl_nodes;   // included_nodes lists, CSR by the record's incl_b / incl_e
   const u32* excl_nodes;
-  const u64* j_place_off;  // offset of the job's placement records
   // ---- results ---------------------------------------------------------------------------
   i64* o_start;
   uint8_t* o_reason;
@@ -75,7 +85,9 @@ struct KParams {
   // ---- scratch ---------------------------------------------------------------------------
   HeapEnt* heap;           // [S + P] partition p uses [part_off[p] + p, ...) of size n_p + 1
   u32* bf_j;               // [S] backfill cursor per selected node
+  UpdRec* g_upd;           // [S] owner updates of selections larger than the LDS list
   u32* fault;              // [4] != 0: an internal invariant failed (code, job, aux, aux)
+  u64* prof;               // [P*32] cycle counters (only written by -DCNS_PROF builds)
   GresDev gres;
 };
 

@@ -173,6 +173,41 @@ CNS_HD bool feasible(const Req& q, const Res& a, Res& out, const GresDev& L) {
   return true;
 }
 
+CNS_HD u32 byte_sum(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sad_u8((u32)v, 0u, __builtin_amdgcn_sad_u8((u32)(v >> 32), 0u, 0u));
+#else
+  u32 s = 0;
+  for (int i = 0; i < 8; ++i) s += (u32)((v >> (8 * i)) & 0xFF);
+  return s;
+#endif
+}
+
+// Truth value of feasible() from COUNTS only: cpu, mem, number of free cores and the per-class slot
+// popcounts (byte g of `cnt`).  GetFeasibleResourceInNode fails exactly when (PublicHeader.cpp:522-594)
+//   cpu or mem is short, a whole-number request finds fewer free core ids than it needs, a specified
+//   type has fewer slots than asked, or the name's slots cannot cover max(total, sum(specified)).
+CNS_HD bool feasible_counts(const Req& q, i64 cpu, u64 mem, u32 ncores, u64 cnt, const GresDev& L) {
+  if (q.cpu > cpu) return false;
+  if (q.mem > mem) return false;
+  const i64 req_int = q.cpu / 256;
+  if (req_int * 256 == q.cpu && ncores != 0 && ncores < (u32)req_int) return false;
+  if (q.gtot | q.gspec) {
+    const u64 H8 = 0x8080808080808080ull;
+    if (q.gspec & H8) return false;  // a class holds <= 64 slots
+    if ((((cnt | H8) - q.gspec) & H8) != H8) return false;  // bytewise spec_g <= cnt_g
+    for (int name = 0; name < kMaxNames; ++name) {
+      const u32 tot = (q.gtot >> (8 * name)) & 0xFF;
+      const u64 spec_b = q.gspec & L.name_bytes[name];
+      if (tot == 0 && spec_b == 0) continue;
+      const u32 have = byte_sum(cnt & L.name_bytes[name]);
+      const u32 ssum = byte_sum(spec_b);
+      if (have < (tot > ssum ? tot : ssum)) return false;
+    }
+  }
+  return true;
+}
+
 // get_max_tasks, JobScheduler.cpp:6171-6186: 0 if the minimum view does not fit, else tpn_min plus
 // the number of further single tasks that fit one at a time, capped at tpn_max.
 CNS_HD int max_tasks(const Req& min_view, i64 task_cpu, u64 task_mem, u32 tpn_min, u32 tpn_max,

@@ -1,22 +1,25 @@
 // gfx950 (MI355X / CDNA4) kernels of the node-selection engine.  Hand-written HIP; no MFMA — this is
-// integer / bitmask work bound by HBM/L2 latency and LDS, not a dense contraction.
+// integer / bitmask work bound by memory latency and LDS, not a dense contraction.
 //
 // k_init_nodes : one thread per partition slot — NodeSelect's prologue on device:
 //                res_avail = res_total - running allocations, the per-node time map and the initial
 //                fp64 cost (src/CraneCtld/JobScheduler.cpp:6681-6732, JobScheduler.h:301-338,498-511).
 // k_select<NPL>: ONE 1024-thread workgroup per partition (independent LocalScheduler,
 //                JobScheduler.cpp:6723-6727), persistent over that partition's whole job queue, because
-//                job j+1 depends on job j's commit (SURVEY.md §7 "sequential semantics").  Inside a job
-//                the reference's cost-ordered node walk (JobScheduler.cpp:6188-6300) becomes
-//                  - a register-resident node tile: each lane owns NPL nodes (cost + "front" summary),
-//                  - a per-lane feasibility filter + (cost, index) argmin, wave64 shuffle reduce,
-//                    16-entry LDS cross-wave reduce  -> the next node in (cost, idx) order that can pass,
-//                  - exact verification of that node by wave 0: wave-parallel window-min (Ckmin) over
-//                    the node's time map in HBM, GetFeasibleResourceInNode on bit masks,
-//                  - commit by wave 0: wave-parallel sorted-array update of the time map, fp64 cost
-//                    update, LDS broadcast of the new summary to the owning lane.
-//                Failing that, the first-k-by-total-capacity nodes are selected the same way and the
-//                earliest common start is found on their time maps (backfill, JobScheduler.h:792-865).
+//                job j+1 depends on job j's commit (SURVEY.md §7 "sequential semantics").  The
+//                workgroup is wave-specialised:
+//                  waves 1..15 "scanners": the partition's node tile lives in their registers (each lane
+//                     owns NPL nodes: fp64 cost + a "front" summary of what is free now).  Per round they
+//                     filter their nodes against the job and deliver — wave64 shuffle argmin, then a
+//                     16-slot LDS reduce — the next node in (cost, index) order that may pass, i.e. the
+//                     reference's cost-ordered walk (JobScheduler.cpp:6188-6300) without the walk.
+//                  wave 0 "worker": exact test of that node — ONE coalesced read of its NodeBlock
+//                     (header + time map, lane i <- entry i), wave-parallel window-min (Ckmin),
+//                     GetFeasibleResourceInNode on bit masks — then the commit straight from registers:
+//                     sorted-array update of the time map, fp64 cost update, LDS broadcast of the new
+//                     summary to the owning scanner lane.  Jobs that cannot start now get their nodes
+//                     by total capacity from the same scan and the earliest start by a bit-scan over
+//                     the time map's "alloc fits" ballot (backfill, JobScheduler.h:792-865).
 // Compile with -ffp-contract=off (fp64 cost must match the CPU bit for bit).
 #include <hip/hip_runtime.h>
 
@@ -29,35 +32,113 @@ namespace cns {
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 cost_key(double c) { return (u64)__double_as_longlong(c); }
 
-__device__ __forceinline__ void wave_argmin(u64& c, u32& p) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) {
-    u64 oc = __shfl_xor(c, off);
-    u32 op = __shfl_xor(p, off);
-    bool take = (oc < c) || (oc == c && op < p);
-    c = take ? oc : c;
-    p = take ? op : p;
-  }
+__device__ __forceinline__ u32 uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni32((u32)(v >> 32)) << 32) | uni32((u32)v); }
+__device__ __forceinline__ u32 rl32(u32 v, u32 idx) { return (u32)__builtin_amdgcn_readlane((int)v, (int)idx); }
+__device__ __forceinline__ u64 rl64(u64 v, u32 idx) { return ((u64)rl32((u32)(v >> 32), idx) << 32) | rl32((u32)v, idx); }
+__device__ __forceinline__ Res rl_res(const Res& r, u32 idx) {
+  Res o;
+  o.cpu = (i64)rl64((u64)r.cpu, idx);
+  o.mem = rl64(r.mem, idx);
+  o.clo = rl64(r.clo, idx);
+  o.chi = rl64(r.chi, idx);
+  o.gres = rl64(r.gres, idx);
+  return o;
 }
-__device__ __forceinline__ i64 wave_min_i64(i64 v) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) { i64 o = __shfl_xor(v, off); v = o < v ? o : v; }
-  return v;
+
+// wave-uniform values -> SGPRs, so that the worker's GetFeasibleResourceInNode arithmetic runs on the
+// scalar unit and does not compete for vector registers
+__device__ __forceinline__ Res uni_res(const Res& r) {
+  Res o;
+  o.cpu = (i64)uni64((u64)r.cpu); o.mem = uni64(r.mem); o.clo = uni64(r.clo); o.chi = uni64(r.chi); o.gres = uni64(r.gres);
+  return o;
 }
-__device__ __forceinline__ i64 wave_max_i64(i64 v) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) { i64 o = __shfl_xor(v, off); v = o > v ? o : v; }
-  return v;
+
+// ---- wave64 reductions on the DPP crossbar (no LDS traffic, no ds_bpermute latency) -------------------
+// row_shr:1,2,4,8 folds each row of 16 lanes into its lane 15; row_bcast:15 / row_bcast:31 fold the
+// four rows into lane 63 (the classic GCN/CDNA wave reduction); v_readlane 63 makes the result scalar.
+// Lanes whose DPP source is out of range keep `identity` (bound_ctrl = 0), so op(v, identity) == v.
+#define CNS_DPP_STEP32(op, v, ident, ctrl, rmask) \
+  v = op(v, (u32)__builtin_amdgcn_update_dpp((int)(ident), (int)(v), ctrl, rmask, 0xF, false))
+__device__ __forceinline__ u32 op_umin(u32 a, u32 b) { return a < b ? a : b; }
+__device__ __forceinline__ u32 op_umax(u32 a, u32 b) { return a > b ? a : b; }
+__device__ __forceinline__ u32 op_and(u32 a, u32 b) { return a & b; }
+__device__ __forceinline__ u32 wave_umin32(u32 v) {
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x111, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x112, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x114, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x118, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x142, 0xA);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x143, 0xC);
+  return rl32(v, 63);
 }
+__device__ __forceinline__ u32 wave_umax32(u32 v) {
+  CNS_DPP_STEP32(op_umax, v, 0u, 0x111, 0xF);
+  CNS_DPP_STEP32(op_umax, v, 0u, 0x112, 0xF);
+  CNS_DPP_STEP32(op_umax, v, 0u, 0x114, 0xF);
+  CNS_DPP_STEP32(op_umax, v, 0u, 0x118, 0xF);
+  CNS_DPP_STEP32(op_umax, v, 0u, 0x142, 0xA);
+  CNS_DPP_STEP32(op_umax, v, 0u, 0x143, 0xC);
+  return rl32(v, 63);
+}
+__device__ __forceinline__ u32 wave_and32(u32 v) {
+  CNS_DPP_STEP32(op_and, v, 0xFFFFFFFFu, 0x111, 0xF);
+  CNS_DPP_STEP32(op_and, v, 0xFFFFFFFFu, 0x112, 0xF);
+  CNS_DPP_STEP32(op_and, v, 0xFFFFFFFFu, 0x114, 0xF);
+  CNS_DPP_STEP32(op_and, v, 0xFFFFFFFFu, 0x118, 0xF);
+  CNS_DPP_STEP32(op_and, v, 0xFFFFFFFFu, 0x142, 0xA);
+  CNS_DPP_STEP32(op_and, v, 0xFFFFFFFFu, 0x143, 0xC);
+  return rl32(v, 63);
+}
+// min over the 16 lanes of each row (used where every row holds the same 16 values)
+__device__ __forceinline__ u32 row_umin32(u32 v) {
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x111, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x112, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x114, 0xF);
+  CNS_DPP_STEP32(op_umin, v, 0xFFFFFFFFu, 0x118, 0xF);
+  return rl32(v, 15);
+}
+// 64-bit unsigned min / max as cascaded 32-bit reductions: high words first, then the low words of the
+// lanes that tie on the high word.  All results are wave-uniform.
 __device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) { u64 o = __shfl_xor(v, off); v = o < v ? o : v; }
-  return v;
+  const u32 hi = (u32)(v >> 32), lo = (u32)v;
+  const u32 mh = wave_umin32(hi);
+  const u32 ml = wave_umin32(hi == mh ? lo : 0xFFFFFFFFu);
+  return ((u64)mh << 32) | ml;
 }
+__device__ __forceinline__ u64 wave_max_u64(u64 v) {
+  const u32 hi = (u32)(v >> 32), lo = (u32)v;
+  const u32 mh = wave_umax32(hi);
+  const u32 ml = wave_umax32(hi == mh ? lo : 0u);
+  return ((u64)mh << 32) | ml;
+}
+// order-preserving map i64 -> u64
+__device__ __forceinline__ i64 wave_min_i64(i64 v) { return (i64)(wave_min_u64((u64)v ^ 0x8000000000000000ull) ^ 0x8000000000000000ull); }
+__device__ __forceinline__ i64 wave_max_i64(i64 v) { return (i64)(wave_max_u64((u64)v ^ 0x8000000000000000ull) ^ 0x8000000000000000ull); }
 __device__ __forceinline__ u64 wave_and_u64(u64 v) {
-#pragma unroll
-  for (int off = 32; off; off >>= 1) v &= __shfl_xor(v, off);
-  return v;
+  return ((u64)wave_and32((u32)(v >> 32)) << 32) | wave_and32((u32)v);
+}
+// lexicographic argmin of (cost key, code) over the wave: three cascaded 32-bit minima
+__device__ __forceinline__ void wave_argmin(u64& c, u32& p) {
+  const u32 hi = (u32)(c >> 32), lo = (u32)c;
+  const u32 mh = wave_umin32(hi);
+  const bool e1 = hi == mh;
+  const u32 ml = wave_umin32(e1 ? lo : 0xFFFFFFFFu);
+  const bool e2 = e1 & (lo == ml);
+  const u32 mp = wave_umin32(e2 ? p : 0xFFFFFFFFu);
+  c = ((u64)mh << 32) | ml;
+  p = mp;
+}
+// the same over 16 per-wave slots replicated in every row
+__device__ __forceinline__ void reduce16(u64& c, u32& p) {
+  const u32 hi = (u32)(c >> 32), lo = (u32)c;
+  const u32 mh = row_umin32(hi);
+  const bool e1 = hi == mh;
+  const u32 ml = row_umin32(e1 ? lo : 0xFFFFFFFFu);
+  const bool e2 = e1 & (lo == ml);
+  const u32 mp = row_umin32(e2 ? p : 0xFFFFFFFFu);
+  c = ((u64)mh << 32) | ml;
+  p = mp;
 }
 
 __device__ __forceinline__ int clamp_cpu(i64 c) {
@@ -81,17 +162,22 @@ __device__ __forceinline__ void set_fault(const KParams& P, u32 code, u32 a, u32
 }
 __device__ __forceinline__ Res res_zero() { Res r; r.cpu = 0; r.mem = 0; r.clo = 0; r.chi = 0; r.gres = 0; return r; }
 
+__device__ __forceinline__ NodeHdr* hdr_of(const KParams& P, u32 q) { return (NodeHdr*)(P.blocks + (u64)q * P.block_stride); }
+__device__ __forceinline__ TlEntry* tl_of(NodeHdr* h) { return (TlEntry*)((char*)h + sizeof(NodeHdr)); }
+
 // ---------------------------------------------------------------------------------------------
 // k_init_nodes — prologue
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_nodes(const KParams P) {
+__global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ Pp) {
+  const KParams& P = *Pp;
   u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P.num_slots) return;
   const u32 n = P.slot_node[q];
   const Res tot = P.total[n];
   Res a0 = tot;
   double cost = 0.0;
-  TlEntry* T = P.tl + (u64)n * P.tl_cap;
+  NodeHdr* hd = hdr_of(P, q);
+  TlEntry* T = tl_of(hd);
   u32 len = 1;  // T[0] reserved for {now, avail0}
   const double tcpu = (double)tot.cpu / 256.0;
   for (u32 a = P.rn_off[n]; a < P.rn_off[n + 1]; ++a) {
@@ -124,8 +210,12 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams P) {
   T[len].t = kInf;  // time_avail_res_map[end].SetToZero(), JobScheduler.h:337
   T[len].r = res_zero();
   ++len;
-  P.tl_len[n] = len;
-  P.avail0[n] = a0;
+  hd->len = len;
+  hd->node = n;
+  hd->type = P.ntype[n];
+  hd->pad = 0;
+  hd->avail0 = a0;
+  hd->total = tot;
   P.cost[q] = cost;
   P.f_cpu[q] = clamp_cpu(a0.cpu);
   P.f_mem[q] = mem_mib_ceil(a0.mem);
@@ -145,17 +235,47 @@ struct JobCtx {
   u32 k, ntasks, tmin, tmax, flags;
   bool general;  // ntasks != node_num: capacities matter, priority_queue emulation needed
   u64 incl_b, incl_e, excl_b, excl_e;
+  u32 orig;      // index in the caller's queue
+  u64 poff;      // first placement record of the job
 };
 
-struct UpdRec {  // what the owning lane must refresh after a commit
-  u32 p, len;
-  double cost;
-  int fcpu;
-  u32 fmem;
-  u64 fcnt;
-  u32 has_front;
-  u32 pad;
+
+// Job records are 32-dword AoS rows in HBM; lane i of a wave loads dword i, so a whole record costs ONE
+// vector register while it is in flight (it is fetched one job ahead) and its fields are then read out
+// with v_readlane straight into scalar registers.
+enum JobRecField : u32 {
+  kJrL = 0, kJrNcpu = 2, kJrNmem = 4, kJrTcpu = 6, kJrTmem = 8, kJrGspec = 10, kJrK = 12, kJrNtasks = 13,
+  kJrTmin = 14, kJrTmax = 15, kJrFlags = 16, kJrGtot = 17, kJrOrig = 18, kJrPoff = 20, kJrInclB = 22,
+  kJrInclE = 24, kJrExclB = 26, kJrExclE = 28
 };
+__device__ __forceinline__ u32 fetch_job(const KParams& P, u64 ji) {
+  return P.jobrec[ji * kJobRecDwords + (threadIdx.x & (kJobRecDwords - 1))];
+}
+__device__ __forceinline__ u64 jr64(u32 raw, u32 f) { return ((u64)rl32(raw, f + 1) << 32) | rl32(raw, f); }
+__device__ __forceinline__ JobCtx make_job(const KParams& P, u64 ji, u32 raw) {
+  JobCtx J;
+  J.ji = ji;
+  J.L = (i64)jr64(raw, kJrL);
+  J.E = P.now + J.L;
+  J.node_view.cpu = (i64)jr64(raw, kJrNcpu);
+  J.node_view.mem = jr64(raw, kJrNmem);
+  J.node_view.gtot = rl32(raw, kJrGtot);
+  J.node_view.gspec = jr64(raw, kJrGspec);
+  J.tcpu = (i64)jr64(raw, kJrTcpu);
+  J.tmem = jr64(raw, kJrTmem);
+  J.k = rl32(raw, kJrK);
+  J.ntasks = rl32(raw, kJrNtasks);
+  J.tmin = rl32(raw, kJrTmin);
+  J.tmax = rl32(raw, kJrTmax);
+  J.flags = rl32(raw, kJrFlags);
+  J.general = J.ntasks != J.k;
+  J.min_view = compose(J.node_view, J.tcpu, J.tmem, J.tmin);
+  J.incl_b = jr64(raw, kJrInclB); J.incl_e = jr64(raw, kJrInclE);
+  J.excl_b = jr64(raw, kJrExclB); J.excl_e = jr64(raw, kJrExclE);
+  J.orig = rl32(raw, kJrOrig);
+  J.poff = jr64(raw, kJrPoff);
+  return J;
+}
 
 // membership of node n in the job's included / excluded list (JobScheduler.cpp:6202-6220)
 __device__ __forceinline__ bool in_list(const u32* lst, u64 b, u64 e, u32 n) {
@@ -164,15 +284,69 @@ __device__ __forceinline__ bool in_list(const u32* lst, u64 b, u64 e, u32 n) {
   return false;
 }
 
+// requests no node can ever satisfy under the engine's 32-bit front summaries (cpu totals are
+// validated < 2^31-2 by cns_set_nodes; a class holds <= 64 slots)
+__device__ __forceinline__ bool job_impossible(const JobCtx& J) {
+  return J.min_view.cpu > 0x7FFFFFFEll || (J.node_view.gspec & 0x8080808080808080ull) != 0;
+}
+
+// ntasks_on_node_total per node type (JobScheduler.cpp:6222): lane t evaluates type t.
+// Only jobs with ntasks > node_num need the capacity itself (rare: kept out of line).
+__device__ __noinline__ int type_capacity_general(const KParams* Pp, i64 mcpu, u64 mmem, u32 gtot, u64 gspec,
+                                                  i64 tcpu, u64 tmem, u32 tmin, u32 tmax, const Res* ttot_p) {
+  Req mv; mv.cpu = mcpu; mv.mem = mmem; mv.gtot = gtot; mv.gspec = gspec;
+  return max_tasks(mv, tcpu, tmem, tmin, tmax, *ttot_p, Pp->gres);
+}
+// Per-type static data held by lane t: exact cpu / mem, number of core ids, per-class slot counts.
+struct TypeLane { i64 cpu; u64 mem; u32 ncores; u64 cnt; };
+__device__ __forceinline__ int type_capacity(const KParams& P, const KParams* Pg, const JobCtx& J, const Res& ttot,
+                                              const TypeLane& tl, u32 lane) {
+  int tt = 0;
+  if (lane < P.num_types) {
+    if (J.general)
+      tt = type_capacity_general(Pg, J.min_view.cpu, J.min_view.mem, J.min_view.gtot, J.min_view.gspec, J.tcpu, J.tmem,
+                                 J.tmin, J.tmax, &ttot);
+    else
+      tt = feasible_counts(J.min_view, tl.cpu, tl.mem, tl.ncores, tl.cnt, P.gres) ? (int)J.tmin : 0;
+  }
+  return tt;
+}
+// get_max_tasks(res_total) > 0  <=>  the minimum view fits res_total (JobScheduler.cpp:6171-6175, :6222-6223)
+__device__ __forceinline__ u64 type_ok_mask(const KParams& P, const JobCtx& J, const TypeLane& tl, u32 lane) {
+  return __ballot((lane < P.num_types) & feasible_counts(J.min_view, tl.cpu, tl.mem, tl.ncores, tl.cnt, P.gres));
+}
+
+constexpr u32 kScan = (kWaves - 1) * 64;  // 960 scanner lanes
+__device__ __forceinline__ u32 slot_of_code(u32 code) { return (code >> 10) * kScan + (code & 1023u); }
+
 // ---------------------------------------------------------------------------------------------
-// wave-0 routines (all 64 lanes of wave 0 execute them; values named "uniform" are wave-uniform)
+// worker routines (all 64 lanes of wave 0 execute them)
 // ---------------------------------------------------------------------------------------------
 
-// Window-min of node n over [now, E): min_res_on_node = res_avail; for entries with time < E: Ckmin
-// (JobScheduler.cpp:6278-6283).  Lanes fold entries in parallel, then a wave64 butterfly.
-__device__ __forceinline__ Res window_min(const KParams& P, u32 n, const Res& a0, i64 E, u32 lane) {
-  const TlEntry* T = P.tl + (u64)n * P.tl_cap;
-  const u32 len = P.tl_len[n];
+// Window-min over [now, E) from a register-resident chunk (lane i holds entry i, len <= 64):
+// min_res_on_node = res_avail; for entries with time < E: Ckmin  (JobScheduler.cpp:6278-6283).
+__device__ __forceinline__ Res window_min_regs(const TlEntry& e, bool act, const Res& a0, i64 E) {
+  const bool inw = act && e.t < E;
+  i64 cpu = inw ? e.r.cpu : a0.cpu;
+  u64 mem = inw ? e.r.mem : a0.mem;
+  const bool hasc = inw && (e.r.clo | e.r.chi) != 0;  // an empty core set is skipped by Ckmin
+  u64 clo = hasc ? e.r.clo : ~0ull, chi = hasc ? e.r.chi : ~0ull;
+  u64 g = inw ? e.r.gres : ~0ull;
+  Res m;
+  cpu = wave_min_i64(cpu);
+  m.cpu = cpu < a0.cpu ? cpu : a0.cpu;
+  mem = wave_min_u64(mem);
+  m.mem = mem < a0.mem ? mem : a0.mem;
+  clo = wave_and_u64(clo);
+  chi = wave_and_u64(chi);
+  m.gres = wave_and_u64(g) & a0.gres;
+  if ((a0.clo | a0.chi) != 0) { m.clo = a0.clo & clo; m.chi = a0.chi & chi; }
+  else { m.clo = 0; m.chi = 0; }
+  return m;
+}
+
+// General form for time maps longer than one chunk.
+__device__ __noinline__ Res window_min(const TlEntry* T, u32 len, const Res& a0, i64 E, u32 lane) {
   i64 cpu = a0.cpu;
   u64 mem = a0.mem, clo = ~0ull, chi = ~0ull, g = a0.gres;
   for (u32 base = 0; base < len; base += 64) {
@@ -185,7 +359,7 @@ __device__ __forceinline__ Res window_min(const KParams& P, u32 n, const Res& a0
     if (inw) {
       cpu = e.r.cpu < cpu ? e.r.cpu : cpu;
       mem = e.r.mem < mem ? e.r.mem : mem;
-      if ((e.r.clo | e.r.chi) != 0) { clo &= e.r.clo; chi &= e.r.chi; }  // empty core set = skipped
+      if ((e.r.clo | e.r.chi) != 0) { clo &= e.r.clo; chi &= e.r.chi; }
       g &= e.r.gres;
     }
     if (__any(act && !inw)) break;  // sorted by time: nothing later is inside the window
@@ -202,9 +376,7 @@ __device__ __forceinline__ Res window_min(const KParams& P, u32 n, const Res& a0
 }
 
 // Exclusive job: every entry with time < E must still hold the whole node (JobScheduler.cpp:6249-6257).
-__device__ __forceinline__ bool window_all_total(const KParams& P, u32 n, const Res& tot, i64 E, u32 lane) {
-  const TlEntry* T = P.tl + (u64)n * P.tl_cap;
-  const u32 len = P.tl_len[n];
+__device__ __noinline__ bool window_all_total(const TlEntry* T, u32 len, const Res& tot, i64 E, u32 lane) {
   bool bad = false;
   for (u32 base = 0; base < len; base += 64) {
     u32 i = base + lane;
@@ -221,10 +393,45 @@ __device__ __forceinline__ bool window_all_total(const KParams& P, u32 n, const 
 
 // NodeState::UpdateResourceInNode (allocate), JobScheduler.h:340-459, on the sorted-array time map.
 // Entries with start <= t < end lose `res`; boundaries at start / end are inserted when missing (the
-// end boundary copies the un-subtracted value of the entry covering `end`).  Returns the new length.
-__device__ u32 tl_commit(const KParams& P, u32 n, i64 start, i64 end, const Res& res, u32 lane, u32 job) {
-  TlEntry* T = P.tl + (u64)n * P.tl_cap;
-  const u32 len = P.tl_len[n];
+// end boundary copies the un-subtracted value of the entry covering `end`).
+// Register form: lane i holds entry i of a map with len <= 64.  Returns the new length.
+__device__ __forceinline__ u32 tl_commit_regs(const KParams& P, NodeHdr* hd, TlEntry* T, TlEntry e, u32 len,
+                                              i64 start, i64 end, const Res& res, u32 lane, u32 job) {
+  const bool act = lane < len;
+  const i64 t = act ? e.t : kInf;
+  const u32 c_start = (u32)__popcll(__ballot(act && t <= start));
+  const u32 c_end = (u32)__popcll(__ballot(act && t <= end));
+  if (c_start == 0 || c_end >= len) {  // cases #1/#2 cannot occur: the INF sentinel is last
+    if (lane == 0) set_fault(P, 1, job, hd->node, len);
+    return len;
+  }
+  const u32 ib = c_start - 1, ie0 = c_end - 1;
+  TlEntry eb, ee;
+  eb.t = (i64)rl64((u64)e.t, ib);
+  ee.t = (i64)rl64((u64)e.t, ie0);
+  eb.r = res_zero();
+  ee.r = res_zero();
+  const bool ins_s = eb.t != start, ins_e = ee.t != end;
+  const u32 np = lane + ((ins_s && lane > ib) ? 1u : 0u) + ((ins_e && lane > ie0) ? 1u : 0u);
+  const bool sub = act && t >= start && t < end;
+  if (ins_s) eb.r = rl_res(e.r, ib);    // pre-subtraction values of the covering entries
+  if (ins_e) ee.r = rl_res(e.r, ie0);
+  if (sub) res_sub(e.r, res);
+  if (act && lane >= ib && (np != lane || sub)) T[np] = e;
+  const u32 nlen = len + (ins_s ? 1u : 0u) + (ins_e ? 1u : 0u);
+  if (lane == 0) {
+    if (ins_s) { TlEntry s = eb; s.t = start; res_sub(s.r, res); T[ib + 1] = s; }
+    if (ins_e) { TlEntry x = ee; x.t = end; T[ie0 + (ins_s ? 1u : 0u) + 1] = x; }
+    hd->len = nlen;
+  }
+  return nlen;
+}
+
+// General form (any length): chunks are rewritten from the highest down so that the <= 2-slot shift
+// never overwrites an entry that has not been read yet.
+__device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, i64 end, const Res& res, u32 lane, u32 job) {
+  TlEntry* T = tl_of(hd);
+  const u32 len = hd->len;
   u32 c_start = 0, c_end = 0;  // #entries with t <= start / t <= end
   for (u32 base = 0; base < len; base += 64) {
     u32 i = base + lane;
@@ -234,8 +441,8 @@ __device__ u32 tl_commit(const KParams& P, u32 n, i64 start, i64 end, const Res&
     c_end += __popcll(__ballot(act && t <= end));
     if (__any(act && t > end)) break;
   }
-  if (c_start == 0 || c_end >= len || len + 2 > P.tl_cap) {  // cases #1/#2 cannot occur: the INF sentinel is last
-    if (lane == 0) set_fault(P, 1, job, n, len);
+  if (c_start == 0 || c_end >= len || len + 2 > P.tl_cap) {
+    if (lane == 0) set_fault(P, 1, job, hd->node, len);
     return len;
   }
   const u32 ib = c_start - 1, ie0 = c_end - 1;
@@ -254,27 +461,19 @@ __device__ u32 tl_commit(const KParams& P, u32 n, i64 start, i64 end, const Res&
     if (sub) res_sub(e.r, res);
     if (act && (np != i || sub)) T[np] = e;
   }
+  const u32 nlen = len + (ins_s ? 1u : 0u) + (ins_e ? 1u : 0u);
   if (lane == 0) {
-    if (ins_s) {
-      TlEntry s = eb;
-      s.t = start;
-      res_sub(s.r, res);
-      T[ib + 1] = s;
-    }
-    if (ins_e) {
-      TlEntry x = ee;
-      x.t = end;
-      T[ie0 + (ins_s ? 1u : 0u) + 1] = x;
-    }
-    P.tl_len[n] = len + (ins_s ? 1u : 0u) + (ins_e ? 1u : 0u);
+    if (ins_s) { TlEntry s = eb; s.t = start; res_sub(s.r, res); T[ib + 1] = s; }
+    if (ins_e) { TlEntry x = ee; x.t = end; T[ie0 + (ins_s ? 1u : 0u) + 1] = x; }
+    hd->len = nlen;
   }
   __threadfence_block();
-  return len + (ins_s ? 1u : 0u) + (ins_e ? 1u : 0u);
+  return nlen;
 }
 
-// Earliest s >= t such that `alloc` fits node n throughout [s, s + L); kInf if never.
-// (per-node half of EarliestStartSubsetSelector, JobScheduler.h:737-790,812-855)
-__device__ i64 next_fit(const TlEntry* T, u32 len, const Res& alloc, i64 L, i64 t, u32& j) {
+// Earliest s >= t such that `alloc` fits the node throughout [s, s + L); kInf if never.
+// (per-node half of EarliestStartSubsetSelector, JobScheduler.h:737-790,812-855) — one lane per node.
+__device__ __noinline__ i64 next_fit(const TlEntry* T, u32 len, const Res& alloc, i64 L, i64 t, u32& j) {
   while (j + 1 < len && T[j + 1].t <= t) ++j;
   i64 s = t;
   u32 i = j;
@@ -294,20 +493,45 @@ __device__ i64 next_fit(const TlEntry* T, u32 len, const Res& alloc, i64 L, i64 
   }
 }
 
-// Shared by the "start now" and "backfill" endings: H[0..k) holds the selected nodes with their
-// assigned task counts; computes the allocations, commits them into the time maps and costs, emits
-// the placement records (sorted by node index) and the owner updates.
-__device__ void commit_selection(const KParams& P, const JobCtx& J, HeapEnt* H, u32 qbeg, i64 start,
+// Same question for ONE node whose map sits in registers (lane i = entry i, len <= 64), answered with
+// a ballot of "alloc fits entry i" and bit scans over its runs.
+__device__ __forceinline__ i64 next_fit_regs(const TlEntry& e, u32 len, const Res& alloc, i64 L, i64 t0, u32 lane) {
+  const bool act = lane < len;
+  const u64 valid = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
+  const u64 sat = __ballot(act && res_le(alloc, e.r));
+  u32 idx = (u32)__popcll(__ballot(act && e.t <= t0)) - 1u;  // entry covering t0 (T[0].t = now <= t0)
+  i64 s = t0;
+  while (true) {
+    if (!((sat >> idx) & 1ull)) {  // not satisfied here: jump to the start of the next satisfied run
+      const u64 above = idx >= 63 ? 0ull : (sat & ~((2ull << idx) - 1ull));
+      if (above == 0) return kInf;
+      idx = (u32)__builtin_ctzll(above);
+      s = (i64)rl64((u64)e.t, idx);
+    }
+    const u64 unsat = idx >= 63 ? 0ull : (~sat & valid & ~((2ull << idx) - 1ull));
+    if (unsat == 0) return s;  // satisfied through the last entry
+    const u32 ue = (u32)__builtin_ctzll(unsat);
+    const i64 endt = (i64)rl64((u64)e.t, ue);
+    if (endt - s >= L) return s;
+    idx = ue;
+  }
+}
+
+// Shared by the "start now" and "backfill" endings of the general path: H[0..k) holds the selected
+// nodes with their assigned task counts and allocations; commits them into the time maps and costs,
+// emits the placement records (sorted by node index) and the owner updates.
+__device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J, HeapEnt* H, u32 qbeg, i64 start,
                                  u32 lane, UpdRec* s_upd, int* s_nupd) {
   const i64 end = start + J.L;  // job->end_time = start_time + time_limit, JobScheduler.cpp:6772
-  const u32 orig = P.j_orig[J.ji];
-  const u64 poff = P.j_place_off[J.ji];
+  const u32 orig = J.orig;
+  const u64 poff = J.poff;
   for (u32 i = 0; i < J.k; ++i) {
     HeapEnt ent = H[i];
-    const u32 n = ent.node;
-    const Res tot = P.total[n];
-    const Res e0 = P.tl[(u64)n * P.tl_cap].r;
-    u32 newlen = tl_commit(P, n, start, end, ent.res, lane, orig);
+    const u32 q = qbeg + slot_of_code(ent.p);
+    NodeHdr* hd = hdr_of(P, q);
+    const Res tot = hd->total;
+    const Res e0 = tl_of(hd)[0].r;
+    u32 newlen = tl_commit(P, hd, start, end, ent.res, lane, orig);
     // MinCpuTimeRatioFirst::UpdateCost, JobScheduler.h:47-53 — ratio first, then x seconds, then +=
     double ratio = ((double)ent.res.cpu / 256.0) / ((double)tot.cpu / 256.0);
     double delta = (double)(end - start) * ratio;
@@ -324,13 +548,12 @@ __device__ void commit_selection(const KParams& P, const JobCtx& J, HeapEnt* H, 
     u.fcnt = class_counts(f.gres, P.gres);
     u.pad = 0;
     if (lane == 0) {
-      const u32 q = qbeg + (ent.p >> 10) * 960u + (ent.p & 1023u);
       P.cost[q] = ncost;
       if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
-      if (J.k <= (u32)kMaxUpd) s_upd[i] = u;
+      s_upd[i] = u;
     }
   }
-  if (lane == 0) *s_nupd = J.k <= (u32)kMaxUpd ? (int)J.k : -1;
+  if (lane == 0) *s_nupd = (int)J.k;
   // placement records, ascending node index: rank = #selected nodes with a smaller index
   for (u32 i = lane; i < J.k; i += 64) {
     const HeapEnt me = H[i];
@@ -347,10 +570,50 @@ __device__ void commit_selection(const KParams& P, const JobCtx& J, HeapEnt* H, 
   }
 }
 
+// Single-node ending (node_num == 1) straight from the register-resident chunk: commit, cost, owner
+// update and the one placement record.
+__device__ __forceinline__ void commit_single_regs(const KParams& P, const JobCtx& J, NodeHdr* hd, const NodeHdr& h,
+                                                   const TlEntry& e, u32 q, u32 code, double cost, const Res& alloc,
+                                                   i64 start, int reason, u32 lane, UpdRec* s_upd, int* s_nupd) {
+  const i64 end = start + J.L;
+  const u32 orig = J.orig;
+  const u64 poff = J.poff;
+  const u32 newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, alloc, lane, orig);
+  const double ratio = ((double)alloc.cpu / 256.0) / ((double)h.total.cpu / 256.0);
+  const double delta = (double)(end - start) * ratio;
+  const double ncost = cost + delta;
+  if (lane == 0) {
+    UpdRec u;
+    u.p = code;
+    u.len = newlen;
+    u.cost = ncost;
+    u.has_front = (start == P.now) ? 1u : 0u;
+    Res f = e.r;  // lane 0 holds entry 0 = the entry at `now`
+    if (u.has_front) res_sub(f, alloc);
+    u.fcpu = clamp_cpu(f.cpu);
+    u.fmem = mem_mib_ceil(f.mem);
+    u.fcnt = class_counts(f.gres, P.gres);
+    u.pad = 0;
+    P.cost[q] = ncost;
+    if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
+    s_upd[0] = u;
+    *s_nupd = 1;
+    P.o_node[poff] = h.node;
+    P.o_ntasks[poff] = 1;
+    P.o_cpu[poff] = alloc.cpu;
+    P.o_mem[poff] = alloc.mem;
+    P.o_clo[poff] = alloc.clo;
+    P.o_chi[poff] = alloc.chi;
+    P.o_gres[poff] = alloc.gres;
+    P.o_start[orig] = start;
+    P.o_reason[orig] = (uint8_t)reason;
+  }
+}
+
 // Task distribution over the k selected nodes, smallest capacity first (JobScheduler.cpp:6304-6325 /
 // :6345-6367), then the per-node allocation cut out of ent.res.  Leaves H[i].ntasks = tasks on the node
 // and H[i].res = allocated_res on the node.  Returns false on an invariant violation.
-__device__ bool distribute_and_alloc(const KParams& P, const JobCtx& J, HeapEnt* H, u32 lane) {
+__device__ __noinline__ bool distribute_and_alloc(const KParams& P, const JobCtx& J, HeapEnt* H, u32 lane) {
   if (J.general) {
     if (lane == 0) {
       int rest = (int)J.ntasks - (int)J.k;
@@ -381,72 +644,401 @@ __device__ bool distribute_and_alloc(const KParams& P, const JobCtx& J, HeapEnt*
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_select — one persistent workgroup per partition, wave-specialised:
-//   wave 0        "worker"  : exact node test, priority_queue emulation, commit, backfill (serial part)
-//   waves 1..15   "scanners": hold the partition's node tile in registers (slot p = r*960 + t) and, per
-//                             round, deliver the next node in (cost, index) order that passes the filter
+// k_select — one persistent, wave-specialised workgroup per partition.
 // Both roles run the same barrier schedule; they exchange only the per-wave argmin slots, one flag and
 // the owner-update records through LDS.  Separate branches => separate register allocation: the tile
 // registers are not live in the worker's code and vice versa.
+//
+// Barrier schedule of one job (W = worker, S = scanners):
+//   S: publish A (can-start-now argmin) and T (fits-res_total argmin)                   B1
+//   while A != none:   W: exact test [+ commit]  -> verdict                            B2
+//                      verdict 2 -> done | else S: next A argmin                       B1
+//   A == none  -> phase B: cur = T;  while cur != none and < k nodes: S: next T argmin  B1 (+B2 if ntasks>k)
+//                 W: allocations vs res_total, earliest start, commit -> verdict       B3
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ JobCtx load_job(const KParams& P, u64 ji) {
-  JobCtx J;
-  J.ji = ji;
-  J.L = P.j_L[ji];
-  J.E = P.now + J.L;
-  J.node_view.cpu = P.j_ncpu[ji];
-  J.node_view.mem = P.j_nmem[ji];
-  J.node_view.gtot = P.j_gtot[ji];
-  J.node_view.gspec = P.j_gspec[ji];
-  J.tcpu = P.j_tcpu[ji];
-  J.tmem = P.j_tmem[ji];
-  J.k = P.j_k[ji];
-  J.ntasks = P.j_ntasks[ji];
-  J.tmin = P.j_tmin[ji];
-  J.tmax = P.j_tmax[ji];
-  J.flags = P.j_flags[ji];
-  J.general = J.ntasks != J.k;
-  J.min_view = compose(J.node_view, J.tcpu, J.tmem, J.tmin);
-  J.incl_b = J.incl_e = J.excl_b = J.excl_e = 0;
-  if (J.flags & kJfIncl) { J.incl_b = P.j_incl_off[ji]; J.incl_e = P.j_incl_off[ji + 1]; }
-  if (J.flags & kJfExcl) { J.excl_b = P.j_excl_off[ji]; J.excl_e = P.j_excl_off[ji + 1]; }
-  return J;
-}
+struct WorkerShared {
+  u64 (*wc)[kWaves];
+  u32 (*wp)[kWaves];
+  int* flag;
+  int* nupd;
+  UpdRec* upd;
+  HeapEnt* heap;
+};
 
-// requests no node can ever satisfy under the engine's 32-bit front summaries (cpu totals are
-// validated < 2^31-1 by cns_set_nodes; a class holds <= 64 slots)
-__device__ __forceinline__ bool job_impossible(const JobCtx& J) {
-  return J.min_view.cpu > 0x7FFFFFFEll || (J.node_view.gspec & 0x8080808080808080ull) != 0;
-}
+#ifdef CNS_PROF
+#define PROF_T(var) const long long var = clock64()
+#define PROF_ADD(slot, a, b) do { if (lane == 0) P.prof[(size_t)blockIdx.x * 32 + (slot)] += (u64)((b) - (a)); } while (0)
+#define PROF_CNT(slot) do { if (lane == 0) P.prof[(size_t)blockIdx.x * 32 + (slot)] += 1; } while (0)
+#define PROF_ADDS(slot, a, b) do { if (lane == 0 && wave == 1) P.prof[(size_t)blockIdx.x * 32 + (slot)] += (u64)((b) - (a)); } while (0)
+#else
+#define PROF_T(var)
+#define PROF_ADD(slot, a, b)
+#define PROF_CNT(slot)
+#define PROF_ADDS(slot, a, b)
+#endif
 
-// ntasks_on_node_total per node type (JobScheduler.cpp:6222): lane t evaluates type t
-__device__ __forceinline__ int type_capacity(const KParams& P, const JobCtx& J, const Res& ttot, u32 lane) {
-  int tt = 0;
-  if (lane < P.num_types) {
-    if (J.general) tt = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, ttot, P.gres);
-    else { Res tmp; tt = feasible(J.min_view, ttot, tmp, P.gres) ? (int)J.tmin : 0; }
+// Out-of-line worker path for everything that is not "node_num == 1, ntasks == 1, shared node":
+// multi-node jobs, ntasks > node_num (priority_queue emulation) and exclusive jobs.  Enters after the
+// round-0 barrier with the A and T winners, leaves after the job's last barrier; returns the LDS
+// double-buffer parity.
+__device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared sh, const JobCtx* Jp, int par,
+                                            u64 wc, u32 wcode, u64 tc, u32 tcode, int tt_lane, u32 qbeg,
+                                            HeapEnt* gheap) {
+  const JobCtx J = *Jp;
+  const u32 lane = threadIdx.x & 63u;
+  const bool excl_job = (J.flags & kJfExclusive) != 0;
+  const u32 orig = J.orig;
+  HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
+  UpdRec* const s_upd = (J.k <= (u32)kMaxUpd) ? sh.upd : P.g_upd + qbeg;  // long lists go through HBM
+  int* const s_nupd = sh.nupd;
+
+  // ---- Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) -------------
+  int hsize = 0, hsum = 0;  // topk_nodes_avail.size(), topk_ntasks_sum_avail
+  while (wcode != kNone) {
+    const u32 q = qbeg + slot_of_code(wcode);
+    NodeHdr* const hd = hdr_of(P, q);
+    TlEntry* const T = tl_of(hd);
+    int code = 0;
+    const u32 len = hd->len;
+    const u32 n = hd->node;
+    bool ok = false;
+    Res m = res_zero();
+    int ta = 0;
+    if (!excl_job) {
+      const Res a0 = hd->avail0;
+      Res f;
+      if (feasible(J.min_view, a0, f, P.gres)) {             // :6274
+        m = window_min(T, len, a0, J.E, lane);               // :6278-6283
+        if (J.general) ta = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, m, P.gres);  // :6285
+        else ta = feasible(J.min_view, m, f, P.gres) ? (int)J.tmin : 0;
+        ok = ta > 0;
+      }
+    } else {
+      m = hd->total;
+      ok = window_all_total(T, len, m, J.E, lane);          // :6250-6260
+      ta = __shfl(tt_lane, (int)hd->type);
+    }
+    if (ok) {
+      HeapEnt x;
+      x.ntasks = ta; x.p = wcode; x.node = n; x.pad = 0;
+      x.cost = __longlong_as_double((long long)wc);
+      x.res = m;
+      int nsum = hsum + ta, nsize = hsize + 1;
+      if (lane == 0) {
+        H[hsize] = x;
+        pq_push(H, nsize);                                                // :6288-6289
+        if (nsize > (int)J.k) { nsum -= H[0].ntasks; pq_pop(H, nsize); }  // :6290-6293
+      }
+      nsum = __shfl(nsum, 0);
+      if (nsize > (int)J.k) --nsize;
+      hsum = nsum; hsize = nsize;
+      __threadfence_block();
+      code = 1;
+      if (hsize == (int)J.k && (u32)hsum >= J.ntasks) {                   // :6294-6297
+        if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 2, orig, n, 2); }
+        commit_selection(P, J, H, qbeg, P.now, lane, s_upd, s_nupd);      // start_time = now (:6326)
+        if (lane == 0) { P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
+        code = 2;
+      }
+    }
+    if (lane == 0) *sh.flag = code;
+    __syncthreads();  // B2: verdict (and, on success, the owner updates) visible to the scanners
+    if (code == 2) return par;
+    __syncthreads();  // B1 of the next round
+    wc = sh.wc[par][lane & (kWaves - 1)];
+    wcode = sh.wp[par][lane & (kWaves - 1)];
+    reduce16(wc, wcode);
+    par ^= 1;
+    wc = uni64(wc); wcode = uni32(wcode);
   }
-  return tt;
+
+  // ---- Phase B: top-k nodes by total capacity, then backfill -----------------------------------
+  // (JobScheduler.cpp:6233-6242, :6335-6368, Backfill_ :6371-6376)
+  int code = 0;
+  int nsel = 0, tsum = 0;
+  bool complete = false;
+  u64 cc = tc;
+  u32 ccode = tcode;
+  while (ccode != kNone) {
+    NodeHdr* const hd = hdr_of(P, qbeg + slot_of_code(ccode));
+    HeapEnt x;
+    x.p = ccode; x.node = hd->node; x.pad = 0;
+    x.cost = __longlong_as_double((long long)cc);
+    x.res = res_zero();
+    if (!J.general) {
+      x.ntasks = 1;
+      if (lane == 0) H[nsel] = x;
+      ++nsel;
+      if (nsel == (int)J.k) { complete = true; break; }
+    } else {
+      const int tt = __shfl(tt_lane, (int)hd->type);
+      x.ntasks = tt;
+      int nsum = tsum + tt, nsize = nsel + 1;  // the push condition (:6233-6234) held, else we had stopped
+      if (lane == 0) {
+        H[nsel] = x;
+        pq_push(H, nsize);
+        if (nsize > (int)J.k) { nsum -= H[0].ntasks; pq_pop(H, nsize); }
+      }
+      nsum = __shfl(nsum, 0);
+      if (nsize > (int)J.k) --nsize;
+      tsum = nsum; nsel = nsize;
+      const bool stop = nsel == (int)J.k && (u32)tsum >= J.ntasks;
+      if (lane == 0) *sh.flag = stop ? 1 : 0;
+      __syncthreads();  // B2 (ntasks > node_num only)
+      if (stop) { complete = true; break; }
+    }
+    __syncthreads();  // B1
+    cc = sh.wc[par][lane & (kWaves - 1)];
+    ccode = sh.wp[par][lane & (kWaves - 1)];
+    reduce16(cc, ccode);
+    par ^= 1;
+    cc = uni64(cc); ccode = uni32(ccode);
+  }
+  if (complete) {
+    __threadfence_block();
+    for (u32 i = lane; i < J.k; i += 64) {
+      HeapEnt x = H[i];
+      x.res = hdr_of(P, qbeg + slot_of_code(x.p))->total;
+      H[i] = x;
+      P.bf_j[qbeg + i] = 0;
+    }
+    __threadfence_block();
+    if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 3, orig, 0, 1); }
+    // EarliestStartSubsetSelector::CalcEarliestStartTime as a fixed point over the k nodes
+    i64 t = P.now;
+    bool found = false;
+    for (u32 iter = 0; iter < (1u << 22); ++iter) {
+      i64 Tm = t;
+      for (u32 i = lane; i < J.k; i += 64) {
+        const HeapEnt x = H[i];
+        NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
+        u32 j = P.bf_j[qbeg + i];
+        i64 s = next_fit(tl_of(hd), hd->len, x.res, J.L, t, j);
+        P.bf_j[qbeg + i] = j;
+        Tm = s > Tm ? s : Tm;
+      }
+      Tm = wave_max_i64(Tm);
+      if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
+      if (Tm == t) { found = true; break; }
+      t = Tm;
+    }
+    if (found) {
+      int reason = 0;
+      if (t != P.now) {  // JobScheduler.cpp:6797-6833 (no reservations in this slice)
+        bool notle = false;
+        for (u32 i = lane; i < J.k; i += 64) {
+          const HeapEnt x = H[i];
+          if (!res_le(x.res, hdr_of(P, qbeg + slot_of_code(x.p))->avail0)) notle = true;
+        }
+        reason = __any(notle) ? 2 /*Resource*/ : 1 /*Priority*/;
+      }
+      commit_selection(P, J, H, qbeg, t, lane, s_upd, s_nupd);
+      if (lane == 0) { P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
+      code = 2;
+    }
+  }
+  if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
+  if (lane == 0) *sh.flag = code;
+  __syncthreads();  // B3
+  return par;
 }
 
-__device__ __forceinline__ void reduce16(u64& wc, u32& wp) {
-#pragma unroll
-  for (int off = kWaves / 2; off; off >>= 1) {
-    u64 oc = __shfl_xor(wc, off);
-    u32 op = __shfl_xor(wp, off);
-    bool take = (oc < wc) || (oc == wc && op < wp);
-    wc = take ? oc : wc;
-    wp = take ? op : wp;
+// Loads the node block of slot q the way the fast paths want it: header scalarised, lane i <- entry i.
+__device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, NodeHdr*& hd, NodeHdr& h, TlEntry& e) {
+  hd = hdr_of(P, q);
+  h = *hd;
+  e = tl_of(hd)[lane];
+  h.len = uni32(h.len); h.node = uni32(h.node); h.type = uni32(h.type);
+  h.avail0 = uni_res(h.avail0); h.total = uni_res(h.total);
+}
+
+// Commit pick i of a multi-node selection (time map, cost, owner update i); H[i].res = its allocation.
+__device__ __forceinline__ void commit_pick(const KParams& P, const JobCtx& J, const HeapEnt& x, u32 i, u32 qbeg,
+                                            i64 start, u32 lane, UpdRec* s_upd, u32 orig) {
+  const u32 q = qbeg + slot_of_code(x.p);
+  NodeHdr* hd; NodeHdr h; TlEntry e;
+  load_block(P, q, lane, hd, h, e);
+  const i64 end = start + J.L;
+  const Res e0 = rl_res(e.r, 0);  // entry at `now`
+  u32 newlen;
+  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, x.res, lane, orig);
+  else newlen = tl_commit(P, hd, start, end, x.res, lane, orig);
+  const double ratio = ((double)x.res.cpu / 256.0) / ((double)h.total.cpu / 256.0);
+  const double ncost = x.cost + (double)(end - start) * ratio;
+  if (lane == 0) {
+    UpdRec u;
+    u.p = x.p; u.len = newlen; u.cost = ncost;
+    u.has_front = (start == P.now) ? 1u : 0u;
+    Res f = e0;
+    if (u.has_front) res_sub(f, x.res);
+    u.fcpu = clamp_cpu(f.cpu); u.fmem = mem_mib_ceil(f.mem); u.fcnt = class_counts(f.gres, P.gres); u.pad = 0;
+    P.cost[q] = ncost;
+    if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
+    s_upd[i] = u;
   }
 }
 
-constexpr u32 kScan = (kWaves - 1) * 64;  // 960 scanner lanes
-__device__ __forceinline__ u32 slot_of_code(u32 code) { return (code >> 10) * kScan + (code & 1023u); }
+// placement records of a k-node selection, ascending node index (k <= 64: lane i holds pick i)
+__device__ __forceinline__ void emit_placements(const KParams& P, const JobCtx& J, const HeapEnt* H, u32 lane) {
+  const u64 poff = J.poff;
+  if (lane < J.k) {
+    const HeapEnt me = H[lane];
+    u32 rank = 0;
+    for (u32 m = 0; m < J.k; ++m) rank += H[m].node < me.node ? 1u : 0u;
+    const u64 o = poff + rank;
+    P.o_node[o] = me.node; P.o_ntasks[o] = 1;
+    P.o_cpu[o] = me.res.cpu; P.o_mem[o] = me.res.mem; P.o_clo[o] = me.res.clo; P.o_chi[o] = me.res.chi;
+    P.o_gres[o] = me.res.gres;
+  }
+}
+
+// Out-of-line worker path for multi-node jobs with ntasks == node_num on shared nodes (2 <= k <= kMaxUpd):
+// same barrier schedule as the general path, but every node is handled with the one-read block primitives.
+__device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShared sh, const JobCtx* Jp, int par,
+                                             u64 wc, u32 wcode, u64 tc, u32 tcode, u32 qbeg) {
+  const JobCtx J = *Jp;
+  const u32 lane = threadIdx.x & 63u;
+  const u32 orig = J.orig;
+  HeapEnt* const H = sh.heap;
+  const Req one_view = compose(J.node_view, J.tcpu, J.tmem, 1);
+
+  // ---- Phase A: the first k nodes in cost order that can start the job now (:6188-6333) ----------
+  u32 npick = 0;
+  while (wcode != kNone) {
+    const u32 q = qbeg + slot_of_code(wcode);
+    NodeHdr* hd; NodeHdr h; TlEntry e;
+    load_block(P, q, lane, hd, h, e);
+    int code = 0;
+    Res f, m;
+    bool ok = false;
+    if (feasible(J.min_view, h.avail0, f, P.gres)) {
+      m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
+                              : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));
+      ok = feasible(J.min_view, m, f, P.gres);
+    }
+    if (ok) {
+      Res alloc = f;
+      if (J.tmin != 1 && !feasible(one_view, m, alloc, P.gres)) { if (lane == 0) set_fault(P, 2, orig, h.node, 3); }
+      if (lane == 0) {
+        HeapEnt x; x.ntasks = 1; x.p = wcode; x.node = h.node; x.pad = 0;
+        x.cost = __longlong_as_double((long long)wc); x.res = alloc;
+        H[npick] = x;
+      }
+      ++npick;
+      code = 1;
+      if (npick == J.k) {  // :6294-6297
+        __threadfence_block();
+        for (u32 i = 0; i < J.k; ++i) commit_pick(P, J, H[i], i, qbeg, P.now, lane, sh.upd, orig);
+        emit_placements(P, J, H, lane);
+        if (lane == 0) { *sh.nupd = (int)J.k; P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
+        code = 2;
+      }
+    }
+    if (lane == 0) *sh.flag = code;
+    __syncthreads();  // B2
+    if (code == 2) return par;
+    __syncthreads();  // B1 of the next round
+    wc = sh.wc[par][lane & (kWaves - 1)];
+    wcode = sh.wp[par][lane & (kWaves - 1)];
+    reduce16(wc, wcode);
+    par ^= 1;
+    wc = uni64(wc); wcode = uni32(wcode);
+  }
+
+  // ---- Phase B: first k nodes by res_total in cost order, earliest common start (:6335-6376) -------
+  int code = 0;
+  u32 nsel = 0;
+  bool complete = false;
+  u64 cc = tc;
+  u32 ccode = tcode;
+  while (ccode != kNone) {
+    if (lane == 0) {
+      HeapEnt x; x.ntasks = 1; x.p = ccode; x.node = 0; x.pad = 0;
+      x.cost = __longlong_as_double((long long)cc); x.res = res_zero();
+      H[nsel] = x;
+    }
+    ++nsel;
+    if (nsel == J.k) { complete = true; break; }
+    __syncthreads();  // B1
+    cc = sh.wc[par][lane & (kWaves - 1)];
+    ccode = sh.wp[par][lane & (kWaves - 1)];
+    reduce16(cc, ccode);
+    par ^= 1;
+    cc = uni64(cc); ccode = uni32(ccode);
+  }
+  if (complete) {
+    __threadfence_block();
+    bool bad = false, notle = false;
+    if (lane < J.k) {  // allocation against res_total (:6353-6361)
+      HeapEnt x = H[lane];
+      const NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
+      x.node = hd->node;
+      Res a;
+      if (!feasible(one_view, hd->total, a, P.gres)) bad = true; else x.res = a;
+      notle = !res_le(x.res, hd->avail0);
+      H[lane] = x;
+    }
+    if (__any(bad) && lane == 0) set_fault(P, 3, orig, 0, 2);
+    notle = __any(notle);
+    __threadfence_block();
+    // EarliestStartSubsetSelector::CalcEarliestStartTime as a fixed point over the k nodes
+    i64 t = P.now;
+    bool found = false;
+    for (u32 iter = 0; iter < (1u << 20); ++iter) {
+      i64 Tm = t;
+      for (u32 i = 0; i < J.k; ++i) {
+        const HeapEnt x = H[i];
+        NodeHdr* hd; NodeHdr h; TlEntry e;
+        load_block(P, qbeg + slot_of_code(x.p), lane, hd, h, e);
+        i64 s;
+        if (h.len <= 64) s = next_fit_regs(e, h.len, x.res, J.L, t, lane);
+        else { u32 j = 0; s = next_fit(tl_of(hd), h.len, x.res, J.L, t, j); }
+        Tm = s > Tm ? s : Tm;
+      }
+      if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
+      if (Tm == t) { found = true; break; }
+      t = Tm;
+    }
+    if (found) {
+      int reason = 0;
+      if (t != P.now) reason = notle ? 2 /*Resource*/ : 1 /*Priority*/;  // :6810-6831
+      for (u32 i = 0; i < J.k; ++i) commit_pick(P, J, H[i], i, qbeg, t, lane, sh.upd, orig);
+      emit_placements(P, J, H, lane);
+      if (lane == 0) { *sh.nupd = (int)J.k; P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
+      code = 2;
+    }
+  }
+  if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
+  if (lane == 0) *sh.flag = code;
+  __syncthreads();  // B3
+  return par;
+}
+
+// ---- scanner tile compression -----------------------------------------------------------------------
+// Per node the scanners keep 5 dwords: fp64 cost (exact), front cpu (exact i32) and two packed words
+//   mw = front mem in GiB rounded up (16 bit, saturating) | time-map length << 16 | node type << 26
+//   gn = front GRES popcount per class, 4 bits each, saturating at 15
+// The front values only feed a NECESSARY condition (the worker's exact test decides), so rounding the
+// node side up and the request side down keeps the filter conservative.
+__device__ __forceinline__ u32 mem_gib16(u32 mib) { u32 g = (mib + 1023u) >> 10; return g > 0xFFFFu ? 0xFFFFu : g; }
+__device__ __forceinline__ u32 nibbles_of(u64 cnt) {  // byte g -> nibble g, saturating at 15
+  const u64 hi = (cnt >> 4) & 0x0F0F0F0F0F0F0F0Full;
+  const u64 nz = ((hi + 0x0F0F0F0F0F0F0F0Full) >> 4) & 0x0101010101010101ull;  // 1 where the byte is >= 16
+  u64 x = (cnt & 0x0F0F0F0F0F0F0F0Full) | (nz * 15ull);
+  x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+  x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+  x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+  return (u32)x;
+}
 
 template <int NPL>
-__global__ __launch_bounds__(kBlock) void k_select(const KParams P) {
+__global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParams* __restrict__ Pg) {
+  // P: by-value copy in the kernarg segment (global pointers, scalar loads) for the inlined hot paths;
+  // PG: the same block in HBM, handed by reference to the out-of-line cold routines.
+  const KParams& PG = *Pg;
   const u32 part = blockIdx.x;
-  const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+  const u32 tid = threadIdx.x, lane = tid & 63u;
+  const u32 wave = uni32(tid >> 6);  // wave-uniform: the role split below is a scalar branch
   const u32 qbeg = P.part_off[part];
   const u32 nn = P.part_off[part + 1] - qbeg;
   const u64 jbeg = P.pj_off[part], jend = P.pj_off[part + 1];
@@ -454,174 +1046,177 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P) {
 
   __shared__ u64 s_wc[2][kWaves];
   __shared__ u32 s_wp[2][kWaves];
+  __shared__ u64 s_tc[kWaves];
+  __shared__ u32 s_tp[kWaves];
   __shared__ int s_flag;
   __shared__ int s_nupd;
   __shared__ UpdRec s_upd[kMaxUpd];
   __shared__ HeapEnt s_heap[kLdsHeap];
+  __shared__ JobCtx s_job;
+  __shared__ int s_ty_cpu[CNS_MAX_NODE_TYPES_DEV];  // per node type: what "completely free" looks like
+  __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
+  __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
 
   const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();  // lane t holds node type t
+  TypeLane tyl;
+  tyl.cpu = ttot.cpu; tyl.mem = ttot.mem; tyl.ncores = (u32)(popc64(ttot.clo) + popc64(ttot.chi));
+  tyl.cnt = class_counts(ttot.gres, P.gres);
   int par = 0;
 
   if (wave == 0) {
     // =============================================================================================
     // WORKER
     // =============================================================================================
-    if (lane == 0) { s_wc[0][0] = ~0ull; s_wc[1][0] = ~0ull; s_wp[0][0] = kNone; s_wp[1][0] = kNone; }
+    if (lane == 0) {
+      s_wc[0][0] = ~0ull; s_wc[1][0] = ~0ull; s_wp[0][0] = kNone; s_wp[1][0] = kNone;
+      s_tc[0] = ~0ull; s_tp[0] = kNone;
+    }
+    s_ty_cpu[lane] = clamp_cpu(ttot.cpu);
+    s_ty_m16[lane] = mem_gib16(mem_mib_ceil(ttot.mem));
+    s_ty_gn[lane] = nibbles_of(tyl.cnt);
+    __syncthreads();  // type tables visible to the scanners
+    WorkerShared sh;
+    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap;
     HeapEnt* const gheap = P.heap + qbeg + part;
+    u32 raw = fetch_job(P, jbeg);
     for (u64 ji = jbeg; ji < jend; ++ji) {
-      const JobCtx J = load_job(P, ji);
-      const bool excl_job = (J.flags & kJfExclusive) != 0;
-      const bool impossible = job_impossible(J);
-      const u32 orig = P.j_orig[ji];
-      const int tt_lane = type_capacity(P, J, ttot, lane);
-      HeapEnt* const H = (J.k < (u32)kLdsHeap) ? s_heap : gheap;
+      PROF_T(p0);
+      const JobCtx J = make_job(P, ji, raw);
+      if (ji + 1 < jend) raw = fetch_job(P, ji + 1);  // next job's record: in flight during this job
+      const bool simple = !(J.flags & kJfExclusive) && !J.general;  // ntasks == node_num on shared nodes
+      const bool fast = simple && J.k == 1;
+      const u32 orig = J.orig;
 
-      // ---- Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) -------------
-      bool success = false;
-      int hsize = 0, hsum = 0;  // topk_nodes_avail.size(), topk_ntasks_sum_avail
-      while (!impossible) {
-        __syncthreads();  // B1: scanners published their per-wave argmin
-        u64 wc = s_wc[par][lane & (kWaves - 1)];
-        u32 wcode = s_wp[par][lane & (kWaves - 1)];
-        reduce16(wc, wcode);
-        par ^= 1;
-        if (wcode == kNone) break;  // no node can start this job now
-        const u32 wp = slot_of_code(wcode);
-        const u32 n = P.slot_node[qbeg + wp];
-        int code = 0;
-        bool ok = false;
-        Res m = res_zero();
-        int ta = 0;
-        if (!excl_job) {
-          const Res a0 = P.avail0[n];
-          Res f;
-          if (feasible(J.min_view, a0, f, P.gres)) {             // :6274
-            m = window_min(P, n, a0, J.E, lane);                 // :6278-6283
-            if (J.general) ta = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, m, P.gres);  // :6285
-            else ta = feasible(J.min_view, m, f, P.gres) ? (int)J.tmin : 0;
-            ok = ta > 0;
-          }
+      __syncthreads();  // B1 (round 0): A and T argmins published
+      PROF_T(p1);
+      PROF_ADD(0, p0, p1);  // worker: decode + wait for the scanners
+      u64 wc = s_wc[par][lane & (kWaves - 1)];
+      u32 wcode = s_wp[par][lane & (kWaves - 1)];
+      u64 tc = s_tc[lane & (kWaves - 1)];
+      u32 tcode = s_tp[lane & (kWaves - 1)];
+      reduce16(wc, wcode);
+      reduce16(tc, tcode);
+      par ^= 1;
+      wc = uni64(wc); wcode = uni32(wcode); tc = uni64(tc); tcode = uni32(tcode);
+
+      if (!fast) {
+        if (lane == 0) s_job = J;
+        __threadfence_block();
+        if (simple && J.k <= (u32)kMaxUpd) {
+          par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
+          PROF_T(p8);
+          PROF_ADD(6, p1, p8);
+          PROF_CNT(15);
         } else {
-          m = P.total[n];
-          ok = window_all_total(P, n, m, J.E, lane);            // :6250-6260
-          ta = __shfl(tt_lane, (int)P.ntype[n]);
+          const int tt_lane = type_capacity(P, Pg, J, ttot, tyl, lane);
+          par = worker_job_slow(PG, sh, &s_job, par, wc, wcode, tc, tcode, tt_lane, qbeg, gheap);
+          PROF_T(p9);
+          PROF_ADD(5, p1, p9);
+          PROF_CNT(13);
         }
+        continue;
+      }
+
+      // ---- fast path, Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) ------
+      bool success = false;
+      while (wcode != kNone) {
+        PROF_T(a0);
+        const u32 q = qbeg + slot_of_code(wcode);
+        int code = 0;
+        // one coalesced read: header (broadcast) + entry `lane` of the time map
+        NodeHdr* hd; NodeHdr h; TlEntry e;
+        load_block(P, q, lane, hd, h, e);
+        const u32 len = h.len;
+        PROF_T(a1);
+        PROF_ADD(1, a0, a1);  // node block load
+        Res f, m;
+        bool ok = false;
+        if (feasible(J.min_view, h.avail0, f, P.gres)) {       // :6274
+          m = uni_res(len <= 64 ? window_min_regs(e, lane < len, h.avail0, J.E)
+                                : window_min(tl_of(hd), len, h.avail0, J.E, lane));  // :6278-6283
+          ok = feasible(J.min_view, m, f, P.gres);              // get_max_tasks(min_res) > 0, :6285
+        }
+        PROF_T(a2);
+        PROF_ADD(2, a1, a2);  // window-min + feasibility
         if (ok) {
-          HeapEnt e;
-          e.ntasks = ta; e.p = wcode; e.node = n; e.pad = 0;
-          e.cost = __longlong_as_double((long long)wc);
-          e.res = m;
-          bool done;
-          if (!J.general) {
-            if (lane == 0) H[hsize] = e;
-            ++hsize;
-            done = hsize == (int)J.k;   // k nodes with >= 1 task each and ntasks == k: break (:6294-6297)
+          Res alloc = f;                                        // tpn_min == 1: min view == 1-task view
+          if (J.tmin != 1 && !feasible(compose(J.node_view, J.tcpu, J.tmem, 1), m, alloc, P.gres)) {
+            if (lane == 0) set_fault(P, 2, orig, h.node, 0);
+          }
+          const double cst = __longlong_as_double((long long)wc);
+          if (len <= 64) {
+            commit_single_regs(P, J, hd, h, e, q, wcode, cst, alloc, P.now, 0, lane, s_upd, &s_nupd);
           } else {
-            int nsum = hsum + ta, nsize = hsize + 1;
             if (lane == 0) {
-              H[hsize] = e;
-              pq_push(H, nsize);                                                // :6288-6289
-              if (nsize > (int)J.k) { nsum -= H[0].ntasks; pq_pop(H, nsize); }  // :6290-6293
+              HeapEnt x; x.ntasks = 1; x.p = wcode; x.node = h.node; x.pad = 0; x.cost = cst; x.res = alloc;
+              s_heap[0] = x;
+              s_job = J;
             }
-            nsum = __shfl(nsum, 0);
-            if (nsize > (int)J.k) --nsize;
-            hsum = nsum; hsize = nsize;
-            done = hsize == (int)J.k && (u32)hsum >= J.ntasks;
-          }
-          __threadfence_block();
-          code = 1;
-          if (done) {
-            if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 2, orig, n, 0); }
-            commit_selection(P, J, H, qbeg, P.now, lane, s_upd, &s_nupd);   // start_time = now (:6326)
+            __threadfence_block();
+            commit_selection(PG, s_job, s_heap, qbeg, P.now, lane, s_upd, &s_nupd);
             if (lane == 0) { P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
-            code = 2;
           }
+          code = 2;
         }
+        PROF_T(a3);
+        PROF_ADD(3, a2, a3);  // commit
         if (lane == 0) s_flag = code;
         __syncthreads();  // B2: verdict (and, on success, the owner updates) visible to the scanners
         if (code == 2) { success = true; break; }
-      }
-      if (success) continue;
-
-      // ---- Phase B: top-k nodes by total capacity, then backfill -----------------------------------
-      // (JobScheduler.cpp:6233-6242, :6335-6368, Backfill_ :6371-6376)
-      int nsel = 0, tsum = 0;
-      bool complete = false;
-      while (!impossible) {
-        __syncthreads();  // B1
-        u64 wc = s_wc[par][lane & (kWaves - 1)];
-        u32 wcode = s_wp[par][lane & (kWaves - 1)];
+        PROF_CNT(14);         // rejected candidate
+        __syncthreads();  // B1 of the next round
+        wc = s_wc[par][lane & (kWaves - 1)];
+        wcode = s_wp[par][lane & (kWaves - 1)];
         reduce16(wc, wcode);
         par ^= 1;
-        if (wcode == kNone) break;
-        const u32 n = P.slot_node[qbeg + slot_of_code(wcode)];
-        HeapEnt e;
-        e.p = wcode; e.node = n; e.pad = 0;
-        e.cost = __longlong_as_double((long long)wc);
-        e.res = res_zero();
-        if (!J.general) {
-          e.ntasks = 1;
-          if (lane == 0) H[nsel] = e;
-          ++nsel;
-          if (nsel == (int)J.k) { complete = true; break; }
-        } else {
-          const int tt = __shfl(tt_lane, (int)P.ntype[n]);
-          e.ntasks = tt;
-          int nsum = tsum + tt, nsize = nsel + 1;  // the push condition (:6233-6234) held, else we had stopped
-          if (lane == 0) {
-            H[nsel] = e;
-            pq_push(H, nsize);
-            if (nsize > (int)J.k) { nsum -= H[0].ntasks; pq_pop(H, nsize); }
-          }
-          nsum = __shfl(nsum, 0);
-          if (nsize > (int)J.k) --nsize;
-          tsum = nsum; nsel = nsize;
-          const bool stop = nsel == (int)J.k && (u32)tsum >= J.ntasks;
-          if (lane == 0) s_flag = stop ? 1 : 0;
-          __syncthreads();  // B2 (general path only)
-          if (stop) { complete = true; break; }
-        }
+        wc = uni64(wc); wcode = uni32(wcode);
       }
+      if (success) { PROF_CNT(11); continue; }
+
+      // ---- fast path, Phase B: the first node in cost order whose res_total fits (the T argmin of
+      // round 0), earliest start on its time map (JobScheduler.cpp:6335-6368, Backfill_ :6371-6376) ----
+      PROF_T(b0);
       int code = 0;
-      if (complete) {
-        __threadfence_block();
-        for (u32 i = lane; i < J.k; i += 64) { HeapEnt e = H[i]; e.res = P.total[e.node]; H[i] = e; P.bf_j[qbeg + i] = 0; }
-        __threadfence_block();
-        if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 3, orig, 0, 0); }
-        // EarliestStartSubsetSelector::CalcEarliestStartTime as a fixed point over the k nodes
-        i64 t = P.now;
-        bool found = false;
-        for (u32 iter = 0; iter < (1u << 22); ++iter) {
-          i64 T = t;
-          for (u32 i = lane; i < J.k; i += 64) {
-            const HeapEnt e = H[i];
-            u32 j = P.bf_j[qbeg + i];
-            i64 s = next_fit(P.tl + (u64)e.node * P.tl_cap, P.tl_len[e.node], e.res, J.L, t, j);
-            P.bf_j[qbeg + i] = j;
-            T = s > T ? s : T;
-          }
-          T = wave_max_i64(T);
-          if (T == kInf || T - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
-          if (T == t) { found = true; break; }
-          t = T;
+      if (tcode != kNone) {
+        const u32 q = qbeg + slot_of_code(tcode);
+        NodeHdr* hd; NodeHdr h; TlEntry e;
+        load_block(P, q, lane, hd, h, e);
+        const u32 len = h.len;
+        Res alloc = res_zero();
+        if (!feasible(compose(J.node_view, J.tcpu, J.tmem, 1), h.total, alloc, P.gres)) {  // :6354-6356
+          if (lane == 0) set_fault(P, 3, orig, h.node, 0);
         }
-        if (found) {
+        i64 s;
+        if (len <= 64) {
+          s = next_fit_regs(e, len, alloc, J.L, P.now, lane);
+        } else {
+          u32 j = 0;
+          s = next_fit(tl_of(hd), len, alloc, J.L, P.now, j);
+        }
+        if (s != kInf && s - P.now <= P.max_window) {          // kAlgoMaxTimeWindow, JobScheduler.h:815
           int reason = 0;
-          if (t != P.now) {  // JobScheduler.cpp:6797-6833 (no reservations in this slice)
-            bool notle = false;
-            for (u32 i = lane; i < J.k; i += 64) {
-              const HeapEnt e = H[i];
-              if (!res_le(e.res, P.avail0[e.node])) notle = true;
+          if (s != P.now) reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;  // :6810-6831
+          const double cst = __longlong_as_double((long long)tc);
+          if (len <= 64) {
+            commit_single_regs(P, J, hd, h, e, q, tcode, cst, alloc, s, reason, lane, s_upd, &s_nupd);
+          } else {
+            if (lane == 0) {
+              HeapEnt x; x.ntasks = 1; x.p = tcode; x.node = h.node; x.pad = 0; x.cost = cst; x.res = alloc;
+              s_heap[0] = x;
+              s_job = J;
             }
-            reason = __any(notle) ? 2 /*Resource*/ : 1 /*Priority*/;
+            __threadfence_block();
+            commit_selection(PG, s_job, s_heap, qbeg, s, lane, s_upd, &s_nupd);
+            if (lane == 0) { P.o_start[orig] = s; P.o_reason[orig] = (uint8_t)reason; }
           }
-          commit_selection(P, J, H, qbeg, t, lane, s_upd, &s_nupd);
-          if (lane == 0) { P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
           code = 2;
         }
       }
       if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
       if (lane == 0) s_flag = code;
+      PROF_T(b1);
+      PROF_ADD(4, b0, b1);  // backfill + commit
+      PROF_CNT(12);
       __syncthreads();  // B3
     }
   } else {
@@ -631,169 +1226,243 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P) {
     const u32 t = tid - 64u;
     double cost[NPL];
     int fcpu[NPL];
-    u32 fmem[NPL];
-    u64 fcnt[NPL];
-    u32 meta[NPL];  // bit31 valid | len << 8 | type
+    u32 mw[NPL];   // fmem GiB (16) | len (10) << 16 | type (6) << 26 ; len = 1023 marks "no node"
+    u32 gn[NPL];   // per-class free-slot count, 4 bits each
 #pragma unroll
     for (int r = 0; r < NPL; ++r) {
       const u32 p = (u32)r * kScan + t;
       if (p < nn) {
         const u32 q = qbeg + p;
-        const u32 n = P.slot_node[q];
+        const NodeHdr* hd = hdr_of(P, q);
         cost[r] = P.cost[q];
         fcpu[r] = P.f_cpu[q];
-        fmem[r] = P.f_mem[q];
-        fcnt[r] = P.f_cnt[q];
-        meta[r] = 0x80000000u | (P.tl_len[n] << 8) | (u32)P.ntype[n];
+        mw[r] = mem_gib16(P.f_mem[q]) | (hd->len << 16) | (hd->type << 26);
+        gn[r] = nibbles_of(P.f_cnt[q]);
       } else {
-        cost[r] = 0.0; fcpu[r] = 0; fmem[r] = 0; fcnt[r] = 0; meta[r] = 0;
+        cost[r] = 0.0; fcpu[r] = 0; mw[r] = 1023u << 16; gn[r] = 0;
       }
     }
-    const int ttot_cpu32 = clamp_cpu(ttot.cpu);
-    const u32 ttot_mem32 = mem_mib_ceil(ttot.mem);
-    const u64 ttot_cnt = class_counts(ttot.gres, P.gres);
-    const u64 H8 = 0x8080808080808080ull;
+    // name masks in the split-nibble domain (even nibbles / odd nibbles as bytes)
+    u32 nme[kMaxNames], nmo[kMaxNames];
+#pragma unroll
+    for (int a = 0; a < kMaxNames; ++a) {
+      const u32 nb = nibbles_of(P.gres.name_bytes[a] & 0x0F0F0F0F0F0F0F0Full);  // nibble g = 0xF if class g is in name a
+      nme[a] = nb & 0x0F0F0F0Fu;
+      nmo[a] = (nb >> 4) & 0x0F0F0F0Fu;
+    }
+    __syncthreads();  // type tables written by the worker
+
+    u32 raw = fetch_job(P, jbeg);
+    JobCtx J = make_job(P, jbeg, raw);
+    u64 typeok = type_ok_mask(P, J, tyl, lane);
+    if (jbeg + 1 < jend) raw = fetch_job(P, jbeg + 1);
+
+    // argmin of (cost, code) over the lane's nodes whose bit is set in `mask`; ties keep the lower r
+    auto lane_argmin = [&](u32 mask, u64& bc, u32& bp) {
+      bc = ~0ull;
+      u32 br = 0xFFu;
+#pragma unroll
+      for (int r = 0; r < NPL; ++r) {
+        const u64 ck = cost_key(cost[r]);
+        const bool take = ((mask >> r) & 1u) & (ck < bc);
+        bc = take ? ck : bc;
+        br = take ? (u32)r : br;
+      }
+      bp = br == 0xFFu ? kNone : ((br << 10) | t);
+    };
 
     for (u64 ji = jbeg; ji < jend; ++ji) {
-      const JobCtx J = load_job(P, ji);
+      PROF_T(s0);
       const bool excl_job = (J.flags & kJfExclusive) != 0;
-      const bool has_lists = (J.flags & (kJfIncl | kJfExcl)) != 0;
       const bool has_gres = (J.flags & kJfGres) != 0;
-      const bool impossible = job_impossible(J);
-      const u64 typeok = __ballot(type_capacity(P, J, ttot, lane) > 0);
-      const int req_cpu32 = J.min_view.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)J.min_view.cpu;
-      const u32 req_mem32 = (J.min_view.mem >> 20) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)(J.min_view.mem >> 20);
+      const bool possible = !job_impossible(J);
+      const int rc32 = J.min_view.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)J.min_view.cpu;
+      const u32 rm16 = (J.min_view.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(J.min_view.mem >> 30);
+      const u32 rq = nibbles_of(J.node_view.gspec);  // specified counts, saturating at 15 like the node side
+      const u32 rqe = rq & 0x0F0F0F0Fu, rqo = (rq >> 4) & 0x0F0F0F0Fu;
+      const u32 gtot = J.node_view.gtot;
+      const u32 kk = J.k;
+      const bool general = J.general;
+      const u32 maxlen = P.max_jobs_per_node;
+      const u32 G8 = 0x80808080u;
 
-      u32 used = 0;
-      int verdict = 0;
-      // ---- Phase A ----------------------------------------------------------------------------------
-      while (!impossible) {
-        u64 bc = ~0ull;
-        u32 bp = kNone;
+      // Nothing the filters look at changes during a job (commits happen at its end), so both candidate
+      // sets are computed ONCE per job as per-lane bitmasks, together with the round-0 argmins; later
+      // rounds only mask out the nodes already visited.
+      //   bmask: node may host the job at all  (len < 1000 :6194, res_total fits :6222, lists :6202-6220)
+      //   amask: ... and may start it now      (front filter: necessary for :6274-6285 / :6251-6257)
+      u32 bmask = 0, amask = 0;
+      u64 ac = ~0ull, tcs = ~0ull;
+      u32 ar = 0xFFu, tr = 0xFFu;
+#pragma unroll
+      for (int r = 0; r < NPL; ++r) {
+        const u32 w = mw[r];
+        const bool b = possible & (((typeok >> (w >> 26)) & 1ull) != 0) & (((w >> 16) & 0x3FFu) < maxlen);
+        bool a = b & (rc32 <= fcpu[r]) & (rm16 <= (w & 0xFFFFu));  // the entry at `now` is in every window
+        if (has_gres) {
+          u32 gr = gn[r];
+          asm volatile("" : "+v"(gr));  // pins the GRES arithmetic inside this (job-uniform) branch
+          const u32 ce = gr & 0x0F0F0F0Fu, co = (gr >> 4) & 0x0F0F0F0Fu;
+          a = a & ((((ce | G8) - rqe) & G8) == G8) & ((((co | G8) - rqo) & G8) == G8);
+#pragma unroll
+          for (int g = 0; g < kMaxNames; ++g) {
+            const u32 tot = (gtot >> (8 * g)) & 0xFFu;
+            const u32 have = __builtin_amdgcn_sad_u8(ce & nme[g], 0u, __builtin_amdgcn_sad_u8(co & nmo[g], 0u, 0u));
+            a = a & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
+          }
+        }
+        const u64 ck = cost_key(cost[r]);
+        const bool ta = a & (ck < ac);
+        ac = ta ? ck : ac;
+        ar = ta ? (u32)r : ar;
+        const bool tt = b & (ck < tcs);
+        tcs = tt ? ck : tcs;
+        tr = tt ? (u32)r : tr;
+        bmask |= (b ? 1u : 0u) << r;
+        amask |= (a ? 1u : 0u) << r;
+      }
+      u32 ap = ar == 0xFFu ? kNone : ((ar << 10) | t);
+      u32 tp = tr == 0xFFu ? kNone : ((tr << 10) | t);
+      if (excl_job) {  // exclusive: the node must be completely free now (necessary for :6251-6257)
+        amask = 0;
 #pragma unroll
         for (int r = 0; r < NPL; ++r) {
-          const u32 m = meta[r];
-          const u32 ty = m & 0xFFu;
-          bool c = (m >> 31) && !((used >> r) & 1u) && ((typeok >> ty) & 1ull) &&
-                   (((m >> 8) & 0xFFFFu) < P.max_jobs_per_node);  // :6194
-          if (!excl_job) {
-            // necessary for :6274-6285: the entry at `now` lies inside every window
-            c = c && req_cpu32 <= fcpu[r] && req_mem32 <= fmem[r];
-            if (has_gres) {
-              const u64 cn = fcnt[r];
-              c = c && ((((cn | H8) - J.node_view.gspec) & H8) == H8);
-#pragma unroll
-              for (int a = 0; a < kMaxNames; ++a) {
-                const u32 tot = (J.node_view.gtot >> (8 * a)) & 0xFFu;
-                if (tot) c = c && sum_bytes(cn & P.gres.name_bytes[a]) >= tot;
-              }
-            }
-          } else {  // exclusive: the node must be completely free now (necessary for :6251-6257)
-            const int tc = __shfl(ttot_cpu32, (int)ty);
-            const u32 tm = __shfl(ttot_mem32, (int)ty);
-            const u64 tn = __shfl(ttot_cnt, (int)ty);
-            c = c && fcpu[r] >= tc && fmem[r] >= tm && fcnt[r] == tn;
-          }
-          if (c && has_lists) {
-            const u32 n = P.slot_node[qbeg + (u32)r * kScan + t];
-            if ((J.flags & kJfIncl) && !in_list(P.incl_nodes, J.incl_b, J.incl_e, n)) c = false;
-            if ((J.flags & kJfExcl) && in_list(P.excl_nodes, J.excl_b, J.excl_e, n)) c = false;
-          }
-          const u64 ck = cost_key(cost[r]);
-          const u32 code = ((u32)r << 10) | t;
-          if (c && (ck < bc || (ck == bc && code < bp))) { bc = ck; bp = code; }
+          const u32 w = mw[r];
+          const u32 ty = w >> 26;
+          const bool a = ((bmask >> r) & 1u) & (fcpu[r] >= s_ty_cpu[ty]) & ((w & 0xFFFFu) >= s_ty_m16[ty]) &
+                         (gn[r] == s_ty_gn[ty]);
+          amask |= (a ? 1u : 0u) << r;
         }
-        wave_argmin(bc, bp);
-        if (lane == 0) { s_wc[par][wave] = bc; s_wp[par][wave] = bp; }
-        __syncthreads();  // B1
-        u64 wc = s_wc[par][lane & (kWaves - 1)];
-        u32 wcode = s_wp[par][lane & (kWaves - 1)];
-        reduce16(wc, wcode);
-        par ^= 1;
-        if (wcode == kNone) break;
+        lane_argmin(amask, ac, ap);
+      }
+      if (J.flags & (kJfIncl | kJfExcl)) {  // included / excluded node lists (rare)
+        u32 lm = 0;
+#pragma unroll 1
+        for (int r = 0; r < NPL; ++r) {
+          if (!((bmask >> r) & 1u)) continue;
+          const u32 n = P.slot_node[qbeg + (u32)r * kScan + t];
+          bool okl = true;
+          if ((J.flags & kJfIncl) && !in_list(P.incl_nodes, J.incl_b, J.incl_e, n)) okl = false;
+          if ((J.flags & kJfExcl) && in_list(P.excl_nodes, J.excl_b, J.excl_e, n)) okl = false;
+          lm |= (okl ? 1u : 0u) << r;
+        }
+        bmask &= lm;
+        amask &= lm;
+        lane_argmin(amask, ac, ap);
+        lane_argmin(bmask, tcs, tp);
+      }
+
+      // ---- round 0: publish both argmins ---------------------------------------------------------------
+      wave_argmin(ac, ap);
+      wave_argmin(tcs, tp);
+      if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; s_tc[wave] = tcs; s_tp[wave] = tp; }
+      PROF_T(s1);
+      PROF_ADDS(16, s0, s1);  // scanner: masks + argmins
+      __syncthreads();  // B1
+      u64 wc = s_wc[par][lane & (kWaves - 1)];
+      u32 wcode = s_wp[par][lane & (kWaves - 1)];
+      u64 tc = s_tc[lane & (kWaves - 1)];
+      u32 tcode = s_tp[lane & (kWaves - 1)];
+      reduce16(wc, wcode);
+      reduce16(tc, tcode);
+      par ^= 1;
+      PROF_T(s2);
+      PROF_ADDS(17, s1, s2);  // scanner: B1 wait + cross-wave reduce
+
+      // while the worker examines the winner: prepare the next job (its record was fetched a job ago)
+      JobCtx Jn = J;
+      u64 typeok_n = typeok;
+      if (ji + 1 < jend) {
+        Jn = make_job(P, ji + 1, raw);
+        typeok_n = type_ok_mask(P, Jn, tyl, lane);
+        if (ji + 2 < jend) raw = fetch_job(P, ji + 2);
+      }
+      PROF_T(s3);
+      PROF_ADDS(18, s2, s3);  // scanner: next-job prep (hidden behind the worker)
+
+      int verdict = 0;
+      u32 used = 0;
+      // ---- Phase A ----------------------------------------------------------------------------------
+      while (wcode != kNone) {
         if ((wcode & 1023u) == t) used |= 1u << (wcode >> 10);
         __syncthreads();  // B2
         verdict = s_flag;
         if (verdict == 2) break;
+        lane_argmin(amask & ~used, ac, ap);
+        wave_argmin(ac, ap);
+        if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; }
+        __syncthreads();  // B1
+        wc = s_wc[par][lane & (kWaves - 1)];
+        wcode = s_wp[par][lane & (kWaves - 1)];
+        reduce16(wc, wcode);
+        par ^= 1;
       }
       // ---- Phase B ----------------------------------------------------------------------------------
       if (verdict != 2) {
-        used = 0;
-        int nsel = 0;
-        while (!impossible) {
-          u64 bc = ~0ull;
-          u32 bp = kNone;
-#pragma unroll
-          for (int r = 0; r < NPL; ++r) {
-            const u32 m = meta[r];
-            bool c = (m >> 31) && !((used >> r) & 1u) && ((typeok >> (m & 0xFFu)) & 1ull) &&
-                     (((m >> 8) & 0xFFFFu) < P.max_jobs_per_node);
-            if (c && has_lists) {
-              const u32 n = P.slot_node[qbeg + (u32)r * kScan + t];
-              if ((J.flags & kJfIncl) && !in_list(P.incl_nodes, J.incl_b, J.incl_e, n)) c = false;
-              if ((J.flags & kJfExcl) && in_list(P.excl_nodes, J.excl_b, J.excl_e, n)) c = false;
+        if (!(!excl_job && !general && kk == 1)) {  // the single-node case needs no further scan
+          used = 0;
+          u32 nsel = 0;
+          u32 ccode = tcode;
+          while (ccode != kNone) {
+            if ((ccode & 1023u) == t) used |= 1u << (ccode >> 10);
+            if (!general) {
+              if (++nsel == kk) break;
+            } else {
+              __syncthreads();  // B2 (ntasks > node_num only)
+              if (s_flag == 1) break;
             }
-            const u64 ck = cost_key(cost[r]);
-            const u32 code = ((u32)r << 10) | t;
-            if (c && (ck < bc || (ck == bc && code < bp))) { bc = ck; bp = code; }
-          }
-          wave_argmin(bc, bp);
-          if (lane == 0) { s_wc[par][wave] = bc; s_wp[par][wave] = bp; }
-          __syncthreads();  // B1
-          u64 wc = s_wc[par][lane & (kWaves - 1)];
-          u32 wcode = s_wp[par][lane & (kWaves - 1)];
-          reduce16(wc, wcode);
-          par ^= 1;
-          if (wcode == kNone) break;
-          if ((wcode & 1023u) == t) used |= 1u << (wcode >> 10);
-          if (!J.general) {
-            if (++nsel == (int)J.k) break;
-          } else {
-            __syncthreads();  // B2 (general path only)
-            if (s_flag == 1) break;
+            lane_argmin(bmask & ~used, tcs, tp);
+            wave_argmin(tcs, tp);
+            if (lane == 0) { s_wc[par][wave] = tcs; s_wp[par][wave] = tp; }
+            __syncthreads();  // B1
+            u64 cc = s_wc[par][lane & (kWaves - 1)];
+            ccode = s_wp[par][lane & (kWaves - 1)];
+            reduce16(cc, ccode);
+            par ^= 1;
           }
         }
         __syncthreads();  // B3: worker finished backfill + commit (or gave up)
         verdict = s_flag;
       }
+      PROF_T(s4);
+      PROF_ADDS(19, s3, s4);  // scanner: waiting for the worker's verdict
       // ---- owners refresh their registers ---------------------------------------------------------------
       if (verdict == 2) {
         const int nu = s_nupd;
-        if (nu >= 0) {
-          for (int i = 0; i < nu; ++i) {
-            const UpdRec u = s_upd[i];
-            if ((u.p & 1023u) == t) {
-              const int rr = (int)(u.p >> 10);
+        const UpdRec* const ub = nu <= kMaxUpd ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
+        for (int i = 0; i < nu; ++i) {
+          const u32 up = ub[i].p;
+          if ((up & 1023u) == t) {
+            const UpdRec u = ub[i];
+            const int rr = (int)(up >> 10);
 #pragma unroll
-              for (int r = 0; r < NPL; ++r)
-                if (r == rr) {
-                  cost[r] = u.cost;
-                  meta[r] = (meta[r] & 0x800000FFu) | (u.len << 8);
-                  if (u.has_front) { fcpu[r] = u.fcpu; fmem[r] = u.fmem; fcnt[r] = u.fcnt; }
+            for (int r = 0; r < NPL; ++r)
+              if (r == rr) {
+                cost[r] = u.cost;
+                u32 w = (mw[r] & ~(0x3FFu << 16)) | (u.len << 16);
+                if (u.has_front) {
+                  fcpu[r] = u.fcpu;
+                  w = (w & ~0xFFFFu) | mem_gib16(u.fmem);
+                  gn[r] = nibbles_of(u.fcnt);
                 }
-            }
-          }
-        } else {  // more nodes than the LDS broadcast holds: reload the tile from HBM
-#pragma unroll
-          for (int r = 0; r < NPL; ++r) {
-            const u32 p = (u32)r * kScan + t;
-            if (p < nn) {
-              const u32 q = qbeg + p;
-              cost[r] = P.cost[q]; fcpu[r] = P.f_cpu[q]; fmem[r] = P.f_mem[q]; fcnt[r] = P.f_cnt[q];
-              meta[r] = (meta[r] & 0x800000FFu) | (P.tl_len[P.slot_node[q]] << 8);
-            }
+                mw[r] = w;
+              }
           }
         }
       }
+      J = Jn;
+      typeok = typeok_n;
+      PROF_T(s5);
+      PROF_ADDS(20, s4, s5);  // scanner: owner update
     }
   }
 }
 
-template __global__ void k_select<1>(const KParams);
-template __global__ void k_select<2>(const KParams);
-template __global__ void k_select<3>(const KParams);
-template __global__ void k_select<5>(const KParams);
-template __global__ void k_select<9>(const KParams);
-template __global__ void k_select<18>(const KParams);
+template __global__ void k_select<1>(const KParams, const KParams*);
+template __global__ void k_select<2>(const KParams, const KParams*);
+template __global__ void k_select<3>(const KParams, const KParams*);
+template __global__ void k_select<5>(const KParams, const KParams*);
+template __global__ void k_select<9>(const KParams, const KParams*);
+template __global__ void k_select<18>(const KParams, const KParams*);
 
 }  // namespace cns

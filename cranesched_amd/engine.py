@@ -20,13 +20,14 @@ import torch  # noqa: F401  (must precede the CDLL below)
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrane_gpu_nodeselect.so")
+LIB_PATH = os.environ.get("CNS_ENGINE_LIB") or os.path.join(_HERE, "libcrane_gpu_nodeselect.so")
 _LIB = None
 
 # every symbol include/crane_gpu/node_select.h declares
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
                "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
-               "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline")
+               "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline",
+               "cns_debug_get_prof")
 
 
 class EngineError(RuntimeError):
@@ -138,6 +139,13 @@ class GpuNodeSelector:
         c = np.zeros(len(self._cluster.part_nodes), np.float64)
         self._check(self._L.cns_debug_get_costs(self._h, c.ctypes.data_as(C.c_void_p)))
         return c
+
+    def prof(self) -> np.ndarray:
+        """[P, 32] cycle counters of the last run (zeros unless built with -DCNS_PROF)."""
+        P = self._cluster.num_partitions
+        out = np.zeros(P * 32, np.uint64)
+        self._check(self._L.cns_debug_get_prof(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(P * 32)))
+        return out.reshape(P, 32)
 
     def timeline(self, node: int, cap: int = 1100):
         n = C.c_uint32(0)
