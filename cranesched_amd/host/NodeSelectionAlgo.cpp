@@ -1,0 +1,282 @@
+// GpuNodeSelectionAlgo: packs CraneCtld-shaped job / node objects into the SoA tables of the C ABI
+// (include/crane_gpu/node_select.h), calls the engine and writes the placements back into
+// PdJobInScheduler exactly where the reference's NodeSelect leaves them
+// (src/CraneCtld/JobScheduler.cpp:6322-6331, :6772, :6768-6831; consumed at :1492-1600).
+#include "NodeSelectionAlgo.h"
+
+#include <algorithm>
+#include <cstring>
+
+#include "../../include/crane_gpu/node_select.h"
+
+namespace crane {
+
+namespace {
+const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", ""};
+}
+
+struct GpuNodeSelectionAlgo::Impl {
+  cns_handle* h = nullptr;
+  // dense indices of the current snapshot
+  std::vector<CranedId> node_name;
+  std::unordered_map<CranedId, uint32_t> node_idx;
+  std::unordered_map<PartitionId, uint32_t> part_idx;
+  // (name, type) -> class; slot path -> bit, per class in lexicographic path order (std::set<SlotId> order)
+  std::vector<std::pair<std::string, std::string>> classes;
+  std::map<std::string, uint32_t> name_id;
+  std::vector<std::map<SlotId, uint32_t>> class_slot_bit;  // per class: slot path -> absolute bit
+  std::vector<std::vector<SlotId>> class_bit_slot;          // per class: bit offset -> slot path
+  cns_gres_layout layout{};
+  bool have_snapshot = false;
+
+  int class_of(const std::string& name, const std::string& type) const {
+    for (size_t c = 0; c < classes.size(); ++c)
+      if (classes[c].first == name && classes[c].second == type) return (int)c;
+    return -1;
+  }
+  uint64_t gres_mask(const DedicatedResourceInNode& d) const {
+    uint64_t m = 0;
+    for (const auto& [name, tm] : d)
+      for (const auto& [type, slots] : tm) {
+        int c = class_of(name, type);
+        if (c < 0) continue;
+        for (const auto& s : slots) {
+          auto it = class_slot_bit[c].find(s);
+          if (it != class_slot_bit[c].end()) m |= 1ull << it->second;
+        }
+      }
+    return m;
+  }
+  static void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi) {
+    lo = hi = 0;
+    for (uint32_t c : ids) {
+      if (c < 64) lo |= 1ull << c;
+      else if (c < 128) hi |= 1ull << (c - 64);
+    }
+  }
+  ResourceInNodeV3 to_res(int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g) const {
+    ResourceInNodeV3 r;
+    r.cpu_set.cpu_count = cpu_t::from_raw(cpu_raw);
+    for (int b = 0; b < 64; ++b) {
+      if ((lo >> b) & 1) r.cpu_set.core_ids.insert((uint32_t)b);
+      if ((hi >> b) & 1) r.cpu_set.core_ids.insert((uint32_t)(64 + b));
+    }
+    r.memory_bytes = mem;
+    r.memory_sw_bytes = mem;
+    for (size_t c = 0; c < classes.size(); ++c)
+      for (uint32_t i = 0; i < layout.class_width[c]; ++i)
+        if ((g >> (layout.class_shift[c] + i)) & 1)
+          r.gres[classes[c].first][classes[c].second].insert(class_bit_slot[c][i]);
+    return r;
+  }
+};
+
+GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(int device, uint64_t scheduled_batch_size) : impl_(new Impl) {
+  cns_config cfg{};
+  cfg.abi_version = CNS_ABI_VERSION;
+  cfg.device = device;
+  cfg.scheduled_batch_size = scheduled_batch_size;
+  status_ = cns_create(&cfg, &impl_->h);
+  if (status_ != 0) error_ = cns_last_error(nullptr);
+}
+
+GpuNodeSelectionAlgo::~GpuNodeSelectionAlgo() {
+  if (impl_ && impl_->h) cns_destroy(impl_->h);
+}
+
+void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
+  Impl& I = *impl_;
+  I.have_snapshot = false;
+  if (!I.h) return;
+  const uint32_t N = (uint32_t)snap.craned_metas.size();
+  I.node_name.clear(); I.node_idx.clear(); I.part_idx.clear();
+  I.classes.clear(); I.name_id.clear(); I.class_slot_bit.clear(); I.class_bit_slot.clear();
+  // GRES classes: every (name,type) seen in any res_total; bits per class = union of its slot paths
+  std::map<std::pair<std::string, std::string>, std::set<SlotId>> cls;
+  for (const auto& m : snap.craned_metas)
+    for (const auto& [name, tm] : m.res_total.gres)
+      for (const auto& [type, slots] : tm) cls[{name, type}].insert(slots.begin(), slots.end());
+  memset(&I.layout, 0, sizeof I.layout);
+  uint32_t shift = 0;
+  for (const auto& [key, slots] : cls) {
+    if (I.classes.size() >= CNS_MAX_GRES_CLASSES || shift + slots.size() > 64) {
+      status_ = CNS_ERR_UNSUPPORTED; error_ = "more GRES classes / slots than the 64-bit slot mask holds"; return;
+    }
+    if (!I.name_id.count(key.first)) {
+      if (I.name_id.size() >= CNS_MAX_GRES_NAMES) { status_ = CNS_ERR_UNSUPPORTED; error_ = "more than 4 GRES names"; return; }
+      uint32_t id = (uint32_t)I.name_id.size();
+      I.name_id[key.first] = id;
+    }
+    const uint32_t c = (uint32_t)I.classes.size();
+    I.classes.push_back(key);
+    I.layout.class_name[c] = (uint8_t)I.name_id[key.first];
+    I.layout.class_shift[c] = (uint8_t)shift;
+    I.layout.class_width[c] = (uint8_t)slots.size();
+    I.class_slot_bit.emplace_back();
+    I.class_bit_slot.emplace_back();
+    for (const auto& s : slots) {  // std::set order = lexicographic path order
+      I.class_slot_bit[c][s] = shift + (uint32_t)I.class_bit_slot[c].size();
+      I.class_bit_slot[c].push_back(s);
+    }
+    shift += (uint32_t)slots.size();
+  }
+  I.layout.num_classes = (uint32_t)I.classes.size();
+
+  std::vector<int64_t> cpu(N);
+  std::vector<uint64_t> mem(N), lo(N), hi(N), gres(N);
+  std::vector<uint8_t> sched(N);
+  for (uint32_t n = 0; n < N; ++n) {
+    const CranedMeta& m = snap.craned_metas[n];
+    I.node_name.push_back(m.craned_id);
+    I.node_idx[m.craned_id] = n;
+    cpu[n] = m.res_total.cpu_set.cpu_count.raw;
+    mem[n] = m.res_total.memory_bytes;
+    Impl::core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n]);
+    gres[n] = I.gres_mask(m.res_total.gres);
+    sched[n] = m.alive && !m.drain;  // JobScheduler.cpp:6595
+  }
+  std::vector<uint32_t> poff{0}, pnodes;
+  for (const auto& [pid, ids] : snap.partitions) {
+    I.part_idx[pid] = (uint32_t)poff.size() - 1;
+    for (const auto& id : ids) {
+      auto it = I.node_idx.find(id);
+      if (it != I.node_idx.end()) pnodes.push_back(it->second);
+    }
+    poff.push_back((uint32_t)pnodes.size());
+  }
+  cns_node_soa nd{};
+  nd.num_nodes = N;
+  nd.num_partitions = (uint32_t)snap.partitions.size();
+  nd.cpu_total_raw = cpu.data(); nd.mem_total = mem.data(); nd.core_lo = lo.data(); nd.core_hi = hi.data();
+  nd.gres_slots = gres.data(); nd.schedulable = sched.data();
+  nd.part_offsets = poff.data(); nd.part_nodes = pnodes.data();
+  nd.gres = I.layout;
+  status_ = cns_set_nodes(I.h, &nd);
+  if (status_ != 0) { error_ = cns_last_error(I.h); return; }
+  I.have_snapshot = true;
+}
+
+void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
+                                      const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
+                                      const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) {
+  Impl& I = *impl_;
+  auto fail_all = [&](int st, const std::string& msg) {
+    status_ = st; error_ = msg;
+    for (const auto& j : pending_jobs) if (j->reason.empty()) j->reason = "GpuEngineError";
+  };
+  if (!I.h) return fail_all(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
+  if (!I.have_snapshot) return fail_all(CNS_ERR_STATE, "NodeSelect before SetClusterSnapshot");
+
+  // ---- running jobs (JobScheduler.cpp:6681-6709); reservations are outside this slice ------------------
+  std::vector<int64_t> r_end;
+  std::vector<uint32_t> r_off{0}, r_node;
+  std::vector<int64_t> r_cpu;
+  std::vector<uint64_t> r_mem, r_lo, r_hi, r_g;
+  for (const auto& rn : running_jobs) {
+    if (!rn->reservation.empty()) continue;
+    r_end.push_back(rn->end_time);
+    for (const auto& [cid, res] : rn->allocated_res) {
+      auto it = I.node_idx.find(cid);
+      if (it == I.node_idx.end()) continue;
+      r_node.push_back(it->second);
+      r_cpu.push_back(res.cpu_set.cpu_count.raw);
+      r_mem.push_back(res.memory_bytes);
+      uint64_t lo, hi;
+      Impl::core_masks(res.cpu_set.core_ids, lo, hi);
+      r_lo.push_back(lo); r_hi.push_back(hi);
+      r_g.push_back(I.gres_mask(res.gres));
+    }
+    r_off.push_back((uint32_t)r_node.size());
+  }
+  cns_running_soa rs{};
+  rs.num_jobs = (uint32_t)r_end.size(); rs.num_allocs = (uint32_t)r_node.size();
+  rs.end_sec = r_end.data(); rs.alloc_offsets = r_off.data(); rs.alloc_node = r_node.data();
+  rs.alloc_cpu_raw = r_cpu.data(); rs.alloc_mem = r_mem.data(); rs.alloc_core_lo = r_lo.data();
+  rs.alloc_core_hi = r_hi.data(); rs.alloc_gres = r_g.data();
+  int st = cns_set_running(I.h, rs.num_jobs ? &rs : nullptr);
+  if (st != 0) return fail_all(st, cns_last_error(I.h));
+
+  // ---- pending jobs -------------------------------------------------------------------------------------
+  const size_t J = pending_jobs.size();
+  std::vector<uint32_t> part(J), k(J), nt(J), tmin(J), tmax(J);
+  std::vector<int64_t> L(J), ncpu(J), tcpu(J);
+  std::vector<uint64_t> nmem(J), tmem(J), ioff{0}, eoff{0};
+  std::vector<uint8_t> excl(J), skip(J), gtot(J * CNS_MAX_GRES_NAMES, 0), gspec(J * CNS_MAX_GRES_CLASSES, 0);
+  std::vector<uint32_t> inodes, enodes;
+  for (size_t j = 0; j < J; ++j) {
+    const PdJobInScheduler& p = *pending_jobs[j];
+    auto pit = I.part_idx.find(p.partition_id);
+    part[j] = pit == I.part_idx.end() ? 0xFFFFFFFFu : pit->second;  // -> "Partition Not Found" (cpp:6748-6752)
+    L[j] = p.time_limit;
+    ncpu[j] = p.req_node_res_view.cpu_count.raw;
+    nmem[j] = p.req_node_res_view.memory_bytes;
+    tcpu[j] = p.req_task_res_view.cpu_count.raw;
+    tmem[j] = p.req_task_res_view.memory_bytes;
+    k[j] = p.node_num; nt[j] = p.ntasks; tmin[j] = p.ntasks_per_node_min; tmax[j] = p.ntasks_per_node_max;
+    excl[j] = p.exclusive;
+    skip[j] = !p.reason.empty() || !p.reservation.empty();  // cpp:6744; reservation jobs stay with the caller
+    for (const auto& [name, gc] : p.req_node_res_view.gres_map) {
+      auto nit = I.name_id.find(name);
+      uint64_t tot = gc.total;
+      if (nit == I.name_id.end()) { if (tot || !gc.specified.empty()) gtot[j * CNS_MAX_GRES_NAMES] = 255; continue; }  // name absent everywhere: never fits
+      gtot[j * CNS_MAX_GRES_NAMES + nit->second] = (uint8_t)std::min<uint64_t>(tot, 255);
+      for (const auto& [type, cnt] : gc.specified) {
+        int c = I.class_of(name, type);
+        if (c < 0) { if (cnt) gtot[j * CNS_MAX_GRES_NAMES + nit->second] = 255; continue; }               // type absent everywhere
+        gspec[j * CNS_MAX_GRES_CLASSES + c] = (uint8_t)std::min<uint64_t>(cnt, 127);
+      }
+    }
+    for (const auto& n : p.included_nodes) { auto it = I.node_idx.find(n); inodes.push_back(it == I.node_idx.end() ? 0xFFFFFFFEu : it->second); }
+    ioff.push_back(inodes.size());
+    for (const auto& n : p.excluded_nodes) { auto it = I.node_idx.find(n); if (it != I.node_idx.end()) enodes.push_back(it->second); }
+    eoff.push_back(enodes.size());
+  }
+  if (inodes.empty()) inodes.push_back(0);
+  if (enodes.empty()) enodes.push_back(0);
+  cns_job_soa js{};
+  js.num_jobs = J;
+  js.partition = part.data(); js.time_limit_sec = L.data(); js.node_cpu_raw = ncpu.data(); js.node_mem = nmem.data();
+  js.task_cpu_raw = tcpu.data(); js.task_mem = tmem.data(); js.node_num = k.data(); js.ntasks = nt.data();
+  js.ntasks_per_node_min = tmin.data(); js.ntasks_per_node_max = tmax.data(); js.exclusive = excl.data();
+  js.gres_total = gtot.data(); js.gres_spec = gspec.data(); js.incl_offsets = ioff.data(); js.incl_nodes = inodes.data();
+  js.excl_offsets = eoff.data(); js.excl_nodes = enodes.data(); js.skip = skip.data();
+
+  uint64_t places = 0;
+  for (size_t j = 0; j < J; ++j) places += k[j];
+  std::vector<int64_t> o_start(J + 1), o_cpu(places + 1);
+  std::vector<uint8_t> o_reason(J + 1);
+  std::vector<uint64_t> o_off(J + 1), o_mem(places + 1), o_lo(places + 1), o_hi(places + 1), o_g(places + 1);
+  std::vector<uint32_t> o_node(places + 1), o_nt(places + 1);
+  cns_placement_soa out{};
+  out.place_capacity = places;
+  out.start_sec = o_start.data(); out.reason = o_reason.data(); out.place_offsets = o_off.data();
+  out.node_idx = o_node.data(); out.ntasks = o_nt.data(); out.cpu_raw = o_cpu.data(); out.mem = o_mem.data();
+  out.core_lo = o_lo.data(); out.core_hi = o_hi.data(); out.gres = o_g.data();
+  st = cns_select(I.h, now, &js, &out);
+  if (st != 0) return fail_all(st, cns_last_error(I.h));
+  status_ = 0;
+  error_.clear();
+
+  // ---- write back (what JobScheduler.cpp:1492-1600 consumes) --------------------------------------------
+  for (size_t j = 0; j < J; ++j) {
+    PdJobInScheduler& p = *pending_jobs[j];
+    const uint8_t r = o_reason[j];
+    if (r == CNS_REASON_SKIPPED) continue;  // the caller's reason stays
+    p.reason = kReasonStr[r];
+    p.craned_ids.clear(); p.craned_id_to_task_num.clear(); p.allocated_res.clear();
+    if (o_start[j] == 0) continue;          // nothing placed ("Resource" / "Partition Not Found" / "Priority" beyond the batch)
+    p.start_time = o_start[j];
+    p.end_time = p.start_time + p.time_limit;  // cpp:6772
+    for (uint64_t q = o_off[j]; q < o_off[j + 1]; ++q) {
+      if (o_node[q] == CNS_NODE_NONE) continue;
+      const CranedId& cid = I.node_name[o_node[q]];
+      p.craned_ids.push_back(cid);
+      p.craned_id_to_task_num[cid] = o_nt[q];
+      ResourceInNodeV3 res = I.to_res(o_cpu[q], o_mem[q], o_lo[q], o_hi[q], o_g[q]);
+      res.memory_sw_bytes = p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o_nt[q];
+      p.allocated_res[cid] = std::move(res);
+    }
+  }
+}
+
+}  // namespace crane

@@ -1,0 +1,161 @@
+// C++ host side of the drop-in: the `INodeSelectionAlgo` plugin surface for CraneCtld's JobScheduler.
+//
+// The reference holds its node-selection algorithm as a concrete class
+//     std::unique_ptr<SchedulerAlgo> m_node_selection_algo_;          src/CraneCtld/JobScheduler.h:1286
+// built at src/CraneCtld/JobScheduler.cpp:158-159 and called once per cycle at :1441 through its single
+// public method (JobScheduler.h:260-263):
+//     void NodeSelect(const absl::Time& now,
+//                     const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
+//                     const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs);
+// `INodeSelectionAlgo` is that signature as an abstract base; `GpuNodeSelectionAlgo` implements it on top
+// of the C ABI in include/crane_gpu/node_select.h, so swapping the make_unique at cpp:158-159 is the whole
+// integration.  Struct and field names follow the reference (JobScheduler.h:57-170,
+// PublicHeader.h:427-761) so that code written against CraneCtld's types reads the same here.
+//
+// abseil / protobuf / fpm are not available offline; their types are restated minimally:
+//   absl::Time      -> crane::TimeSec   (int64 seconds; the path only uses whole seconds, cpp:1351)
+//   cpu_t           -> crane::cpu_t     (int64 raw = value * 256, fpm::fixed<int64,__int128,8>)
+//   CranedId/SlotId -> std::string, as in the reference
+#pragma once
+#include <cstdint>
+#include <list>
+#include <map>
+#include <memory>
+#include <set>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+struct cns_engine;
+
+namespace crane {
+
+using TimeSec = int64_t;
+using job_id_t = uint32_t;
+using CranedId = std::string;
+using PartitionId = std::string;
+using SlotId = std::string;
+
+struct cpu_t {  // fpm::fixed<int64_t, __int128, 8>
+  int64_t raw = 0;
+  cpu_t() = default;
+  explicit cpu_t(int v) : raw(static_cast<int64_t>(v) * 256) {}
+  explicit cpu_t(double v) : raw(static_cast<int64_t>(v * 256.0 + (v >= 0 ? 0.5 : -0.5))) {}
+  static cpu_t from_raw(int64_t r) { cpu_t c; c.raw = r; return c; }
+  explicit operator double() const { return static_cast<double>(raw) / 256.0; }
+  bool operator==(const cpu_t& o) const { return raw == o.raw; }
+};
+
+struct GresCount {  // PublicHeader.h:505-523
+  uint64_t total{0};
+  std::unordered_map<std::string /*type*/, uint64_t> specified;
+};
+using GresMap = std::unordered_map<std::string /*name*/, GresCount>;
+
+struct ResourceView {  // PublicHeader.h:695-761 (fields that reach the path)
+  cpu_t cpu_count;
+  uint64_t memory_bytes{0};
+  uint64_t memory_sw_bytes{0};
+  GresMap gres_map;
+};
+
+struct CpuSet {  // PublicHeader.h:555-573
+  std::set<uint32_t> core_ids;
+  cpu_t cpu_count;
+};
+using TypeSlotsMap = std::unordered_map<std::string /*type*/, std::set<SlotId>>;
+using DedicatedResourceInNode = std::unordered_map<std::string /*name*/, TypeSlotsMap>;
+
+struct ResourceInNodeV3 {  // PublicHeader.h:586-639
+  CpuSet cpu_set;
+  uint64_t memory_bytes{0};
+  uint64_t memory_sw_bytes{0};
+  DedicatedResourceInNode gres;
+};
+using ResourceV3 = std::unordered_map<CranedId, ResourceInNodeV3>;  // EachNodeResMap()
+
+struct RnJobInScheduler {  // JobScheduler.h:57-90
+  job_id_t job_id{0};
+  PartitionId partition_id;
+  std::string reservation;
+  TimeSec start_time{0};
+  TimeSec end_time{0};
+  ResourceV3 allocated_res;
+};
+
+struct PdJobInScheduler {  // JobScheduler.h:92-170
+  job_id_t job_id{0};
+  int64_t time_limit{0};  // absl::Duration, whole seconds
+  PartitionId partition_id;
+  std::string reservation;
+  ResourceView req_node_res_view;
+  ResourceView req_task_res_view;
+  uint32_t node_num{1};
+  uint32_t ntasks_per_node_min{1};
+  uint32_t ntasks_per_node_max{1};
+  uint32_t ntasks{1};
+  bool exclusive{false};
+  std::unordered_set<std::string> included_nodes;
+  std::unordered_set<std::string> excluded_nodes;
+  // results (JobScheduler.h:117-133)
+  std::unordered_map<CranedId, uint32_t> craned_id_to_task_num;
+  TimeSec start_time{0};
+  TimeSec end_time{0};
+  ResourceV3 allocated_res;
+  std::vector<CranedId> craned_ids;
+  std::string reason;
+  bool is_scheduled() const { return reason.empty(); }
+};
+
+// What NodeSelect's prologue reads from g_meta_container (JobScheduler.cpp:6563-6617): per craned its
+// res_total, alive/drain, and the partition -> craned ids map.  In CraneCtld the adapter fills this from
+// CranedMetaContainer (src/CraneCtld/Node/CranedMetaContainer.h:116-120, NodeDefs.h:59-81) while holding
+// the same locks the reference takes.
+struct CranedMeta {
+  CranedId craned_id;
+  ResourceInNodeV3 res_total;
+  bool alive{true};
+  bool drain{false};
+};
+struct ClusterSnapshot {
+  std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
+  std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
+};
+
+class INodeSelectionAlgo {
+ public:
+  virtual ~INodeSelectionAlgo() = default;
+  virtual void NodeSelect(const TimeSec& now,
+                          const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
+                          const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) = 0;
+};
+
+// MI355X implementation.  Engine-level failures (no GPU, unsupported input) never fall back to a CPU
+// scheduler: every pending job is left unscheduled with reason "GpuEngineError" and LastError() says why.
+class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
+ public:
+  explicit GpuNodeSelectionAlgo(int device = 0, uint64_t scheduled_batch_size = 0);
+  ~GpuNodeSelectionAlgo() override;
+  GpuNodeSelectionAlgo(const GpuNodeSelectionAlgo&) = delete;
+  GpuNodeSelectionAlgo& operator=(const GpuNodeSelectionAlgo&) = delete;
+
+  // Per-cycle snapshot (the reference re-reads the meta container inside NodeSelect; here the caller
+  // hands the snapshot over before the call).
+  void SetClusterSnapshot(const ClusterSnapshot& snap);
+
+  void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
+                  const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) override;
+
+  bool Ok() const { return status_ == 0; }
+  int LastStatus() const { return status_; }
+  const std::string& LastError() const { return error_; }
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+  int status_{0};
+  std::string error_;
+};
+
+}  // namespace crane

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz: inputs are re-derived from seeds, outputs come from the CPU oracle
+(mask algebra, cross-checked against the literal-container algebra before writing).
+
+    python tests/golden/make_golden.py
+
+The reference itself cannot be built or imported here, so these are ORACLE outputs
+frozen as regression fixtures — they pin the engine and the oracle against silent drift, they are
+not outputs of the reference binary.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from cranesched_amd import synth  # noqa: E402
+from oracle import pyoracle  # noqa: E402
+from tests import helpers  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+CASES = {
+    "c1_full": lambda: synth.make_config("C1") + (None,),
+    "c2_small": lambda: synth.make_config("C2", J=5000, N=128) + (None,),
+    "c4_small": lambda: synth.make_config("C4", J=6000, N=512, P=8) + (None,),
+    "c5_small": lambda: synth.make_config("C5", J=6000, N=256, P=8) + (None,),
+    "hetero_3": lambda: helpers.random_case(3),
+    "hetero_5": lambda: helpers.random_case(5),
+}
+
+
+def main():
+    for name, make in CASES.items():
+        c, j, now, run = make()
+        r = pyoracle.select(c, j, now, running=run)
+        r2 = pyoracle.select(c, j, now, running=run, algebra=pyoracle.LITERAL)
+        assert r.placements.diff(r2.placements) is None, name
+        t = r.placements.trimmed()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), costs=r.costs().view(np.uint64), **t)
+        print(name, j.num_jobs, "jobs", np.bincount(t["reason"], minlength=3))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,54 @@
+"""The C ABI library builds for gfx950, loads without a GPU, exports every symbol the header
+declares, and refuses to run without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "crane_gpu", "node_select.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(cns_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(built):
+    from cranesched_amd import engine
+    lib = engine.lib()
+    names = header_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in node_select.h but not exported"
+    assert set(names) == set(engine.ABI_SYMBOLS), "engine.ABI_SYMBOLS out of sync with the header"
+    assert lib.cns_abi_version() == 1
+
+
+def test_no_gpu_means_loud_failure(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from cranesched_amd import abi, engine
+    with pytest.raises(engine.EngineError) as ei:
+        engine.GpuNodeSelector(device=0)
+    assert ei.value.status == -2  # CNS_ERR_NO_DEVICE: never a silent CPU path
+
+
+def test_bad_abi_version_rejected(built):
+    from cranesched_amd import abi, engine
+    h = C.c_void_p()
+    cfg = abi.CnsConfig(99, 0, 0, 0, 0, 0)
+    assert engine.lib().cns_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"ABI" in engine.lib().cns_last_error(None)
+
+
+def test_product_never_imports_oracle():
+    """oracle/ is test infrastructure: nothing under cranesched_amd/ may import, link or exec it."""
+    for d, _, files in os.walk(os.path.join(ROOT, "cranesched_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f"{f} imports the oracle"
+                assert "liboracle" not in txt and "pyoracle" not in txt and "oracle/" not in txt, f"{f} uses the oracle"

@@ -1,0 +1,27 @@
+"""Committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py) vs today's oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+from tests.golden.make_golden import CASES, HERE
+
+
+def load(name):
+    return np.load(os.path.join(HERE, name + ".npz"))
+
+
+def compare(name, placements, costs):
+    g = load(name)
+    t = placements.trimmed()
+    for k in t:
+        assert np.array_equal(g[k], t[k]), f"{name}: {k} differs from the golden fixture"
+    assert np.array_equal(g["costs"], costs.view(np.uint64)), f"{name}: fp64 costs differ"
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_golden(name):
+    c, j, now, run = CASES[name]()
+    r = pyoracle.select(c, j, now, running=run)
+    compare(name, r.placements, r.costs())

@@ -1,0 +1,22 @@
+"""C++ host adapter (cranesched_amd/host): INodeSelectionAlgo::NodeSelect over the C ABI."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "cranesched_amd", "host", "test_host_adapter")
+
+
+def test_adapter_without_gpu_is_loud(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([EXE, "--no-gpu"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_adapter_known_answers_on_gpu(built):
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr

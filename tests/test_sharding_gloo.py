@@ -1,0 +1,79 @@
+"""The N > 1 path on CPU: two gloo ranks, partition-sharded queue, all-gather of the packed
+placement buffers, merge — must reproduce the single-process result bit for bit.
+
+No GPU here, so each rank's shard is computed by the CPU oracle standing in for the engine; what is
+under test is everything bench.py adds for N > 1: the partition plan, the shard selection, the
+packed-buffer layout (mirror of csrc/engine.hip), the collective and the merge."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def pack(pl, jobs):
+    from cranesched_amd import sharding
+    lay = sharding.results_layout(jobs.num_jobs, jobs.total_places())
+    buf = np.zeros(lay["total"], np.uint8)
+    for name, (off, elem, n) in lay.items() if False else [(k, v) for k, v in lay.items() if k != "total"]:
+        arr = getattr(pl, name)[:n]
+        buf[off:off + elem * n] = np.ascontiguousarray(arr).view(np.uint8)
+    return buf
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cranesched_amd import sharding, synth
+    from oracle import pyoracle
+    cluster, jobs, now = synth.make_config("C4", J=6000, N=512, P=8)
+    mine, idx = sharding.shard(cluster, jobs, rank, world)
+    r = pyoracle.select(cluster, mine, now)
+    buf = pack(r.placements, mine)
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([len(buf)], dtype=torch.int64))
+    pad = int(max(s.item() for s in sizes))
+    send = torch.zeros(pad, dtype=torch.uint8)
+    send[:len(buf)] = torch.from_numpy(buf)
+    out = torch.empty(pad * world, dtype=torch.uint8)
+    dist.all_gather_into_tensor(out, send)
+    # every rank now holds all shards: unpack + merge into global queue order
+    shards = []
+    for rk in range(world):
+        sj, sidx = sharding.shard(cluster, jobs, rk, world)
+        raw = out[rk * pad:(rk + 1) * pad].numpy()
+        shards.append((sharding.unpack_results(raw, sj), sidx))
+    merged = sharding.merge(jobs, shards)
+    ref = pyoracle.select(cluster, jobs, now)
+    q.put((rank, merged.diff(ref.placements)))
+    dist.destroy_process_group()
+
+
+def test_two_rank_shard_allgather_merge():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, d in res:
+        assert d is None, f"rank {rank}: merged result differs from the single-process run: {d}"
+
+
+def test_partition_plan_covers_everything():
+    from cranesched_amd import sharding
+    for P in (1, 3, 8):
+        for w in (1, 2, 4, 8):
+            plan = sharding.partition_plan(P, w)
+            assert sorted(p for r in plan for p in r) == list(range(P))
