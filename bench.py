@@ -116,6 +116,13 @@ def main():
         value = total_jobs * args.steps / elapsed
         avg_sel_ms = float(np.mean(sel_ms))
         achieved = tm["algorithmic_bytes"] / (avg_sel_ms * 1e-3) / 1e9
+        traffic = None  # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+        try:
+            prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm.json"))
+            if prof and args.config == "C4" and args.jobs is None and args.nodes is None and world == 1:
+                traffic = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["traffic_bytes_per_launch"]
+        except OSError:
+            pass
         got = eng.download()
         r = got.reason[:my_jobs.num_jobs]
         line = {
@@ -133,7 +140,7 @@ def main():
                        "kernel_ms": {"k_select": avg_sel_ms, "k_init_nodes+fill": float(np.mean(init_ms))},
                        "h2d_job_table_ms": h2d_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "k_select", "algorithmic_bytes_per_launch": tm["algorithmic_bytes"],
                          "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); "
                                  "the node tile is register-resident, so HBM traffic is far below this"},
