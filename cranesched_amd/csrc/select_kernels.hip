@@ -54,6 +54,15 @@ __device__ __forceinline__ Res uni_res(const Res& r) {
   return o;
 }
 
+// Workgroup barrier that only drains LDS traffic.  __syncthreads() also waits for every outstanding
+// global load / store of the wave (s_waitcnt vmcnt(0)): that would expose, at EVERY barrier, the latency of
+// the job-record prefetch (scanners) and of the time-map stores just issued (worker).  Everything the
+// roles exchange goes through LDS; the two places where data crosses waves through HBM (owner-update
+// lists longer than the LDS list) fence explicitly.
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// The worker re-reads node blocks it stored to in earlier jobs: make those stores complete first.
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- wave64 reductions on the DPP crossbar (no LDS traffic, no ds_bpermute latency) -------------------
 // row_shr:1,2,4,8 folds each row of 16 lanes into its lane 15; row_bcast:15 / row_bcast:31 fold the
 // four rows into lane 63 (the classic GCN/CDNA wave reduction); v_readlane 63 makes the result scalar.
@@ -277,6 +286,41 @@ __device__ __forceinline__ JobCtx make_job(const KParams& P, u64 ji, u32 raw) {
   return J;
 }
 
+// Compact view of a job for the worker's inline fast path (the full JobCtx only exists in LDS, for the
+// out-of-line multi-node / general paths): keeps the worker's scalar-register footprint small.
+struct FastJob {
+  i64 L, E;
+  Req mv;        // minimum view = req_node + req_task * tpn_min
+  u32 flags, k, tmin, ntasks;
+  u32 orig;
+  u64 poff;
+};
+__device__ __forceinline__ FastJob make_fast_job(const KParams& P, u32 raw) {
+  FastJob F;
+  F.L = (i64)jr64(raw, kJrL);
+  F.E = P.now + F.L;
+  F.k = rl32(raw, kJrK);
+  F.ntasks = rl32(raw, kJrNtasks);
+  F.tmin = rl32(raw, kJrTmin);
+  F.flags = rl32(raw, kJrFlags);
+  Req nv;
+  nv.cpu = (i64)jr64(raw, kJrNcpu); nv.mem = jr64(raw, kJrNmem);
+  nv.gtot = rl32(raw, kJrGtot); nv.gspec = jr64(raw, kJrGspec);
+  F.mv = compose(nv, (i64)jr64(raw, kJrTcpu), jr64(raw, kJrTmem), F.tmin);
+  F.orig = rl32(raw, kJrOrig);
+  F.poff = jr64(raw, kJrPoff);
+  return F;
+}
+// full decode into LDS for the out-of-line paths
+__device__ __noinline__ void job_to_lds(const KParams& P, u64 ji, u32 raw, JobCtx* dst) {
+  const JobCtx J = make_job(P, ji, raw);
+  if ((threadIdx.x & 63u) == 0) *dst = J;
+  __threadfence_block();
+}
+__device__ __forceinline__ bool req_impossible(const Req& mv) {
+  return mv.cpu > 0x7FFFFFFEll || (mv.gspec & 0x8080808080808080ull) != 0;
+}
+
 // membership of node n in the job's included / excluded list (JobScheduler.cpp:6202-6220)
 __device__ __forceinline__ bool in_list(const u32* lst, u64 b, u64 e, u32 n) {
   for (u64 i = b; i < e; ++i)
@@ -312,8 +356,11 @@ __device__ __forceinline__ int type_capacity(const KParams& P, const KParams* Pg
   return tt;
 }
 // get_max_tasks(res_total) > 0  <=>  the minimum view fits res_total (JobScheduler.cpp:6171-6175, :6222-6223)
+__device__ __forceinline__ u64 type_ok_mask(const KParams& P, const Req& mv, const TypeLane& tl, u32 lane) {
+  return __ballot((lane < P.num_types) & feasible_counts(mv, tl.cpu, tl.mem, tl.ncores, tl.cnt, P.gres));
+}
 __device__ __forceinline__ u64 type_ok_mask(const KParams& P, const JobCtx& J, const TypeLane& tl, u32 lane) {
-  return __ballot((lane < P.num_types) & feasible_counts(J.min_view, tl.cpu, tl.mem, tl.ncores, tl.cnt, P.gres));
+  return type_ok_mask(P, J.min_view, tl, lane);
 }
 
 constexpr u32 kScan = (kWaves - 1) * 64;  // 960 scanner lanes
@@ -572,30 +619,42 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
 
 // Single-node ending (node_num == 1) straight from the register-resident chunk: commit, cost, owner
 // update and the one placement record.
-__device__ __forceinline__ void commit_single_regs(const KParams& P, const JobCtx& J, NodeHdr* hd, const NodeHdr& h,
-                                                   const TlEntry& e, u32 q, u32 code, double cost, const Res& alloc,
-                                                   i64 start, int reason, u32 lane, UpdRec* s_upd, int* s_nupd) {
-  const i64 end = start + J.L;
-  const u32 orig = J.orig;
-  const u64 poff = J.poff;
+// What the scanners (and the worker's own merge) know about one node: the scan summary.
+struct NodeSum {
+  u64 cost;   // fp64 cost bit pattern
+  u32 code;   // scanner slot code (kNone = no node)
+  u32 len, type;
+  int fcpu;   // front (t = now) summary, as in KParams::f_cpu / f_mem / f_cnt
+  u32 fmem;
+  u64 fcnt;
+};
+
+__device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 orig, u64 poff, NodeHdr* hd,
+                                                   const NodeHdr& h, const TlEntry& e, u32 q, u32 code, double cost,
+                                                   const Res& alloc, i64 start, int reason, u32 lane, UpdRec* s_upd,
+                                                   int* s_nupd, NodeSum& ns) {
+  const i64 end = start + L;
   const u32 newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, alloc, lane, orig);
   const double ratio = ((double)alloc.cpu / 256.0) / ((double)h.total.cpu / 256.0);
   const double delta = (double)(end - start) * ratio;
   const double ncost = cost + delta;
+  const bool has_front = start == P.now;
+  Res f = rl_res(e.r, 0);  // entry 0 = the entry at `now`
+  if (has_front) res_sub(f, alloc);
+  ns.cost = cost_key(ncost); ns.code = code; ns.len = newlen; ns.type = h.type;
+  ns.fcpu = clamp_cpu(f.cpu); ns.fmem = mem_mib_ceil(f.mem); ns.fcnt = class_counts(f.gres, P.gres);
   if (lane == 0) {
     UpdRec u;
     u.p = code;
     u.len = newlen;
     u.cost = ncost;
-    u.has_front = (start == P.now) ? 1u : 0u;
-    Res f = e.r;  // lane 0 holds entry 0 = the entry at `now`
-    if (u.has_front) res_sub(f, alloc);
-    u.fcpu = clamp_cpu(f.cpu);
-    u.fmem = mem_mib_ceil(f.mem);
-    u.fcnt = class_counts(f.gres, P.gres);
+    u.has_front = has_front ? 1u : 0u;
+    u.fcpu = ns.fcpu;
+    u.fmem = ns.fmem;
+    u.fcnt = ns.fcnt;
     u.pad = 0;
     P.cost[q] = ncost;
-    if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
+    if (has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
     s_upd[0] = u;
     *s_nupd = 1;
     P.o_node[poff] = h.node;
@@ -607,6 +666,22 @@ __device__ __forceinline__ void commit_single_regs(const KParams& P, const JobCt
     P.o_gres[poff] = alloc.gres;
     P.o_start[orig] = start;
     P.o_reason[orig] = (uint8_t)reason;
+  }
+}
+
+// Would node `ns` be a candidate of job X?  b: may host it at all, a: may start it now.  Same meaning as the
+// scanners' bmask / amask (any NECESSARY condition is valid for `a`: the exact test decides).
+__device__ __forceinline__ void eval_node(const KParams& P, const Req& mv, u32 flags, u64 typeok, const NodeSum& ns,
+                                          bool& b, bool& a) {
+  b = ns.code != kNone && !req_impossible(mv) && ((typeok >> ns.type) & 1ull) != 0 && ns.len < P.max_jobs_per_node;
+  a = b && mv.cpu <= (i64)ns.fcpu && (mv.mem >> 20) <= (u64)ns.fmem;
+  if (a && (flags & kJfGres)) {
+    const u64 H8 = 0x8080808080808080ull;
+    a = (((ns.fcnt | H8) - mv.gspec) & H8) == H8;
+    for (int g = 0; g < kMaxNames; ++g) {
+      const u32 tot = (mv.gtot >> (8 * g)) & 0xFFu;
+      if (tot && byte_sum(ns.fcnt & P.gres.name_bytes[g]) < tot) a = false;
+    }
   }
 }
 
@@ -682,11 +757,18 @@ struct WorkerShared {
 // round-0 barrier with the A and T winners, leaves after the job's last barrier; returns the LDS
 // double-buffer parity.
 __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared sh, const JobCtx* Jp, int par,
-                                            u64 wc, u32 wcode, u64 tc, u32 tcode, int tt_lane, u32 qbeg,
-                                            HeapEnt* gheap) {
+                                            u64 wc, u32 wcode, u64 tc, u32 tcode, u32 qbeg, HeapEnt* gheap) {
   const JobCtx J = *Jp;
   const u32 lane = threadIdx.x & 63u;
+  drain_stores();
   const bool excl_job = (J.flags & kJfExclusive) != 0;
+  // ntasks_on_node_total per node type (JobScheduler.cpp:6222): lane t evaluates type t
+  int tt_lane = 0;
+  if (lane < P.num_types) {
+    const Res ttot = P.type_total[lane];
+    if (J.general) tt_lane = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, ttot, P.gres);
+    else { Res tmp; tt_lane = feasible(J.min_view, ttot, tmp, P.gres) ? (int)J.tmin : 0; }
+  }
   const u32 orig = J.orig;
   HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
   UpdRec* const s_upd = (J.k <= (u32)kMaxUpd) ? sh.upd : P.g_upd + qbeg;  // long lists go through HBM
@@ -741,10 +823,11 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
         code = 2;
       }
     }
+    if (J.k > (u32)kMaxUpd) __threadfence_block();  // the owner updates went through HBM (g_upd)
     if (lane == 0) *sh.flag = code;
-    __syncthreads();  // B2: verdict (and, on success, the owner updates) visible to the scanners
+    wg_barrier();  // B2: verdict (and, on success, the owner updates) visible to the scanners
     if (code == 2) return par;
-    __syncthreads();  // B1 of the next round
+    wg_barrier();  // B1 of the next round
     wc = sh.wc[par][lane & (kWaves - 1)];
     wcode = sh.wp[par][lane & (kWaves - 1)];
     reduce16(wc, wcode);
@@ -784,10 +867,10 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       tsum = nsum; nsel = nsize;
       const bool stop = nsel == (int)J.k && (u32)tsum >= J.ntasks;
       if (lane == 0) *sh.flag = stop ? 1 : 0;
-      __syncthreads();  // B2 (ntasks > node_num only)
+      wg_barrier();  // B2 (ntasks > node_num only)
       if (stop) { complete = true; break; }
     }
-    __syncthreads();  // B1
+    wg_barrier();  // B1
     cc = sh.wc[par][lane & (kWaves - 1)];
     ccode = sh.wp[par][lane & (kWaves - 1)];
     reduce16(cc, ccode);
@@ -838,13 +921,15 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     }
   }
   if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
+  if (J.k > (u32)kMaxUpd) __threadfence_block();  // the owner updates went through HBM (g_upd)
   if (lane == 0) *sh.flag = code;
-  __syncthreads();  // B3
+  wg_barrier();  // B3
   return par;
 }
 
 // Loads the node block of slot q the way the fast paths want it: header scalarised, lane i <- entry i.
 __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, NodeHdr*& hd, NodeHdr& h, TlEntry& e) {
+  drain_stores();
   hd = hdr_of(P, q);
   h = *hd;
   e = tl_of(hd)[lane];
@@ -935,9 +1020,9 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
       }
     }
     if (lane == 0) *sh.flag = code;
-    __syncthreads();  // B2
+    wg_barrier();  // B2
     if (code == 2) return par;
-    __syncthreads();  // B1 of the next round
+    wg_barrier();  // B1 of the next round
     wc = sh.wc[par][lane & (kWaves - 1)];
     wcode = sh.wp[par][lane & (kWaves - 1)];
     reduce16(wc, wcode);
@@ -959,7 +1044,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
     }
     ++nsel;
     if (nsel == J.k) { complete = true; break; }
-    __syncthreads();  // B1
+    wg_barrier();  // B1
     cc = sh.wc[par][lane & (kWaves - 1)];
     ccode = sh.wp[par][lane & (kWaves - 1)];
     reduce16(cc, ccode);
@@ -1010,8 +1095,24 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
   }
   if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
   if (lane == 0) *sh.flag = code;
-  __syncthreads();  // B3
+  wg_barrier();  // B3
   return par;
+}
+
+// included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
+// whose bit is set in bmask; out of line: rare, and it touches no tile register.
+__device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 incl_b, u64 incl_e, u64 excl_b, u64 excl_e,
+                                      u32 bmask, u32 slot0, u32 npl) {
+  u32 lm = 0;
+  for (u32 r = 0; r < npl; ++r) {
+    if (!((bmask >> r) & 1u)) continue;
+    const u32 n = Pp->slot_node[slot0 + r * kScan];
+    bool okl = true;
+    if ((flags & kJfIncl) && !in_list(Pp->incl_nodes, incl_b, incl_e, n)) okl = false;
+    if ((flags & kJfExcl) && in_list(Pp->excl_nodes, excl_b, excl_e, n)) okl = false;
+    lm |= (okl ? 1u : 0u) << r;
+  }
+  return lm;
 }
 
 // ---- scanner tile compression -----------------------------------------------------------------------
@@ -1048,7 +1149,14 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ u32 s_wp[2][kWaves];
   __shared__ u64 s_tc[kWaves];
   __shared__ u32 s_tp[kWaves];
+  __shared__ u64 s_pc[kWaves];   // pre-scan of the NEXT job: per-wave A / T argmins over the nodes that
+  __shared__ u32 s_pp[kWaves];   // cannot change (everything but this job's round-0 winners)
+  __shared__ u64 s_ptc[kWaves];
+  __shared__ u32 s_ptp[kWaves];
+  __shared__ u64 s_win_c[2];     // winners of the next job as merged by the worker: [0] = A, [1] = T
+  __shared__ u32 s_win_p[2];
   __shared__ int s_flag;
+  __shared__ int s_r0;   // worker -> scanners: this job may be followed by the worker-side merge
   __shared__ int s_nupd;
   __shared__ UpdRec s_upd[kMaxUpd];
   __shared__ HeapEnt s_heap[kLdsHeap];
@@ -1074,150 +1182,187 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     s_ty_cpu[lane] = clamp_cpu(ttot.cpu);
     s_ty_m16[lane] = mem_gib16(mem_mib_ceil(ttot.mem));
     s_ty_gn[lane] = nibbles_of(tyl.cnt);
-    __syncthreads();  // type tables visible to the scanners
+    wg_barrier();  // type tables visible to the scanners
     WorkerShared sh;
     sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap;
     HeapEnt* const gheap = P.heap + qbeg + part;
-    u32 raw = fetch_job(P, jbeg);
+    if (lane == 0) { s_pc[0] = ~0ull; s_pp[0] = kNone; s_ptc[0] = ~0ull; s_ptp[0] = kNone; }
+    u32 raw = fetch_job(P, jbeg);       // record of the job being processed
+    u32 raw_n = jbeg + 1 < jend ? fetch_job(P, jbeg + 1) : 0u;  // next job's record: in flight during this job
+    bool pre_valid = false;   // winners of this job already known from the previous iteration's merge
+    u64 wc = ~0ull, tc = ~0ull;
+    u32 wcode = kNone, tcode = kNone;
     for (u64 ji = jbeg; ji < jend; ++ji) {
       PROF_T(p0);
-      const JobCtx J = make_job(P, ji, raw);
-      if (ji + 1 < jend) raw = fetch_job(P, ji + 1);  // next job's record: in flight during this job
-      const bool simple = !(J.flags & kJfExclusive) && !J.general;  // ntasks == node_num on shared nodes
-      const bool fast = simple && J.k == 1;
-      const u32 orig = J.orig;
+      const FastJob F = make_fast_job(P, raw);
+      const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
+      const bool fast = simple && F.k == 1 && F.tmin == 1;
 
-      __syncthreads();  // B1 (round 0): A and T argmins published
-      PROF_T(p1);
-      PROF_ADD(0, p0, p1);  // worker: decode + wait for the scanners
-      u64 wc = s_wc[par][lane & (kWaves - 1)];
-      u32 wcode = s_wp[par][lane & (kWaves - 1)];
-      u64 tc = s_tc[lane & (kWaves - 1)];
-      u32 tcode = s_tp[lane & (kWaves - 1)];
-      reduce16(wc, wcode);
-      reduce16(tc, tcode);
-      par ^= 1;
-      wc = uni64(wc); wcode = uni32(wcode); tc = uni64(tc); tcode = uni32(tcode);
-
-      if (!fast) {
-        if (lane == 0) s_job = J;
-        __threadfence_block();
-        if (simple && J.k <= (u32)kMaxUpd) {
-          par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
-          PROF_T(p8);
-          PROF_ADD(6, p1, p8);
-          PROF_CNT(15);
-        } else {
-          const int tt_lane = type_capacity(P, Pg, J, ttot, tyl, lane);
-          par = worker_job_slow(PG, sh, &s_job, par, wc, wcode, tc, tcode, tt_lane, qbeg, gheap);
-          PROF_T(p9);
-          PROF_ADD(5, p1, p9);
-          PROF_CNT(13);
-        }
-        continue;
-      }
-
-      // ---- fast path, Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) ------
-      bool success = false;
-      while (wcode != kNone) {
-        PROF_T(a0);
-        const u32 q = qbeg + slot_of_code(wcode);
-        int code = 0;
-        // one coalesced read: header (broadcast) + entry `lane` of the time map
-        NodeHdr* hd; NodeHdr h; TlEntry e;
-        load_block(P, q, lane, hd, h, e);
-        const u32 len = h.len;
-        PROF_T(a1);
-        PROF_ADD(1, a0, a1);  // node block load
-        Res f, m;
-        bool ok = false;
-        if (feasible(J.min_view, h.avail0, f, P.gres)) {       // :6274
-          m = uni_res(len <= 64 ? window_min_regs(e, lane < len, h.avail0, J.E)
-                                : window_min(tl_of(hd), len, h.avail0, J.E, lane));  // :6278-6283
-          ok = feasible(J.min_view, m, f, P.gres);              // get_max_tasks(min_res) > 0, :6285
-        }
-        PROF_T(a2);
-        PROF_ADD(2, a1, a2);  // window-min + feasibility
-        if (ok) {
-          Res alloc = f;                                        // tpn_min == 1: min view == 1-task view
-          if (J.tmin != 1 && !feasible(compose(J.node_view, J.tcpu, J.tmem, 1), m, alloc, P.gres)) {
-            if (lane == 0) set_fault(P, 2, orig, h.node, 0);
-          }
-          const double cst = __longlong_as_double((long long)wc);
-          if (len <= 64) {
-            commit_single_regs(P, J, hd, h, e, q, wcode, cst, alloc, P.now, 0, lane, s_upd, &s_nupd);
-          } else {
-            if (lane == 0) {
-              HeapEnt x; x.ntasks = 1; x.p = wcode; x.node = h.node; x.pad = 0; x.cost = cst; x.res = alloc;
-              s_heap[0] = x;
-              s_job = J;
-            }
-            __threadfence_block();
-            commit_selection(PG, s_job, s_heap, qbeg, P.now, lane, s_upd, &s_nupd);
-            if (lane == 0) { P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
-          }
-          code = 2;
-        }
-        PROF_T(a3);
-        PROF_ADD(3, a2, a3);  // commit
-        if (lane == 0) s_flag = code;
-        __syncthreads();  // B2: verdict (and, on success, the owner updates) visible to the scanners
-        if (code == 2) { success = true; break; }
-        PROF_CNT(14);         // rejected candidate
-        __syncthreads();  // B1 of the next round
+      if (!pre_valid) {
+        wg_barrier();  // B1 (round 0): A and T argmins published by the scanners
         wc = s_wc[par][lane & (kWaves - 1)];
         wcode = s_wp[par][lane & (kWaves - 1)];
+        tc = s_tc[lane & (kWaves - 1)];
+        tcode = s_tp[lane & (kWaves - 1)];
         reduce16(wc, wcode);
+        reduce16(tc, tcode);
         par ^= 1;
-        wc = uni64(wc); wcode = uni32(wcode);
+        wc = uni64(wc); wcode = uni32(wcode); tc = uni64(tc); tcode = uni32(tcode);
       }
-      if (success) { PROF_CNT(11); continue; }
+      PROF_T(p1);
+      PROF_ADD(0, p0, p1);  // worker: wait for the scanners (only when the pre-scan could not be used)
 
-      // ---- fast path, Phase B: the first node in cost order whose res_total fits (the T argmin of
-      // round 0), earliest start on its time map (JobScheduler.cpp:6335-6368, Backfill_ :6371-6376) ----
-      PROF_T(b0);
-      int code = 0;
-      if (tcode != kNone) {
-        const u32 q = qbeg + slot_of_code(tcode);
-        NodeHdr* hd; NodeHdr h; TlEntry e;
-        load_block(P, q, lane, hd, h, e);
-        const u32 len = h.len;
-        Res alloc = res_zero();
-        if (!feasible(compose(J.node_view, J.tcpu, J.tmem, 1), h.total, alloc, P.gres)) {  // :6354-6356
-          if (lane == 0) set_fault(P, 3, orig, h.node, 0);
+      bool round0 = true;       // this job may be followed by the worker-side merge
+      NodeSum cn, on;           // scan summaries after this job: the committed / examined node, the other winner
+      cn.code = kNone; cn.cost = 0; cn.len = 0; cn.type = 0; cn.fcpu = 0; cn.fmem = 0; cn.fcnt = 0;
+      on = cn;
+
+      bool divert = !fast;      // leave the inline path (multi-node / general / exclusive / long time map)
+      if (fast) {
+        // The T winner's summary is needed for the merge when this job commits on the A winner: fetch it
+        // now, ahead of the commit's stores (gfx9 counts loads and stores on one in-order counter).
+        if (wcode != kNone && tcode != kNone && tcode != wcode) {
+          drain_stores();  // its summary may have been stored by the previous job's commit
+          const u32 qt = qbeg + slot_of_code(tcode);
+          const NodeHdr* ht = hdr_of(P, qt);
+          on.code = tcode; on.cost = tc;
+          on.len = uni32(ht->len); on.type = uni32(ht->type);
+          on.fcpu = (int)uni32((u32)P.f_cpu[qt]); on.fmem = uni32(P.f_mem[qt]); on.fcnt = uni64(P.f_cnt[qt]);
         }
-        i64 s;
-        if (len <= 64) {
-          s = next_fit_regs(e, len, alloc, J.L, P.now, lane);
-        } else {
-          u32 j = 0;
-          s = next_fit(tl_of(hd), len, alloc, J.L, P.now, j);
-        }
-        if (s != kInf && s - P.now <= P.max_window) {          // kAlgoMaxTimeWindow, JobScheduler.h:815
-          int reason = 0;
-          if (s != P.now) reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;  // :6810-6831
-          const double cst = __longlong_as_double((long long)tc);
-          if (len <= 64) {
-            commit_single_regs(P, J, hd, h, e, q, tcode, cst, alloc, s, reason, lane, s_upd, &s_nupd);
-          } else {
-            if (lane == 0) {
-              HeapEnt x; x.ntasks = 1; x.p = tcode; x.node = h.node; x.pad = 0; x.cost = cst; x.res = alloc;
-              s_heap[0] = x;
-              s_job = J;
-            }
-            __threadfence_block();
-            commit_selection(PG, s_job, s_heap, qbeg, s, lane, s_upd, &s_nupd);
-            if (lane == 0) { P.o_start[orig] = s; P.o_reason[orig] = (uint8_t)reason; }
+        // ---- fast path, Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) ------
+        bool done = false;
+        while (wcode != kNone) {
+          PROF_T(a0);
+          const u32 q = qbeg + slot_of_code(wcode);
+          int code = 0;
+          // one coalesced read: header (broadcast) + entry `lane` of the time map
+          NodeHdr* hd; NodeHdr h; TlEntry e;
+          load_block(P, q, lane, hd, h, e);
+          if (h.len > 64) { divert = true; break; }  // long time map: the general routines take over from here
+          PROF_T(a1);
+          PROF_ADD(1, a0, a1);  // node block load
+          Res f, m;
+          bool ok = false;
+          // :6274 only needs the truth value of GetFeasibleResourceInNode(res_avail): counts suffice
+          if (feasible_counts(F.mv, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
+                              class_counts(h.avail0.gres, P.gres), P.gres)) {
+            m = uni_res(window_min_regs(e, lane < h.len, h.avail0, F.E));   // :6278-6283
+            ok = feasible(F.mv, m, f, P.gres);                             // get_max_tasks(min_res) > 0, :6285
           }
-          code = 2;
+          PROF_T(a2);
+          PROF_ADD(2, a1, a2);  // window-min + feasibility
+          if (ok) {  // tpn_min == 1: the minimum view is the 1-task view, f is the allocation (:6312-6320)
+            commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, __longlong_as_double((long long)wc), f,
+                               P.now, 0, lane, s_upd, &s_nupd, cn);
+            code = 2;
+          }
+          PROF_T(a3);
+          PROF_ADD(3, a2, a3);  // commit
+          if (lane == 0) { s_flag = code; s_r0 = round0 ? 1 : 0; }
+          wg_barrier();  // B2: verdict (and, on success, the owner updates) visible to the scanners
+          if (code == 2) { done = true; break; }
+          PROF_CNT(14);         // rejected candidate
+          round0 = false;
+          wg_barrier();  // B1 of the next round
+          wc = s_wc[par][lane & (kWaves - 1)];
+          wcode = s_wp[par][lane & (kWaves - 1)];
+          reduce16(wc, wcode);
+          par ^= 1;
+          wc = uni64(wc); wcode = uni32(wcode);
+        }
+        if (done) {
+          PROF_CNT(11);
+        } else if (!divert) {
+          // ---- fast path, Phase B: the first node in cost order whose res_total fits (the T argmin of
+          // round 0), earliest start on its time map (JobScheduler.cpp:6335-6368, Backfill_ :6371-6376) ----
+          PROF_T(b0);
+          int code = 0;
+          on.code = kNone;
+          NodeHdr* hd = nullptr; NodeHdr h; TlEntry e;
+          if (tcode != kNone) {
+            load_block(P, qbeg + slot_of_code(tcode), lane, hd, h, e);
+            if (h.len > 64) divert = true;
+          }
+          if (!divert) {
+            if (tcode != kNone) {
+              const u32 q = qbeg + slot_of_code(tcode);
+              Res alloc = res_zero();
+              if (!feasible(F.mv, h.total, alloc, P.gres)) {  // :6354-6356
+                if (lane == 0) set_fault(P, 3, F.orig, h.node, 0);
+              }
+              const i64 st = next_fit_regs(e, h.len, alloc, F.L, P.now, lane);
+              // the node as the scanners see it if nothing is committed
+              const Res e0 = rl_res(e.r, 0);
+              cn.code = tcode; cn.cost = tc; cn.len = h.len; cn.type = h.type;
+              cn.fcpu = clamp_cpu(e0.cpu); cn.fmem = mem_mib_ceil(e0.mem); cn.fcnt = class_counts(e0.gres, P.gres);
+              if (st != kInf && st - P.now <= P.max_window) {          // kAlgoMaxTimeWindow, JobScheduler.h:815
+                int reason = 0;
+                if (st != P.now) reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;  // :6810-6831
+                commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, __longlong_as_double((long long)tc),
+                                   alloc, st, reason, lane, s_upd, &s_nupd, cn);
+                code = 2;
+              }
+            }
+            if (code == 0 && lane == 0) { P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2; }  // "Resource", :6768
+            if (lane == 0) { s_flag = code; s_r0 = round0 ? 1 : 0; }
+            PROF_T(b1);
+            PROF_ADD(4, b0, b1);  // backfill + commit
+            PROF_CNT(12);
+            wg_barrier();  // B3
+          }
         }
       }
-      if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
-      if (lane == 0) s_flag = code;
-      PROF_T(b1);
-      PROF_ADD(4, b0, b1);  // backfill + commit
-      PROF_CNT(12);
-      __syncthreads();  // B3
+      if (divert) {
+        // out-of-line continuation from the current round: same barrier schedule, general code
+        round0 = false;
+        if (lane == 0) s_r0 = 0;
+        job_to_lds(PG, ji, raw, &s_job);
+        PROF_T(d0);
+        if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1) {
+          par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
+          PROF_T(p8);
+          PROF_ADD(6, d0, p8);
+          PROF_CNT(15);
+        } else {
+          par = worker_job_slow(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg, gheap);
+          PROF_T(p9);
+          PROF_ADD(5, d0, p9);
+          PROF_CNT(13);
+        }
+      }
+
+      // ---- next job: if the scanners' pre-scan is usable, merge the (at most two) nodes this job could
+      // have changed into it right here — the scanners are not on the critical path ------------------------
+      PROF_T(m0);
+      if (ji + 1 >= jend) break;
+      raw = raw_n;
+      raw_n = ji + 2 < jend ? fetch_job(P, ji + 2) : 0u;
+      const u32 nflags = rl32(raw, kJrFlags);
+      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl));
+      if (nv) {
+        const FastJob Fn = make_fast_job(P, raw);
+        u64 ac = s_pc[lane & (kWaves - 1)];
+        u32 ap = s_pp[lane & (kWaves - 1)];
+        u64 tcs = s_ptc[lane & (kWaves - 1)];
+        u32 tp = s_ptp[lane & (kWaves - 1)];
+        reduce16(ac, ap);
+        reduce16(tcs, tp);
+        ac = uni64(ac); ap = uni32(ap); tcs = uni64(tcs); tp = uni32(tp);
+        const u64 tyok = type_ok_mask(P, Fn.mv, tyl, lane);
+        bool b, a;
+        eval_node(P, Fn.mv, Fn.flags, tyok, cn, b, a);
+        if (a && (cn.cost < ac || (cn.cost == ac && cn.code < ap))) { ac = cn.cost; ap = cn.code; }
+        if (b && (cn.cost < tcs || (cn.cost == tcs && cn.code < tp))) { tcs = cn.cost; tp = cn.code; }
+        eval_node(P, Fn.mv, Fn.flags, tyok, on, b, a);
+        if (a && (on.cost < ac || (on.cost == ac && on.code < ap))) { ac = on.cost; ap = on.code; }
+        if (b && (on.cost < tcs || (on.cost == tcs && on.code < tp))) { tcs = on.cost; tp = on.code; }
+        wc = ac; wcode = ap; tc = tcs; tcode = tp;
+        if (lane == 0) { s_win_c[0] = wc; s_win_p[0] = wcode; s_win_c[1] = tc; s_win_p[1] = tcode; }
+        wg_barrier();  // B1': winners of the next job visible to the scanners
+      }
+      PROF_T(m1);
+      PROF_ADD(7, m0, m1);  // worker: next-job decode + merge
+      pre_valid = nv;
     }
   } else {
     // =============================================================================================
@@ -1250,12 +1395,14 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       nme[a] = nb & 0x0F0F0F0Fu;
       nmo[a] = (nb >> 4) & 0x0F0F0F0Fu;
     }
-    __syncthreads();  // type tables written by the worker
+    wg_barrier();  // type tables written by the worker
 
     u32 raw = fetch_job(P, jbeg);
     JobCtx J = make_job(P, jbeg, raw);
     u64 typeok = type_ok_mask(P, J, tyl, lane);
     if (jbeg + 1 < jend) raw = fetch_job(P, jbeg + 1);
+    const u32 maxlen = P.max_jobs_per_node;
+    const u32 G8 = 0x80808080u;
 
     // argmin of (cost, code) over the lane's nodes whose bit is set in `mask`; ties keep the lower r
     auto lane_argmin = [&](u32 mask, u64& bc, u32& bp) {
@@ -1271,33 +1418,28 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       bp = br == 0xFFu ? kNone : ((br << 10) | t);
     };
 
-    for (u64 ji = jbeg; ji < jend; ++ji) {
-      PROF_T(s0);
-      const bool excl_job = (J.flags & kJfExclusive) != 0;
-      const bool has_gres = (J.flags & kJfGres) != 0;
-      const bool possible = !job_impossible(J);
-      const int rc32 = J.min_view.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)J.min_view.cpu;
-      const u32 rm16 = (J.min_view.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(J.min_view.mem >> 30);
-      const u32 rq = nibbles_of(J.node_view.gspec);  // specified counts, saturating at 15 like the node side
+    // Candidate sets of one job as per-lane bitmasks + their lane-local argmins.  Nothing the filters look
+    // at changes during a job (commits happen at its end), so this runs ONCE per job:
+    //   bmask: node may host the job at all  (len < 1000 :6194, res_total fits :6222, lists :6202-6220)
+    //   amask: ... and may start it now      (front filter: necessary for :6274-6285 / :6251-6257)
+    // `skip` masks out nodes whose state is about to change (speculative pre-scan, see below).
+    auto scan_job = [&](const JobCtx& X, u64 tyok, u32 skip, u32& bmask, u32& amask, u64& ac, u32& ap, u64& tcs,
+                        u32& tp) {
+      const bool possible = !job_impossible(X);
+      const bool has_gres = (X.flags & kJfGres) != 0;
+      const int rc32 = X.min_view.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)X.min_view.cpu;
+      const u32 rm16 = (X.min_view.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(X.min_view.mem >> 30);
+      const u32 rq = nibbles_of(X.node_view.gspec);  // specified counts, saturating at 15 like the node side
       const u32 rqe = rq & 0x0F0F0F0Fu, rqo = (rq >> 4) & 0x0F0F0F0Fu;
-      const u32 gtot = J.node_view.gtot;
-      const u32 kk = J.k;
-      const bool general = J.general;
-      const u32 maxlen = P.max_jobs_per_node;
-      const u32 G8 = 0x80808080u;
-
-      // Nothing the filters look at changes during a job (commits happen at its end), so both candidate
-      // sets are computed ONCE per job as per-lane bitmasks, together with the round-0 argmins; later
-      // rounds only mask out the nodes already visited.
-      //   bmask: node may host the job at all  (len < 1000 :6194, res_total fits :6222, lists :6202-6220)
-      //   amask: ... and may start it now      (front filter: necessary for :6274-6285 / :6251-6257)
-      u32 bmask = 0, amask = 0;
-      u64 ac = ~0ull, tcs = ~0ull;
+      const u32 gtot = X.node_view.gtot;
+      bmask = 0; amask = 0;
+      ac = ~0ull; tcs = ~0ull;
       u32 ar = 0xFFu, tr = 0xFFu;
 #pragma unroll
       for (int r = 0; r < NPL; ++r) {
         const u32 w = mw[r];
-        const bool b = possible & (((typeok >> (w >> 26)) & 1ull) != 0) & (((w >> 16) & 0x3FFu) < maxlen);
+        const bool b = possible & (((tyok >> (w >> 26)) & 1ull) != 0) & (((w >> 16) & 0x3FFu) < maxlen) &
+                       (((skip >> r) & 1u) == 0);
         bool a = b & (rc32 <= fcpu[r]) & (rm16 <= (w & 0xFFFFu));  // the entry at `now` is in every window
         if (has_gres) {
           u32 gr = gn[r];
@@ -1321,9 +1463,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         bmask |= (b ? 1u : 0u) << r;
         amask |= (a ? 1u : 0u) << r;
       }
-      u32 ap = ar == 0xFFu ? kNone : ((ar << 10) | t);
-      u32 tp = tr == 0xFFu ? kNone : ((tr << 10) | t);
-      if (excl_job) {  // exclusive: the node must be completely free now (necessary for :6251-6257)
+      ap = ar == 0xFFu ? kNone : ((ar << 10) | t);
+      tp = tr == 0xFFu ? kNone : ((tr << 10) | t);
+      if (X.flags & kJfExclusive) {  // exclusive: the node must be completely free now (necessary for :6251-6257)
         amask = 0;
 #pragma unroll
         for (int r = 0; r < NPL; ++r) {
@@ -1335,63 +1477,98 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         }
         lane_argmin(amask, ac, ap);
       }
-      if (J.flags & (kJfIncl | kJfExcl)) {  // included / excluded node lists (rare)
-        u32 lm = 0;
-#pragma unroll 1
-        for (int r = 0; r < NPL; ++r) {
-          if (!((bmask >> r) & 1u)) continue;
-          const u32 n = P.slot_node[qbeg + (u32)r * kScan + t];
-          bool okl = true;
-          if ((J.flags & kJfIncl) && !in_list(P.incl_nodes, J.incl_b, J.incl_e, n)) okl = false;
-          if ((J.flags & kJfExcl) && in_list(P.excl_nodes, J.excl_b, J.excl_e, n)) okl = false;
-          lm |= (okl ? 1u : 0u) << r;
-        }
+      if (X.flags & (kJfIncl | kJfExcl)) {  // included / excluded node lists (rare)
+        const u32 lm = list_mask(Pg, X.flags, X.incl_b, X.incl_e, X.excl_b, X.excl_e, bmask, qbeg + t, (u32)NPL);
         bmask &= lm;
         amask &= lm;
         lane_argmin(amask, ac, ap);
         lane_argmin(bmask, tcs, tp);
       }
+    };
 
-      // ---- round 0: publish both argmins ---------------------------------------------------------------
-      wave_argmin(ac, ap);
-      wave_argmin(tcs, tp);
-      if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; s_tc[wave] = tcs; s_tp[wave] = tp; }
-      PROF_T(s1);
-      PROF_ADDS(16, s0, s1);  // scanner: masks + argmins
-      __syncthreads();  // B1
-      u64 wc = s_wc[par][lane & (kWaves - 1)];
-      u32 wcode = s_wp[par][lane & (kWaves - 1)];
-      u64 tc = s_tc[lane & (kWaves - 1)];
-      u32 tcode = s_tp[lane & (kWaves - 1)];
-      reduce16(wc, wcode);
-      reduce16(tc, tcode);
-      par ^= 1;
+    u32 bmask = 0, amask = 0;
+    u64 ac = ~0ull, tcs = ~0ull;
+    u32 ap = kNone, tp = kNone;
+    // state carried from the previous iteration's pre-scan
+    u32 bmask_n = 0, amask_n = 0, skipm = 0;
+    bool pre_valid = false;  // the winners of this job came from the worker's merge of the pre-scan
+    u64 wc = ~0ull, tc = ~0ull;
+    u32 wcode = kNone, tcode = kNone;
+
+    for (u64 ji = jbeg; ji < jend; ++ji) {
+      PROF_T(s6);
+      const bool excl_job = (J.flags & kJfExclusive) != 0;
+      const u32 kk = J.k;
+      const bool general = J.general;
+      if (!pre_valid) {
+        // ---- full scan of this job, publish both argmins ------------------------------------------------
+        scan_job(J, typeok, 0u, bmask, amask, ac, ap, tcs, tp);
+        wave_argmin(ac, ap);
+        wave_argmin(tcs, tp);
+        if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; s_tc[wave] = tcs; s_tp[wave] = tp; }
+        wg_barrier();  // B1
+        wc = s_wc[par][lane & (kWaves - 1)];
+        wcode = s_wp[par][lane & (kWaves - 1)];
+        tc = s_tc[lane & (kWaves - 1)];
+        tcode = s_tp[lane & (kWaves - 1)];
+        reduce16(wc, wcode);
+        reduce16(tc, tcode);
+        par ^= 1;
+      } else {
+        // winners came from the worker; complete the pre-scanned candidate sets with the skipped nodes
+        // (their registers are up to date now) — only needed if this job goes beyond round 0
+        bmask = bmask_n; amask = amask_n;
+        if (__ballot(skipm != 0) != 0ull) {
+          u32 b2, a2, ap2, tp2;
+          u64 ac2, tcs2;
+          scan_job(J, typeok, ~skipm, b2, a2, ac2, ap2, tcs2, tp2);
+          bmask |= b2; amask |= a2;
+        }
+      }
       PROF_T(s2);
-      PROF_ADDS(17, s1, s2);  // scanner: B1 wait + cross-wave reduce
+      PROF_ADDS(17, s6, s2);  // scanner: scan / mask completion + B1
 
-      // while the worker examines the winner: prepare the next job (its record was fetched a job ago)
+      // ---- while the worker examines the winner: decode the next job and PRE-SCAN it ----------------------
+      // The only nodes this job can change (if it resolves in round 0, as ~99.9 % of single-node jobs do)
+      // are the two round-0 winners.  The next job's candidate sets and argmins are computed now over all
+      // OTHER nodes and published; after its commit the WORKER merges the winners' new state into them.
       JobCtx Jn = J;
       u64 typeok_n = typeok;
-      if (ji + 1 < jend) {
+      const bool have_next = ji + 1 < jend;
+      const bool spec_ok = !excl_job && !general && kk == 1;  // this job touches one node, a round-0 winner
+      skipm = 0;
+      if ((wcode & 1023u) == t && wcode != kNone) skipm |= 1u << (wcode >> 10);
+      if ((tcode & 1023u) == t && tcode != kNone) skipm |= 1u << (tcode >> 10);
+      if (have_next) {
         Jn = make_job(P, ji + 1, raw);
         typeok_n = type_ok_mask(P, Jn, tyl, lane);
         if (ji + 2 < jend) raw = fetch_job(P, ji + 2);
+        if (spec_ok) {
+          u64 pc, ptc;
+          u32 pp, ptp;
+          scan_job(Jn, typeok_n, skipm, bmask_n, amask_n, pc, pp, ptc, ptp);
+          wave_argmin(pc, pp);
+          wave_argmin(ptc, ptp);
+          if (lane == 0) { s_pc[wave] = pc; s_pp[wave] = pp; s_ptc[wave] = ptc; s_ptp[wave] = ptp; }
+        }
       }
       PROF_T(s3);
-      PROF_ADDS(18, s2, s3);  // scanner: next-job prep (hidden behind the worker)
+      PROF_ADDS(18, s2, s3);  // scanner: next-job prep + pre-scan (hidden behind the worker)
 
       int verdict = 0;
       u32 used = 0;
+      bool round0 = true;  // resolved without a second scan round
       // ---- Phase A ----------------------------------------------------------------------------------
       while (wcode != kNone) {
         if ((wcode & 1023u) == t) used |= 1u << (wcode >> 10);
-        __syncthreads();  // B2
+        wg_barrier();  // B2
         verdict = s_flag;
         if (verdict == 2) break;
+        round0 = false;
         lane_argmin(amask & ~used, ac, ap);
         wave_argmin(ac, ap);
         if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; }
-        __syncthreads();  // B1
+        wg_barrier();  // B1
         wc = s_wc[par][lane & (kWaves - 1)];
         wcode = s_wp[par][lane & (kWaves - 1)];
         reduce16(wc, wcode);
@@ -1408,24 +1585,26 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             if (!general) {
               if (++nsel == kk) break;
             } else {
-              __syncthreads();  // B2 (ntasks > node_num only)
+              wg_barrier();  // B2 (ntasks > node_num only)
               if (s_flag == 1) break;
             }
             lane_argmin(bmask & ~used, tcs, tp);
             wave_argmin(tcs, tp);
             if (lane == 0) { s_wc[par][wave] = tcs; s_wp[par][wave] = tp; }
-            __syncthreads();  // B1
+            wg_barrier();  // B1
             u64 cc = s_wc[par][lane & (kWaves - 1)];
             ccode = s_wp[par][lane & (kWaves - 1)];
             reduce16(cc, ccode);
             par ^= 1;
           }
         }
-        __syncthreads();  // B3: worker finished backfill + commit (or gave up)
+        wg_barrier();  // B3: worker finished backfill + commit (or gave up)
         verdict = s_flag;
       }
       PROF_T(s4);
       PROF_ADDS(19, s3, s4);  // scanner: waiting for the worker's verdict
+      // a single-node job whose time map was longer than one chunk is committed out of line: rescan
+      if (s_r0 == 0) round0 = false;  // the worker left its inline path (long time map): rescan
       // ---- owners refresh their registers ---------------------------------------------------------------
       if (verdict == 2) {
         const int nu = s_nupd;
@@ -1450,10 +1629,17 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           }
         }
       }
-      J = Jn;
-      typeok = typeok_n;
       PROF_T(s5);
       PROF_ADDS(20, s4, s5);  // scanner: owner update
+      pre_valid = have_next && spec_ok && round0 && !(Jn.flags & (kJfExclusive | kJfIncl | kJfExcl));
+      if (pre_valid) {
+        wg_barrier();  // B1': the worker merged the winners into the pre-scan
+        wc = s_win_c[0]; wcode = s_win_p[0]; tc = s_win_c[1]; tcode = s_win_p[1];
+      }
+      J = Jn;
+      typeok = typeok_n;
+      PROF_T(s7);
+      PROF_ADDS(21, s5, s7);  // scanner: wait for the worker's merge
     }
   }
 }

@@ -19,12 +19,12 @@ t = e.timing(); pr = e.prof().astype(np.float64)
 jobs = j.num_jobs / c.num_partitions
 print(f"{name} J={j.num_jobs} N={c.num_nodes} P={c.num_partitions}: k_select {t['select_ms']:.1f} ms = "
       f"{1e3*t['select_ms']/jobs:.2f} us/job/partition")
-names = {0: "W decode+wait scanners(B1)", 1: "W node block load", 2: "W window-min+feasible", 3: "W commit(now)",
+names = {0: "W wait scanners (B1, no pre-scan)", 7: "W next-job decode + merge", 1: "W node block load", 2: "W window-min+feasible", 3: "W commit(now)",
          4: "W backfill+commit", 5: "W slow-path job", 6: "W multi-node job", 11: "#fast start-now",
-         12: "#fast backfill", 13: "#slow jobs", 14: "#rejected candidates", 15: "#multi-node jobs", 16: "S masks+argmin", 17: "S B1 wait+reduce", 18: "S next-job prep",
-         19: "S wait verdict", 20: "S owner update"}
+         12: "#fast backfill", 13: "#slow jobs", 14: "#rejected candidates", 15: "#multi-node jobs", 17: "S scan/mask completion (+B1)", 18: "S next-job prep+pre-scan",
+         19: "S wait verdict", 20: "S owner update", 21: "S wait worker merge (B1')"}
 m = pr.mean(axis=0)
-tot_w = m[[0, 1, 2, 3, 4, 5, 6]].sum(); tot_s = m[[16, 17, 18, 19, 20]].sum()
+tot_w = m[[0, 1, 2, 3, 4, 5, 6, 7]].sum(); tot_s = m[[17, 18, 19, 20, 21]].sum()
 for k, v in names.items():
     if k in (11, 12, 13, 14, 15):
         print(f"  {v:32s} {m[k]:12.0f}")
