@@ -1099,6 +1099,81 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
   return par;
 }
 
+// ---- multi-node jobs: candidate i of the selection is verified / committed by ONE wave, all candidates in
+// parallel on the scanner waves ("helpers").  H[i] carries (cost, slot code) in, (node, allocation, ok) out.
+__device__ __noinline__ void helper_verify(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, u32 qbeg) {
+  const u32 lane = threadIdx.x & 63u;
+  const JobCtx J = *Jp;
+  const u32 code = H[i].p;
+  NodeHdr* hd; NodeHdr h; TlEntry e;
+  load_block(P, qbeg + slot_of_code(code), lane, hd, h, e);
+  Res f = res_zero(), m;
+  bool ok = false;
+  if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
+                      class_counts(h.avail0.gres, P.gres), P.gres)) {                          // :6274
+    m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
+                            : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));              // :6278-6283
+    ok = feasible(J.min_view, m, f, P.gres);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
+  }
+  if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
+}
+__device__ __noinline__ void helper_commit(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, u32 qbeg, i64 start,
+                                           UpdRec* upd) {
+  const u32 lane = threadIdx.x & 63u;
+  const JobCtx J = *Jp;
+  const HeapEnt x = H[i];
+  commit_pick(P, J, x, i, qbeg, start, lane, upd, J.orig);
+  if (lane == 0) {  // placement record, ascending node index
+    u32 rank = 0;
+    for (u32 m = 0; m < J.k; ++m) rank += H[m].node < x.node ? 1u : 0u;
+    const u64 o = J.poff + rank;
+    P.o_node[o] = x.node; P.o_ntasks[o] = 1;
+    P.o_cpu[o] = x.res.cpu; P.o_mem[o] = x.res.mem; P.o_clo[o] = x.res.clo; P.o_chi[o] = x.res.chi;
+    P.o_gres[o] = x.res.gres;
+  }
+}
+// Phase B of a multi-node job on the worker: allocations against res_total, earliest common start
+// (fixed point over the k nodes), pending reason.  Returns the start time or kInf.
+__device__ __noinline__ i64 multi_backfill(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 qbeg, int* reason_out) {
+  const u32 lane = threadIdx.x & 63u;
+  const JobCtx J = *Jp;
+  drain_stores();
+  bool bad = false, notle = false;
+  if (lane < J.k) {  // allocation against res_total (:6353-6361)
+    HeapEnt x = H[lane];
+    const NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
+    x.node = hd->node;
+    x.ntasks = 1;
+    Res a = res_zero();
+    if (!feasible(J.min_view, hd->total, a, P.gres)) bad = true;
+    x.res = a;
+    notle = !res_le(a, hd->avail0);
+    H[lane] = x;
+  }
+  if (__any(bad) && lane == 0) set_fault(P, 3, J.orig, 0, 2);
+  notle = __any(notle);
+  __threadfence_block();
+  i64 t = P.now;
+  bool found = false;
+  for (u32 iter = 0; iter < (1u << 20); ++iter) {
+    i64 Tm = t;
+    for (u32 i = 0; i < J.k; ++i) {
+      const HeapEnt x = H[i];
+      NodeHdr* hd; NodeHdr h; TlEntry e;
+      load_block(P, qbeg + slot_of_code(x.p), lane, hd, h, e);
+      i64 sx;
+      if (h.len <= 64) sx = next_fit_regs(e, h.len, x.res, J.L, t, lane);
+      else { u32 j = 0; sx = next_fit(tl_of(hd), h.len, x.res, J.L, t, j); }
+      Tm = sx > Tm ? sx : Tm;
+    }
+    if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
+    if (Tm == t) { found = true; break; }
+    t = Tm;
+  }
+  *reason_out = (found && t != P.now) ? (notle ? 2 : 1) : 0;  // :6810-6831
+  return found ? t : kInf;
+}
+
 // included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
 // whose bit is set in bmask; out of line: rare, and it touches no tile register.
 __device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 incl_b, u64 incl_e, u64 excl_b, u64 excl_e,
@@ -1153,8 +1228,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ u32 s_pp[kWaves];   // cannot change (everything but this job's round-0 winners)
   __shared__ u64 s_ptc[kWaves];
   __shared__ u32 s_ptp[kWaves];
+  __shared__ u64 s_tyok_n;       // res_total-fits mask per node type for the next job (from the scanners)
   __shared__ u64 s_win_c[2];     // winners of the next job as merged by the worker: [0] = A, [1] = T
   __shared__ u32 s_win_p[2];
+  __shared__ i64 s_start;  // multi-node backfill: the common start time found by the worker
   __shared__ int s_flag;
   __shared__ int s_r0;   // worker -> scanners: this job may be followed by the worker-side merge
   __shared__ int s_nupd;
@@ -1186,6 +1263,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     WorkerShared sh;
     sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap;
     HeapEnt* const gheap = P.heap + qbeg + part;
+    // The worker is the serial chain of the whole partition and shares its SIMD with three scanner waves
+    // that pre-scan the next job at the same time: let its instructions issue first.
+    __builtin_amdgcn_s_setprio(3);
     if (lane == 0) { s_pc[0] = ~0ull; s_pp[0] = kNone; s_ptc[0] = ~0ull; s_ptp[0] = kNone; }
     u32 raw = fetch_job(P, jbeg);       // record of the job being processed
     u32 raw_n = jbeg + 1 < jend ? fetch_job(P, jbeg + 1) : 0u;  // next job's record: in flight during this job
@@ -1319,7 +1399,62 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         job_to_lds(PG, ji, raw, &s_job);
         PROF_T(d0);
         if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1) {
-          par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
+          // ---- multi-node job, parallel protocol: selection-only rounds among the scanners (no exact test
+          // in between), then the k candidates are verified and committed in parallel by the scanner waves
+          bool fallback = false;
+          u32 ncand = 0;
+          u64 cc = wc;
+          u32 ccode = wcode;
+          while (ccode != kNone) {   // mirror of the scanners' selection rounds
+            if (++ncand == F.k) break;
+            wg_barrier();
+            cc = s_wc[par][lane & (kWaves - 1)];
+            ccode = s_wp[par][lane & (kWaves - 1)];
+            reduce16(cc, ccode);
+            par ^= 1;
+            ccode = uni32(ccode);
+          }
+          if (ncand == F.k) {  // k start-now candidates exist: exact tests run on the helpers
+            wg_barrier();  // Bv1: candidate list complete
+            wg_barrier();  // Bv2: verdicts in
+            u32 nok = 0;
+            for (u32 i = 0; i < F.k; ++i) nok += s_heap[i].ntasks != 0 ? 1u : 0u;
+            if (nok == F.k) {  // :6294-6297 reached with the first k nodes in cost order: start now (:6326)
+              if (lane == 0) { s_nupd = (int)F.k; P.o_start[F.orig] = P.now; P.o_reason[F.orig] = 0; }
+              wg_barrier();  // Bc: helpers committed
+            } else {
+              fallback = true;  // a candidate failed its exact test (rare): redo this job sequentially
+            }
+          } else {  // fewer than k nodes can start it now -> top-k by res_total + backfill (:6335-6376)
+            u32 nt = 0;
+            cc = tc;
+            ccode = tcode;
+            while (ccode != kNone) {
+              if (++nt == F.k) break;
+              wg_barrier();
+              cc = s_wc[par][lane & (kWaves - 1)];
+              ccode = s_wp[par][lane & (kWaves - 1)];
+              reduce16(cc, ccode);
+              par ^= 1;
+              ccode = uni32(ccode);
+            }
+            if (nt == F.k) {
+              wg_barrier();  // Bt1: the k nodes are listed
+              int reason = 0;
+              const i64 st = multi_backfill(PG, &s_job, s_heap, qbeg, &reason);
+              const int code = st != kInf ? 2 : 0;
+              if (lane == 0) {
+                s_flag = code; s_start = st; s_nupd = (int)F.k;
+                if (code == 2) { P.o_start[F.orig] = st; P.o_reason[F.orig] = (uint8_t)reason; }
+                else { P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2; }  // "Resource", :6768
+              }
+              wg_barrier();  // Bt2: decision + allocations visible
+              if (code == 2) wg_barrier();  // Bt3: helpers committed
+            } else if (lane == 0) {
+              P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2;  // not even k nodes fit res_total (:6335-6343)
+            }
+          }
+          if (fallback) par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
           PROF_T(p8);
           PROF_ADD(6, d0, p8);
           PROF_CNT(15);
@@ -1348,7 +1483,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         reduce16(ac, ap);
         reduce16(tcs, tp);
         ac = uni64(ac); ap = uni32(ap); tcs = uni64(tcs); tp = uni32(tp);
-        const u64 tyok = type_ok_mask(P, Fn.mv, tyl, lane);
+        const u64 tyok = s_tyok_n;
         bool b, a;
         eval_node(P, Fn.mv, Fn.flags, tyok, cn, b, a);
         if (a && (cn.cost < ac || (cn.cost == ac && cn.code < ap))) { ac = cn.cost; ap = cn.code; }
@@ -1550,6 +1685,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           wave_argmin(pc, pp);
           wave_argmin(ptc, ptp);
           if (lane == 0) { s_pc[wave] = pc; s_pp[wave] = pp; s_ptc[wave] = ptc; s_ptp[wave] = ptp; }
+          if (tid == 64) s_tyok_n = typeok_n;
         }
       }
       PROF_T(s3);
@@ -1558,8 +1694,82 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       int verdict = 0;
       u32 used = 0;
       bool round0 = true;  // resolved without a second scan round
+      bool sequential = true;  // run the one-candidate-per-round protocol below
+      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMaxUpd && J.tmin == 1) {
+        // ---- multi-node job, parallel protocol (mirror of the worker's): selection-only rounds, then this
+        // wave verifies / commits candidates i = wave-1, wave-1+15, ... as a helper ---------------------------
+        sequential = false;
+        round0 = false;
+        u32 ncand = 0;
+        u64 cc = wc;
+        u32 ccode = wcode;
+        while (ccode != kNone) {
+          if (tid == 64) {
+            HeapEnt x; x.ntasks = 0; x.p = ccode; x.node = 0; x.pad = 0;
+            x.cost = __longlong_as_double((long long)cc); x.res = res_zero();
+            s_heap[ncand] = x;
+          }
+          if ((ccode & 1023u) == t) used |= 1u << (ccode >> 10);
+          if (++ncand == kk) break;
+          lane_argmin(amask & ~used, ac, ap);
+          wave_argmin(ac, ap);
+          if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; }
+          wg_barrier();
+          cc = s_wc[par][lane & (kWaves - 1)];
+          ccode = s_wp[par][lane & (kWaves - 1)];
+          reduce16(cc, ccode);
+          par ^= 1;
+        }
+        if (ncand == kk) {
+          wg_barrier();  // Bv1
+          for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_verify(PG, &s_job, s_heap, i, qbeg);
+          wg_barrier();  // Bv2
+          u32 nok = 0;
+          for (u32 i = 0; i < kk; ++i) nok += s_heap[i].ntasks != 0 ? 1u : 0u;
+          if (nok == kk) {
+            for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_commit(PG, &s_job, s_heap, i, qbeg, P.now, s_upd);
+            wg_barrier();  // Bc
+            verdict = 2;
+          } else {
+            sequential = true;  // rare: fall back to the sequential protocol from round 0
+            used = 0;
+          }
+        } else {
+          u32 nt = 0;
+          used = 0;
+          cc = tc;
+          ccode = tcode;
+          while (ccode != kNone) {
+            if (tid == 64) {
+              HeapEnt x; x.ntasks = 1; x.p = ccode; x.node = 0; x.pad = 0;
+              x.cost = __longlong_as_double((long long)cc); x.res = res_zero();
+              s_heap[nt] = x;
+            }
+            if ((ccode & 1023u) == t) used |= 1u << (ccode >> 10);
+            if (++nt == kk) break;
+            lane_argmin(bmask & ~used, tcs, tp);
+            wave_argmin(tcs, tp);
+            if (lane == 0) { s_wc[par][wave] = tcs; s_wp[par][wave] = tp; }
+            wg_barrier();
+            cc = s_wc[par][lane & (kWaves - 1)];
+            ccode = s_wp[par][lane & (kWaves - 1)];
+            reduce16(cc, ccode);
+            par ^= 1;
+          }
+          if (nt == kk) {
+            wg_barrier();  // Bt1
+            wg_barrier();  // Bt2: the worker's backfill decision
+            if (s_flag == 2) {
+              const i64 st = s_start;
+              for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_commit(PG, &s_job, s_heap, i, qbeg, st, s_upd);
+              wg_barrier();  // Bt3
+              verdict = 2;
+            }
+          }
+        }
+      }
       // ---- Phase A ----------------------------------------------------------------------------------
-      while (wcode != kNone) {
+      while (sequential && wcode != kNone) {
         if ((wcode & 1023u) == t) used |= 1u << (wcode >> 10);
         wg_barrier();  // B2
         verdict = s_flag;
@@ -1575,7 +1785,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         par ^= 1;
       }
       // ---- Phase B ----------------------------------------------------------------------------------
-      if (verdict != 2) {
+      if (sequential && verdict != 2) {
         if (!(!excl_job && !general && kk == 1)) {  // the single-node case needs no further scan
           used = 0;
           u32 nsel = 0;
