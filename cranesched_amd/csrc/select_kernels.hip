@@ -540,6 +540,55 @@ __device__ __noinline__ i64 next_fit(const TlEntry* T, u32 len, const Res& alloc
   }
 }
 
+// Wave-parallel form for time maps of any length: 64 entries per step, "alloc fits" ballot per chunk, run
+// state (inside a satisfied run? its start) carried across chunks.  All lanes return the same value.
+__device__ __noinline__ i64 next_fit_wave(const TlEntry* T, u32 len, const Res* alloc_p, i64 L, i64 t0) {
+  const u32 lane = threadIdx.x & 63u;
+  const Res alloc = *alloc_p;
+  bool in_run = false;
+  i64 s = t0;
+  for (u32 base = 0; base < len; base += 64) {
+    const u32 i = base + lane;
+    const bool act = i < len;
+    TlEntry e;
+    e.t = kInf;
+    e.r = res_zero();
+    if (act) e = T[i];
+    const u32 n = len - base < 64 ? len - base : 64;
+    const u64 valid = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+    const u64 sat = __ballot(act && res_le(alloc, e.r));
+    // The first relevant entry is the one covering t0 = the last entry with t <= t0 (T[0].t = now <= t0).
+    const u32 c = (u32)__popcll(__ballot(act && e.t <= t0));
+    u32 pos = 0;  // first bit of this chunk still to be looked at
+    if (c != 0) {
+      if (c == n && base + 64 < len && T[base + 64].t <= t0) continue;  // the covering entry is further on
+      pos = c - 1;
+    }
+    while (pos < n) {
+      const u64 from = ~0ull << pos;
+      if (!in_run) {
+        const u64 cand = sat & valid & from;
+        if (cand == 0) break;
+        const u32 ns = (u32)__builtin_ctzll(cand);
+        const i64 tn = (i64)rl64((u64)e.t, ns);
+        s = tn > t0 ? tn : t0;
+        in_run = true;
+        pos = ns + 1;
+      } else {
+        const u64 un = ~sat & valid & from;
+        if (un == 0) break;
+        const u32 ue = (u32)__builtin_ctzll(un);
+        const i64 endt = (i64)rl64((u64)e.t, ue);
+        if (endt - s >= L) return s;   // kth_time + time_limit <= next flip (JobScheduler.h:837-839)
+        in_run = false;
+        pos = ue + 1;
+      }
+    }
+    if (in_run && (i64)rl64((u64)e.t, n - 1) - s >= L) return s;  // the run already covers [s, s + L)
+  }
+  return in_run ? s : kInf;  // satisfied through the last entry ("ReachEnd"), or never
+}
+
 // Same question for ONE node whose map sits in registers (lane i = entry i, len <= 64), answered with
 // a ballot of "alloc fits entry i" and bit scans over its runs.
 __device__ __forceinline__ i64 next_fit_regs(const TlEntry& e, u32 len, const Res& alloc, i64 L, i64 t0, u32 lane) {
@@ -892,15 +941,12 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     bool found = false;
     for (u32 iter = 0; iter < (1u << 22); ++iter) {
       i64 Tm = t;
-      for (u32 i = lane; i < J.k; i += 64) {
+      for (u32 i = 0; i < J.k; ++i) {
         const HeapEnt x = H[i];
         NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
-        u32 j = P.bf_j[qbeg + i];
-        i64 s = next_fit(tl_of(hd), hd->len, x.res, J.L, t, j);
-        P.bf_j[qbeg + i] = j;
-        Tm = s > Tm ? s : Tm;
+        const i64 sx = next_fit_wave(tl_of(hd), hd->len, &H[i].res, J.L, t);
+        Tm = sx > Tm ? sx : Tm;
       }
-      Tm = wave_max_i64(Tm);
       if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
       if (Tm == t) { found = true; break; }
       t = Tm;
@@ -1077,7 +1123,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
         load_block(P, qbeg + slot_of_code(x.p), lane, hd, h, e);
         i64 s;
         if (h.len <= 64) s = next_fit_regs(e, h.len, x.res, J.L, t, lane);
-        else { u32 j = 0; s = next_fit(tl_of(hd), h.len, x.res, J.L, t, j); }
+        else s = next_fit_wave(tl_of(hd), h.len, &x.res, J.L, t);
         Tm = s > Tm ? s : Tm;
       }
       if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
@@ -1163,7 +1209,7 @@ __device__ __noinline__ i64 multi_backfill(const KParams& P, const JobCtx* Jp, H
       load_block(P, qbeg + slot_of_code(x.p), lane, hd, h, e);
       i64 sx;
       if (h.len <= 64) sx = next_fit_regs(e, h.len, x.res, J.L, t, lane);
-      else { u32 j = 0; sx = next_fit(tl_of(hd), h.len, x.res, J.L, t, j); }
+      else sx = next_fit_wave(tl_of(hd), h.len, &x.res, J.L, t);
       Tm = sx > Tm ? sx : Tm;
     }
     if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815

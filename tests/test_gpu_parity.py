@@ -63,3 +63,18 @@ def test_tile_widths(engine_cls, N):
     # every register-tile width (nodes per scanner lane 1,2,3,5,9,18)
     c, j, now = synth.make_config("C3", J=3000, N=(N // 4) * 4, P=1)
     _run(engine_cls, c, j, now, tag=f"tile N={N}")
+
+
+@pytest.mark.parametrize("name,J,N", [("C2", 5000, 16), ("C3", 4000, 24), ("C2", 14000, 8)])
+def test_deep_backfill_long_time_maps(engine_cls, name, J, N):
+    # few nodes, many jobs: time maps grow far beyond one 64-entry chunk (up to the 1000-entry limit),
+    # which exercises the chunked window-min / commit / earliest-start routines and the :6194 cut-off
+    c, j, now = synth.make_config(name, J=J, N=N, P=1)
+    got, _ = _run(engine_cls, c, j, now, tag=f"deep {name}")
+    r = got.reason[:J]
+    assert (r == 1).sum() > J // 2
+
+
+def test_deep_backfill_heterogeneous(engine_cls):
+    c, j, now, run = helpers.random_case(11, N=10, J=2500, P=1, running=6)
+    _run(engine_cls, c, j, now, running=run, tag="deep hetero")
