@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -119,6 +120,10 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.num_nodes = h->N; K.num_parts = h->P; K.num_slots = h->S; K.num_types = h->T;
   K.tl_cap = kTlCap;
   K.max_jobs_per_node = h->cfg.max_job_num_per_node;
+  {
+    const char* bm = getenv("CNS_BATCH");  // experimental batch mode: needs a -DCNS_ENABLE_BATCH build and CNS_BATCH=1
+    K.batch_mode = (bm && bm[0] == '1') ? 1u : 0u;
+  }
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
   K.part_off = h->d_part_off.as<u32>();

@@ -35,6 +35,32 @@ constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * sizeof(TlEntry);
 
 constexpr u32 kJobRecDwords = 32;
 
+// ---- batch mode (frontier + deferred verification) ---------------------------------------------------
+constexpr int kFrPerWave = 16;                       // frontier entries proposed per scanner wave
+constexpr int kFrMax = (kWaves - 1) * kFrPerWave;    // 240 <= 4 per decider lane
+constexpr int kMaxDec = 60;                          // node decisions per batch (4 per helper wave)
+constexpr int kMaxBatchJobs = 48;
+constexpr u32 kBatchMaxK = 8;                        // node_num handled in a batch
+constexpr int kMaxDead = 16;                         // remembered request shapes with no start-now node left
+
+struct FrEnt {  // one frontier node as the decider sees it (the scanners' 5-dword summary + its slot code)
+  u64 cost;
+  u32 code;
+  int fcpu;
+  u32 mw, gn;
+};
+struct BDec {   // one (job, node) decision of a batch: filled by the decider, completed by its helper wave
+  u64 cost;     // fp64 cost bits of the node when it was chosen (the commit adds the job's delta to it)
+  u32 code, jrel, first, k, kind, ok;  // kind 0 = start now, 1 = backfill on the res_total winner
+  i64 start, L;
+  u64 poff;
+  u32 orig, node;
+  int reason;
+  u32 pad;
+  Res res;      // allocation on the node
+};
+struct DeadShape { i64 cpu; u64 mem; u64 gspec; u32 gtot; u32 pad; };
+
 struct UpdRec {  // what the owning scanner lane must refresh after a commit
   u32 p, len;
   double cost;
@@ -51,6 +77,7 @@ struct KParams {
   // ---- cluster -------------------------------------------------------------------------
   u32 num_nodes, num_parts, num_slots, num_types;
   u32 tl_cap, max_jobs_per_node;
+  u32 batch_mode, reserved1;
   i64 now, max_window;
   const u32* part_off;     // [P+1] slot range of each partition
   const u32* slot_node;    // [S]   dense node index of slot q (ascending inside a partition)

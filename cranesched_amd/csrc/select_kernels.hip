@@ -1220,22 +1220,6 @@ __device__ __noinline__ i64 multi_backfill(const KParams& P, const JobCtx* Jp, H
   return found ? t : kInf;
 }
 
-// included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
-// whose bit is set in bmask; out of line: rare, and it touches no tile register.
-__device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 incl_b, u64 incl_e, u64 excl_b, u64 excl_e,
-                                      u32 bmask, u32 slot0, u32 npl) {
-  u32 lm = 0;
-  for (u32 r = 0; r < npl; ++r) {
-    if (!((bmask >> r) & 1u)) continue;
-    const u32 n = Pp->slot_node[slot0 + r * kScan];
-    bool okl = true;
-    if ((flags & kJfIncl) && !in_list(Pp->incl_nodes, incl_b, incl_e, n)) okl = false;
-    if ((flags & kJfExcl) && in_list(Pp->excl_nodes, excl_b, excl_e, n)) okl = false;
-    lm |= (okl ? 1u : 0u) << r;
-  }
-  return lm;
-}
-
 // ---- scanner tile compression -----------------------------------------------------------------------
 // Per node the scanners keep 5 dwords: fp64 cost (exact), front cpu (exact i32) and two packed words
 //   mw = front mem in GiB rounded up (16 bit, saturating) | time-map length << 16 | node type << 26
@@ -1251,6 +1235,282 @@ __device__ __forceinline__ u32 nibbles_of(u64 cnt) {  // byte g -> nibble g, sat
   x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
   x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
   return (u32)x;
+}
+
+// =====================================================================================================
+// Batch mode.  Inside a partition job j+1 depends on job j only through the ONE node j committed on: its
+// cost rises (exactly predictable: += time_limit * cpu_req / cpu_total, no time map needed) and what is free
+// on it now shrinks.  The worker therefore decides a whole batch of jobs back to back from node SUMMARIES:
+//   frontier  F = every node whose (cost, index) key is <= theta (a prefix of the cost order), held in the
+//               decider's registers, 4 entries per lane; all other nodes have larger keys, so a candidate
+//               found in F is the true first candidate in cost order;
+//   decision    filter + argmin over F, then the chosen entry gets its predicted cost and a conservative
+//               predicted summary; it leaves F if its key passes theta;
+//   then the 15 scanner waves run the exact tests of all decisions in parallel and, for the longest prefix
+//   of jobs whose every test passed, the commits in parallel; the rest of the batch is discarded (nothing of
+//   it was written) and the first rejected job goes through the sequential protocol.
+// A batch stops BEFORE a job it cannot decide exactly: a node would be touched twice, no candidate is inside
+// F, the job is exclusive / has node lists / needs priority_queue semantics, or it needs a multi-node backfill.
+// "No node can start this request now" is remembered per request shape: availability at `now` only shrinks
+// during a cycle, so once the sequential protocol found no start-now candidate for a shape, later jobs of the
+// same shape go straight to the res_total winner + backfill (kind 1).
+// =====================================================================================================
+__device__ __forceinline__ bool key_le(u64 c, u32 p, u64 tc, u32 tp) { return c < tc || (c == tc && p <= tp); }
+
+__device__ __forceinline__ bool job_batchable(u32 flags, u32 k, u32 ntasks, u32 tmin) {
+  return !(flags & (kJfExclusive | kJfIncl | kJfExcl)) && ntasks == k && tmin == 1 && k >= 1 && k <= kBatchMaxK;
+}
+
+// exact test of one decision on a helper wave
+__device__ __noinline__ void batch_verify(const KParams& P, BDec* D, u32 d, u64 jfirst, u32 qbeg) {
+  const u32 lane = threadIdx.x & 63u;
+  const u32 code = D[d].code, kind = D[d].kind;
+  const u64 ji = jfirst + D[d].jrel;
+  const JobCtx J = make_job(P, ji, fetch_job(P, ji));
+  NodeHdr* hd; NodeHdr h; TlEntry e;
+  load_block(P, qbeg + slot_of_code(code), lane, hd, h, e);
+  Res f = res_zero(), m;
+  bool ok = false;
+  i64 start = P.now;
+  int reason = 0;
+  if (kind == 0) {
+    if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
+                        class_counts(h.avail0.gres, P.gres), P.gres)) {                          // :6274
+      m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
+                              : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));              // :6278-6283
+      ok = feasible(J.min_view, m, f, P.gres);                                                   // :6285
+    }
+  } else {
+    if (!feasible(J.min_view, h.total, f, P.gres)) { if (lane == 0) set_fault(P, 3, J.orig, h.node, 5); }  // :6354-6356
+    i64 st;
+    if (h.len <= 64) st = next_fit_regs(e, h.len, f, J.L, P.now, lane);
+    else st = next_fit_wave(tl_of(hd), h.len, &f, J.L, P.now);
+    ok = st != kInf && st - P.now <= P.max_window;                                              // JobScheduler.h:815
+    start = st;
+    if (ok && st != P.now) reason = res_le(f, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;      // :6810-6831
+  }
+  if (lane == 0) {
+    D[d].ok = ok ? 1u : 0u; D[d].start = start; D[d].reason = reason; D[d].res = f; D[d].node = h.node;
+    D[d].L = J.L; D[d].poff = J.poff; D[d].orig = J.orig;
+  }
+}
+
+// commit of one accepted decision on a helper wave (time map, cost, owner update, placement record)
+__device__ __noinline__ void batch_commit(const KParams& P, BDec* D, u32 d, u32 qbeg, UpdRec* upd) {
+  const u32 lane = threadIdx.x & 63u;
+  const BDec x = D[d];
+  const u32 q = qbeg + slot_of_code(x.code);
+  NodeHdr* hd; NodeHdr h; TlEntry e;
+  load_block(P, q, lane, hd, h, e);
+  const i64 end = x.start + x.L;
+  const Res e0 = rl_res(e.r, 0);
+  u32 newlen;
+  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, x.start, end, x.res, lane, x.orig);
+  else newlen = tl_commit(P, hd, x.start, end, x.res, lane, x.orig);
+  const double ratio = ((double)x.res.cpu / 256.0) / ((double)h.total.cpu / 256.0);
+  const double ncost = __longlong_as_double((long long)x.cost) + (double)(end - x.start) * ratio;
+  if (lane == 0) {
+    UpdRec u;
+    u.p = x.code; u.len = newlen; u.cost = ncost;
+    u.has_front = (x.start == P.now) ? 1u : 0u;
+    Res f = e0;
+    if (u.has_front) res_sub(f, x.res);
+    u.fcpu = clamp_cpu(f.cpu); u.fmem = mem_mib_ceil(f.mem); u.fcnt = class_counts(f.gres, P.gres); u.pad = 0;
+    P.cost[q] = ncost;
+    if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
+    upd[d] = u;
+    u32 rank = 0;  // placement record, ascending node index inside the job
+    for (u32 m = x.first; m < x.first + x.k; ++m) rank += D[m].node < x.node ? 1u : 0u;
+    const u64 o = x.poff + rank;
+    P.o_node[o] = x.node; P.o_ntasks[o] = 1;
+    P.o_cpu[o] = x.res.cpu; P.o_mem[o] = x.res.mem; P.o_clo[o] = x.res.clo; P.o_chi[o] = x.res.chi;
+    P.o_gres[o] = x.res.gres;
+    if (d == x.first) { P.o_start[x.orig] = x.start; P.o_reason[x.orig] = (uint8_t)x.reason; }
+  }
+}
+
+struct BatchShared {
+  FrEnt* fr;        // [kFrMax] frontier proposals of the scanner waves
+  u64* mth_c;       // [kWaves-1] key of each wave's last proposal (~0 = the wave listed all its nodes)
+  u32* mth_p;
+  BDec* dec;        // [kMaxDec]
+  DeadShape* dead;  // [kMaxDead]
+  int* ndead;
+  int* nb;          // jobs decided
+  int* nd;          // node decisions
+};
+
+#ifdef CNS_PROF
+#define BPROF(slot) do { if (lane == 0) P.prof[(size_t)blockIdx.x * 32 + (slot)] += 1; } while (0)
+#else
+#define BPROF(slot)
+#endif
+// The decider (wave 0): decides jobs ji.. from the frontier until a stop condition; writes sh.dec / nb / nd.
+__device__ __noinline__ void batch_decide(const KParams& P, const BatchShared sh, u64 ji, u64 jend, u32 qbeg) {
+  const u32 lane = threadIdx.x & 63u;
+  // per-type data: lane t holds type t
+  const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();
+  TypeLane tyl;
+  tyl.cpu = ttot.cpu; tyl.mem = ttot.mem; tyl.ncores = (u32)(popc64(ttot.clo) + popc64(ttot.chi));
+  tyl.cnt = class_counts(ttot.gres, P.gres);
+  // theta = the smallest "last proposal" key over the waves: every node with key <= theta was proposed
+  u64 thc = lane < (u32)(kWaves - 1) ? sh.mth_c[lane] : ~0ull;
+  u32 thp = lane < (u32)(kWaves - 1) ? sh.mth_p[lane] : ~0u;
+  wave_argmin(thc, thp);
+  // frontier entries: lane l holds proposals l, l+64, l+128, l+192
+  u64 fc[4];
+  u32 fp[4], fmw[4], fgn[4];
+  int fcpu[4];
+  i64 ftot[4];   // cpu_total of the entry's node type (for the cost prediction)
+  u32 fvalid = 0, fpend = 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const u32 idx = lane + 64u * (u32)e;
+    fc[e] = ~0ull; fp[e] = kNone; fmw[e] = 1023u << 16; fgn[e] = 0; fcpu[e] = 0;
+    if (idx < (u32)kFrMax) {
+      const FrEnt x = sh.fr[idx];
+      fc[e] = x.cost; fp[e] = x.code; fmw[e] = x.mw; fgn[e] = x.gn; fcpu[e] = x.fcpu;
+      if (x.code != kNone && key_le(x.cost, x.code, thc, thp)) fvalid |= 1u << e;
+    }
+    ftot[e] = __shfl(tyl.cpu, (int)(fmw[e] >> 26));
+  }
+  const u32 maxlen = P.max_jobs_per_node;
+  const u32 G8 = 0x80808080u;
+  u32 nme[kMaxNames], nmo[kMaxNames], name_classes[kMaxNames];
+#pragma unroll
+  for (int a = 0; a < kMaxNames; ++a) {
+    const u32 nb = (u32)((P.gres.name_bytes[a] & 0x0F0F0F0F0F0F0F0Full) != 0);
+    (void)nb;
+    u64 x = P.gres.name_bytes[a] & 0x0F0F0F0F0F0F0F0Full;   // byte g = 0x0F if class g belongs to name a
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    nme[a] = (u32)x & 0x0F0F0F0Fu;
+    nmo[a] = ((u32)x >> 4) & 0x0F0F0F0Fu;
+    name_classes[a] = (u32)__popcll(P.gres.name_bytes[a]) / 8u;
+  }
+  int nb = 0, nd = 0;
+  const int ndead = *sh.ndead;
+  u64 jj = ji;
+  while (jj < jend && nb < kMaxBatchJobs && nd + (int)kBatchMaxK <= kMaxDec) {
+    const u32 raw = fetch_job(P, jj);
+    const FastJob F = make_fast_job(P, raw);
+    if (!job_batchable(F.flags, F.k, F.ntasks, F.tmin) || req_impossible(F.mv)) { BPROF(24); break; }
+    const u64 tyok = type_ok_mask(P, F.mv, tyl, lane);
+    // is this request shape known to have no start-now node left?
+    bool dead = false;
+    for (int i = 0; i < ndead; ++i) {
+      const DeadShape ds = sh.dead[i];
+      dead = dead || (ds.cpu == F.mv.cpu && ds.mem == F.mv.mem && ds.gspec == F.mv.gspec && ds.gtot == F.mv.gtot);
+    }
+    if (dead && F.k != 1) { BPROF(25); break; }  // multi-node backfill needs the joint earliest start: sequential protocol
+    const u32 kind = dead ? 1u : 0u;
+    const bool has_gres = (F.flags & kJfGres) != 0;
+    const int rc32 = F.mv.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)F.mv.cpu;
+    const u32 rm16 = (F.mv.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(F.mv.mem >> 30);
+    const u32 rq = nibbles_of(F.mv.gspec);
+    const u32 rqe = rq & 0x0F0F0F0Fu, rqo = (rq >> 4) & 0x0F0F0F0Fu;
+    // candidate bits of this lane's entries for this job (same filters as the scanners' bmask / amask)
+    u32 cand = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const u32 w = fmw[e];
+      bool c = ((fvalid >> e) & 1u) && ((tyok >> (w >> 26)) & 1ull) != 0 && ((w >> 16) & 0x3FFu) < maxlen;
+      if (kind == 0) {
+        c = c && rc32 <= fcpu[e] && rm16 <= (w & 0xFFFFu);
+        if (c && has_gres) {
+          const u32 ce = fgn[e] & 0x0F0F0F0Fu, co = (fgn[e] >> 4) & 0x0F0F0F0Fu;
+          c = ((((ce | G8) - rqe) & G8) == G8) && ((((co | G8) - rqo) & G8) == G8);
+          for (int g = 0; g < kMaxNames; ++g) {
+            const u32 tot = (F.mv.gtot >> (8 * g)) & 0xFFu;
+            const u32 have = __builtin_amdgcn_sad_u8(ce & nme[g], 0u, __builtin_amdgcn_sad_u8(co & nmo[g], 0u, 0u));
+            if (tot && have < (tot > 15u ? 15u : tot)) c = false;
+          }
+        }
+      }
+      cand |= (c ? 1u : 0u) << e;
+    }
+    // the first k candidates in (cost, index) order
+    bool stop = false;
+    u32 taken = 0;
+    for (u32 pk = 0; pk < F.k; ++pk) {
+      u64 bc = ~0ull;
+      u32 bp = kNone;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool c = ((cand >> e) & 1u) && !((taken >> e) & 1u);
+        if (c && (fc[e] < bc || (fc[e] == bc && fp[e] < bp))) { bc = fc[e]; bp = fp[e]; }
+      }
+      wave_argmin(bc, bp);
+      if (bp == kNone) { stop = true; if (kind) BPROF(27); else if (pk) BPROF(28); else BPROF(26); break; }   // not inside the frontier: the sequential protocol decides
+      bool mine_pending = false;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (fp[e] == bp && ((fvalid >> e) & 1u)) { taken |= 1u << e; mine_pending = (fpend >> e) & 1u; }
+      if (__any(mine_pending)) { stop = true; BPROF(29); break; }  // the node was already touched in this batch
+      if (lane == 0) {
+        BDec x;
+        x.cost = bc; x.code = bp; x.jrel = (u32)nb; x.first = (u32)nd; x.k = F.k; x.kind = kind; x.ok = 0;
+        x.start = 0; x.L = F.L; x.poff = F.poff; x.orig = F.orig; x.node = 0; x.reason = 0; x.pad = 0;
+        x.res = res_zero();
+        sh.dec[nd + (int)pk] = x;
+      }
+    }
+    if (stop) break;
+    // predicted state of the chosen nodes after this job's commit
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!((taken >> e) & 1u)) continue;
+      // MinCpuTimeRatioFirst::UpdateCost (JobScheduler.h:47-53): alloc.cpu == the request's cpu
+      const double ratio = ((double)F.mv.cpu / 256.0) / ((double)ftot[e] / 256.0);
+      const double nc = __longlong_as_double((long long)fc[e]) + (double)F.L * ratio;
+      fc[e] = cost_key(nc);
+      fpend |= 1u << e;
+      if (kind == 0) {  // what is free now shrinks (conservatively: never below the true value)
+        fcpu[e] -= rc32;
+        u32 w = fmw[e];
+        const u32 m16 = w & 0xFFFFu;
+        const u32 sub = rm16 > m16 ? m16 : rm16;
+        fmw[e] = (w & ~0xFFFFu) | (m16 == 0xFFFFu ? m16 : m16 - sub);
+        if (has_gres) {  // per class: specified counts; a name's untyped remainder only if it has one class
+          u32 g = fgn[e];
+          for (int c = 0; c < kMaxClasses; ++c) {
+            u32 cur = (g >> (4 * c)) & 0xFu;
+            if (cur == 15u) continue;  // saturated: unknown true value
+            u32 dec = (u32)((F.mv.gspec >> (8 * c)) & 0xFFu);
+            const u32 a = (P.gres.class_name_packed >> (4 * c)) & 0xFu;
+            const u32 tot = (F.mv.gtot >> (8 * a)) & 0xFFu;
+            if (c < (int)P.gres.num_classes && name_classes[a] == 1u && tot > dec) dec = tot;
+            dec = dec > cur ? cur : dec;
+            g = (g & ~(0xFu << (4 * c))) | ((cur - dec) << (4 * c));
+          }
+          fgn[e] = g;
+        }
+      }
+      if (!key_le(fc[e], fp[e], thc, thp)) fvalid &= ~(1u << e);  // left the frontier
+    }
+    nd += (int)F.k;
+    ++nb;
+    ++jj;
+  }
+  if (jj >= jend) BPROF(30); else if (nb >= kMaxBatchJobs || nd + (int)kBatchMaxK > kMaxDec) BPROF(31);
+  if (lane == 0) { *sh.nb = nb; *sh.nd = nd; }
+}
+
+// included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
+// whose bit is set in bmask; out of line: rare, and it touches no tile register.
+__device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 incl_b, u64 incl_e, u64 excl_b, u64 excl_e,
+                                      u32 bmask, u32 slot0, u32 npl) {
+  u32 lm = 0;
+  for (u32 r = 0; r < npl; ++r) {
+    if (!((bmask >> r) & 1u)) continue;
+    const u32 n = Pp->slot_node[slot0 + r * kScan];
+    bool okl = true;
+    if ((flags & kJfIncl) && !in_list(Pp->incl_nodes, incl_b, incl_e, n)) okl = false;
+    if ((flags & kJfExcl) && in_list(Pp->excl_nodes, excl_b, excl_e, n)) okl = false;
+    lm |= (okl ? 1u : 0u) << r;
+  }
+  return lm;
 }
 
 template <int NPL>
@@ -1284,6 +1544,15 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ UpdRec s_upd[kMaxUpd];
   __shared__ HeapEnt s_heap[kLdsHeap];
   __shared__ JobCtx s_job;
+  // batch mode
+  __shared__ FrEnt s_fr[kFrMax];
+  __shared__ u64 s_mth_c[kWaves - 1];
+  __shared__ u32 s_mth_p[kWaves - 1];
+  __shared__ BDec s_dec[kMaxDec];
+  __shared__ UpdRec s_bupd[kMaxDec];
+  __shared__ DeadShape s_dead[kMaxDead];
+  __shared__ int s_ndead;
+  __shared__ int s_nb, s_nd;
   __shared__ int s_ty_cpu[CNS_MAX_NODE_TYPES_DEV];  // per node type: what "completely free" looks like
   __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
   __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
@@ -1318,8 +1587,52 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     bool pre_valid = false;   // winners of this job already known from the previous iteration's merge
     u64 wc = ~0ull, tc = ~0ull;
     u32 wcode = kNone, tcode = kNone;
-    for (u64 ji = jbeg; ji < jend; ++ji) {
+#ifdef CNS_ENABLE_BATCH
+    const bool bm = P.batch_mode != 0;
+#else
+    const bool bm = false;  // batch mode is compiled out by default: measured slower than the pipelined protocol
+#endif
+    BatchShared bsh;
+    bsh.fr = s_fr; bsh.mth_c = s_mth_c; bsh.mth_p = s_mth_p; bsh.dec = s_dec; bsh.dead = s_dead; bsh.ndead = &s_ndead;
+    bsh.nb = &s_nb; bsh.nd = &s_nd;
+    if (lane == 0) s_ndead = 0;
+    u64 ji = jbeg;
+    while (ji < jend) {
       PROF_T(p0);
+      if (bm) {
+        // ---- batch attempt: decide as many jobs as possible from the frontier, helpers test + commit them ----
+        raw = fetch_job(P, ji);
+        if (job_batchable(rl32(raw, kJrFlags), rl32(raw, kJrK), rl32(raw, kJrNtasks), rl32(raw, kJrTmin))) {
+          PROF_T(q0);
+          wg_barrier();  // R: the scanners proposed the frontier
+          batch_decide(PG, bsh, ji, jend, qbeg);
+          PROF_T(q1);
+          PROF_ADD(8, q0, q1);  // worker: frontier wait + deciding
+          wg_barrier();  // D: decisions listed
+          const int nd = s_nd;
+          u32 nacc = 0;
+          if (nd > 0) {
+            wg_barrier();  // V: exact tests done
+            for (int d = 0; d < nd;) {  // longest prefix of jobs whose every node passed
+              const u32 kk = s_dec[d].k;
+              bool okj = true;
+              for (u32 i = 0; i < kk; ++i) okj = okj && s_dec[d + (int)i].ok != 0;
+              if (!okj) break;
+              d += (int)kk;
+              ++nacc;
+            }
+            wg_barrier();  // C: commits done
+          }
+          PROF_T(q2);
+          PROF_ADD(9, q1, q2);  // worker: waiting for the helpers
+#ifdef CNS_PROF
+          if (lane == 0) { P.prof[(size_t)blockIdx.x * 32 + 22] += nacc; P.prof[(size_t)blockIdx.x * 32 + 23] += 1; }
+#endif
+          ji += nacc;
+          if (nacc) continue;
+        }
+        pre_valid = false;
+      }
       const FastJob F = make_fast_job(P, raw);
       const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
       const bool fast = simple && F.k == 1 && F.tmin == 1;
@@ -1337,6 +1650,21 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       }
       PROF_T(p1);
       PROF_ADD(0, p0, p1);  // worker: wait for the scanners (only when the pre-scan could not be used)
+      if (bm && wcode == kNone && job_batchable(F.flags, F.k, F.ntasks, F.tmin) && s_ndead < kMaxDead) {
+        // a full scan found no node that could start this request now: availability at `now` only shrinks
+        // within a cycle, so this request shape stays without start-now candidates (see batch mode)
+        const int nde = s_ndead;
+        bool known = false;
+        for (int i = 0; i < nde; ++i) {
+          const DeadShape ds = s_dead[i];
+          known = known || (ds.cpu == F.mv.cpu && ds.mem == F.mv.mem && ds.gspec == F.mv.gspec && ds.gtot == F.mv.gtot);
+        }
+        if (!known && lane == 0) {
+          DeadShape ds; ds.cpu = F.mv.cpu; ds.mem = F.mv.mem; ds.gspec = F.mv.gspec; ds.gtot = F.mv.gtot; ds.pad = 0;
+          s_dead[nde] = ds;
+          s_ndead = nde + 1;
+        }
+      }
 
       bool round0 = true;       // this job may be followed by the worker-side merge
       NodeSum cn, on;           // scan summaries after this job: the committed / examined node, the other winner
@@ -1347,7 +1675,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       if (fast) {
         // The T winner's summary is needed for the merge when this job commits on the A winner: fetch it
         // now, ahead of the commit's stores (gfx9 counts loads and stores on one in-order counter).
-        if (wcode != kNone && tcode != kNone && tcode != wcode) {
+        if (!bm && wcode != kNone && tcode != kNone && tcode != wcode) {
           drain_stores();  // its summary may have been stored by the previous job's commit
           const u32 qt = qbeg + slot_of_code(tcode);
           const NodeHdr* ht = hdr_of(P, qt);
@@ -1515,6 +1843,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       // ---- next job: if the scanners' pre-scan is usable, merge the (at most two) nodes this job could
       // have changed into it right here — the scanners are not on the critical path ------------------------
       PROF_T(m0);
+      if (bm) { ++ji; continue; }  // batch mode re-reads the queue position; no pre-scan pipeline
       if (ji + 1 >= jend) break;
       raw = raw_n;
       raw_n = ji + 2 < jend ? fetch_job(P, ji + 2) : 0u;
@@ -1544,6 +1873,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       PROF_T(m1);
       PROF_ADD(7, m0, m1);  // worker: next-job decode + merge
       pre_valid = nv;
+      ++ji;
     }
   } else {
     // =============================================================================================
@@ -1676,8 +2006,95 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     u64 wc = ~0ull, tc = ~0ull;
     u32 wcode = kNone, tcode = kNone;
 
-    for (u64 ji = jbeg; ji < jend; ++ji) {
+    // owner lanes refresh their registers from an update record
+    auto apply_upd = [&](const UpdRec& u) {
+      const int rr = (int)(u.p >> 10);
+#pragma unroll
+      for (int r = 0; r < NPL; ++r)
+        if (r == rr) {
+          cost[r] = u.cost;
+          u32 w = (mw[r] & ~(0x3FFu << 16)) | (u.len << 16);
+          if (u.has_front) {
+            fcpu[r] = u.fcpu;
+            w = (w & ~0xFFFFu) | mem_gib16(u.fmem);
+            gn[r] = nibbles_of(u.fcnt);
+          }
+          mw[r] = w;
+        }
+    };
+#ifdef CNS_ENABLE_BATCH
+    const bool bm = P.batch_mode != 0;
+#else
+    const bool bm = false;  // batch mode is compiled out by default: measured slower than the pipelined protocol
+#endif
+    u64 ji = jbeg;
+    while (ji < jend) {
       PROF_T(s6);
+      if (bm) {
+        raw = fetch_job(P, ji);
+        J = make_job(P, ji, raw);
+        typeok = type_ok_mask(P, J, tyl, lane);
+        if (job_batchable(J.flags, J.k, J.ntasks, J.tmin)) {
+          // ---- batch attempt.  Frontier proposal: this wave's kFrPerWave smallest (cost, index) keys with
+          // their summaries; theta = the smallest "last proposal" over the waves, so every node with a key
+          // <= theta is in some wave's list (a prefix of the global cost order).
+          u32 exist = 0;
+#pragma unroll
+          for (int r = 0; r < NPL; ++r) exist |= ((((mw[r] >> 16) & 0x3FFu) != 1023u) ? 1u : 0u) << r;
+          u32 listed = 0;
+          u64 lastc = ~0ull;
+          u32 lastp = kNone;
+          for (int i = 0; i < kFrPerWave; ++i) {
+            u64 c;
+            u32 code;
+            lane_argmin(exist & ~listed, c, code);
+            wave_argmin(c, code);
+            const u32 slot = (wave - 1) * kFrPerWave + (u32)i;
+            if (code != kNone && (code & 1023u) == t) {
+              const int rr = (int)(code >> 10);
+              FrEnt x;
+              x.cost = c; x.code = code; x.fcpu = 0; x.mw = 0; x.gn = 0;
+#pragma unroll
+              for (int r = 0; r < NPL; ++r)
+                if (r == rr) { x.fcpu = fcpu[r]; x.mw = mw[r]; x.gn = gn[r]; }
+              s_fr[slot] = x;
+              listed |= 1u << rr;
+            }
+            if (code == kNone && lane == 0) {
+              FrEnt x;
+              x.cost = ~0ull; x.code = kNone; x.fcpu = 0; x.mw = 1023u << 16; x.gn = 0;
+              s_fr[slot] = x;
+            }
+            lastc = c; lastp = code;
+          }
+          if (lane == 0) { s_mth_c[wave - 1] = lastp == kNone ? ~0ull : lastc; s_mth_p[wave - 1] = lastp == kNone ? ~0u : lastp; }
+          wg_barrier();  // R
+          wg_barrier();  // D: the worker decided
+          const int nd = s_nd;
+          u32 nacc = 0;
+          if (nd > 0) {
+            for (int d = (int)wave - 1; d < nd; d += kWaves - 1) batch_verify(PG, s_dec, (u32)d, ji, qbeg);
+            wg_barrier();  // V
+            int ndacc = 0;
+            for (int d = 0; d < nd;) {  // longest prefix of jobs whose every node passed
+              const u32 kkd = s_dec[d].k;
+              bool okj = true;
+              for (u32 i = 0; i < kkd; ++i) okj = okj && s_dec[d + (int)i].ok != 0;
+              if (!okj) break;
+              d += (int)kkd;
+              ndacc = d;
+              ++nacc;
+            }
+            for (int d = (int)wave - 1; d < ndacc; d += kWaves - 1) batch_commit(PG, s_dec, (u32)d, qbeg, s_bupd);
+            wg_barrier();  // C
+            for (int d = 0; d < ndacc; ++d)
+              if ((s_bupd[d].p & 1023u) == t) apply_upd(s_bupd[d]);
+          }
+          ji += nacc;
+          if (nacc) continue;
+        }
+        pre_valid = false;
+      }
       const bool excl_job = (J.flags & kJfExclusive) != 0;
       const u32 kk = J.k;
       const bool general = J.general;
@@ -1715,7 +2132,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       // OTHER nodes and published; after its commit the WORKER merges the winners' new state into them.
       JobCtx Jn = J;
       u64 typeok_n = typeok;
-      const bool have_next = ji + 1 < jend;
+      const bool have_next = !bm && ji + 1 < jend;
       const bool spec_ok = !excl_job && !general && kk == 1;  // this job touches one node, a round-0 winner
       skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= 1u << (wcode >> 10);
@@ -1867,22 +2284,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         const UpdRec* const ub = nu <= kMaxUpd ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
         for (int i = 0; i < nu; ++i) {
           const u32 up = ub[i].p;
-          if ((up & 1023u) == t) {
-            const UpdRec u = ub[i];
-            const int rr = (int)(up >> 10);
-#pragma unroll
-            for (int r = 0; r < NPL; ++r)
-              if (r == rr) {
-                cost[r] = u.cost;
-                u32 w = (mw[r] & ~(0x3FFu << 16)) | (u.len << 16);
-                if (u.has_front) {
-                  fcpu[r] = u.fcpu;
-                  w = (w & ~0xFFFFu) | mem_gib16(u.fmem);
-                  gn[r] = nibbles_of(u.fcnt);
-                }
-                mw[r] = w;
-              }
-          }
+          if ((up & 1023u) == t) apply_upd(ub[i]);
         }
       }
       PROF_T(s5);
@@ -1896,6 +2298,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       typeok = typeok_n;
       PROF_T(s7);
       PROF_ADDS(21, s5, s7);  // scanner: wait for the worker's merge
+      ++ji;
     }
   }
 }
