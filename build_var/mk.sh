@@ -1,0 +1,5 @@
+#!/bin/bash
+# usage: mk.sh name [extra -D flags]   (experiment build: NPL=9 only)
+n=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I../include -DCNS_ONLY_NPL9 \
+  "$@" ../cranesched_amd/csrc/engine.hip -o v_$n.so 2> v_$n.log && echo built $n

@@ -120,10 +120,6 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.num_nodes = h->N; K.num_parts = h->P; K.num_slots = h->S; K.num_types = h->T;
   K.tl_cap = kTlCap;
   K.max_jobs_per_node = h->cfg.max_job_num_per_node;
-  {
-    const char* bm = getenv("CNS_BATCH");  // experimental batch mode: needs a -DCNS_ENABLE_BATCH build and CNS_BATCH=1
-    K.batch_mode = (bm && bm[0] == '1') ? 1u : 0u;
-  }
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
   K.part_off = h->d_part_off.as<u32>();
@@ -408,7 +404,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   std::vector<u64> pj_off(h->P + 1, 0);
   for (u32 p = 0; p < h->P; ++p) pj_off[p + 1] = pj_off[p] + pj_cnt[p + 1];
   const u64 Jg = pj_off[h->P];
-  // 32-dword job records, grouped by partition in queue order (lane-striped fetch on the device)
+  // job records (host half: dwords 0..29 of 64), grouped by partition in queue order (lane-striped fetch on the device)
   std::vector<u32> stage((size_t)std::max<u64>(Jg, 1) * kJobRecDwords, 0);
   std::vector<u64> cur(pj_off.begin(), pj_off.end() - 1);
   std::vector<u32> incl, excl;
@@ -502,16 +498,22 @@ int cns_run_resident(cns_handle* h, int64_t now) {
   HIPCHK(h, h->d_params.ensure(sizeof(KParams)));
   HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
   if (h->S) hipLaunchKernelGGL(k_init_nodes, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_params.as<KParams>());
+  if (h->Jg) hipLaunchKernelGGL(k_prep_jobs, dim3((unsigned)((h->Jg + 255) / 256)), dim3(256), 0, h->stream, h->d_params.as<KParams>(), (u64)h->Jg);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   if (h->Jg) {
     const u32 np = h->max_np;
+#ifdef CNS_ONLY_NPL9   // experiment builds: one tile width only (partitions of <= 8640 nodes)
+    if (np > 8640) return fail(h, CNS_ERR_UNSUPPORTED, "experiment build: partition > 8640 nodes");
+    launch_select<9>(h, K);
+#else
     if (np <= 960) launch_select<1>(h, K);
     else if (np <= 1920) launch_select<2>(h, K);
     else if (np <= 2880) launch_select<3>(h, K);
     else if (np <= 4800) launch_select<5>(h, K);
     else if (np <= 8640) launch_select<9>(h, K);
     else launch_select<18>(h, K);
+#endif
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));

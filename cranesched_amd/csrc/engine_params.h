@@ -33,33 +33,11 @@ static_assert(sizeof(NodeHdr) == 96, "NodeHdr = 2 TlEntry slots");
 static_assert(sizeof(TlEntry) == 48, "TlEntry layout");
 constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * sizeof(TlEntry);
 
-constexpr u32 kJobRecDwords = 32;
+// Job record: 64 dwords, lane-striped (lane i of a wave loads dword i: one VGPR while in flight).
+// Dwords 0..29 are packed by the host (cns_upload_jobs); dwords 32.. are derived per cycle by the
+// job-parallel pre-pass k_prep_jobs, so that the sequential chain only reads them out with v_readlane.
+constexpr u32 kJobRecDwords = 64;
 
-// ---- batch mode (frontier + deferred verification) ---------------------------------------------------
-constexpr int kFrPerWave = 16;                       // frontier entries proposed per scanner wave
-constexpr int kFrMax = (kWaves - 1) * kFrPerWave;    // 240 <= 4 per decider lane
-constexpr int kMaxDec = 60;                          // node decisions per batch (4 per helper wave)
-constexpr int kMaxBatchJobs = 48;
-constexpr u32 kBatchMaxK = 8;                        // node_num handled in a batch
-constexpr int kMaxDead = 16;                         // remembered request shapes with no start-now node left
-
-struct FrEnt {  // one frontier node as the decider sees it (the scanners' 5-dword summary + its slot code)
-  u64 cost;
-  u32 code;
-  int fcpu;
-  u32 mw, gn;
-};
-struct BDec {   // one (job, node) decision of a batch: filled by the decider, completed by its helper wave
-  u64 cost;     // fp64 cost bits of the node when it was chosen (the commit adds the job's delta to it)
-  u32 code, jrel, first, k, kind, ok;  // kind 0 = start now, 1 = backfill on the res_total winner
-  i64 start, L;
-  u64 poff;
-  u32 orig, node;
-  int reason;
-  u32 pad;
-  Res res;      // allocation on the node
-};
-struct DeadShape { i64 cpu; u64 mem; u64 gspec; u32 gtot; u32 pad; };
 
 struct UpdRec {  // what the owning scanner lane must refresh after a commit
   u32 p, len;
@@ -77,7 +55,7 @@ struct KParams {
   // ---- cluster -------------------------------------------------------------------------
   u32 num_nodes, num_parts, num_slots, num_types;
   u32 tl_cap, max_jobs_per_node;
-  u32 batch_mode, reserved1;
+  u32 reserved0, reserved1;
   i64 now, max_window;
   const u32* part_off;     // [P+1] slot range of each partition
   const u32* slot_node;    // [S]   dense node index of slot q (ascending inside a partition)
@@ -96,7 +74,7 @@ struct KParams {
   const Res* rn_res;       // [A]
   // ---- jobs, grouped by partition: 32-dword records (JobRecField in select_kernels.hip) ---------
   const u64* pj_off;       // [P+1]
-  const u32* jobrec;       // [Jg * 32]
+  const u32* jobrec;       // [Jg * kJobRecDwords]
   const u32* incl_nodes;   // included_nodes lists, CSR by the record's incl_b / incl_e
   const u32* excl_nodes;
   // ---- results ---------------------------------------------------------------------------

@@ -25,6 +25,7 @@
 
 #include "engine_params.h"
 
+
 namespace cns {
 
 // ---------------------------------------------------------------------------------------------
@@ -127,6 +128,7 @@ __device__ __forceinline__ i64 wave_max_i64(i64 v) { return (i64)(wave_max_u64((
 __device__ __forceinline__ u64 wave_and_u64(u64 v) {
   return ((u64)wave_and32((u32)(v >> 32)) << 32) | wave_and32((u32)v);
 }
+__device__ __forceinline__ u64 wave_or_u64(u64 v) { return ~wave_and_u64(~v); }
 // lexicographic argmin of (cost key, code) over the wave: three cascaded 32-bit minima
 __device__ __forceinline__ void wave_argmin(u64& c, u32& p) {
   const u32 hi = (u32)(c >> 32), lo = (u32)c;
@@ -255,7 +257,18 @@ struct JobCtx {
 enum JobRecField : u32 {
   kJrL = 0, kJrNcpu = 2, kJrNmem = 4, kJrTcpu = 6, kJrTmem = 8, kJrGspec = 10, kJrK = 12, kJrNtasks = 13,
   kJrTmin = 14, kJrTmax = 15, kJrFlags = 16, kJrGtot = 17, kJrOrig = 18, kJrPoff = 20, kJrInclB = 22,
-  kJrInclE = 24, kJrExclB = 26, kJrExclE = 28
+  kJrInclE = 24, kJrExclB = 26, kJrExclE = 28,
+  // derived by k_prep_jobs
+  kJdMcpu = 32,   // minimum view = req_node + req_task * tpn_min (JobScheduler.cpp:6154-6156): cpu (i64)
+  kJdMmem = 34,   //                                                                               mem (u64)
+  kJdRc32 = 36,   // min-view cpu clamped to the scanners' 32-bit front summary
+  kJdRm16 = 37,   // min-view mem in GiB, rounded down, saturating at 0xFFFF
+  kJdRq = 38,     // specified GRES counts per class as nibbles, saturating at 15 (like the node side)
+  kJdShape = 39,  // bit 0: ntasks != node_num, bit 1: tpn_min == 1, bit 2: satisfiable under the 32-bit summaries
+  kJdGmode = 40,  // GRES request shape: 0 none; bit 0 one specified class, bit 1 one untyped total; 4 general
+  kJdGsel = 41,   // nibble shift of that class | index of that name << 8
+  kJdGneed = 42,  // its count | the total << 8, both saturated at 15
+  kJdTyok = 44    // u64: bit t = the minimum view fits res_total of node type t (:6171-6175, :6222-6223)
 };
 __device__ __forceinline__ u32 fetch_job(const KParams& P, u64 ji) {
   return P.jobrec[ji * kJobRecDwords + (threadIdx.x & (kJobRecDwords - 1))];
@@ -303,10 +316,8 @@ __device__ __forceinline__ FastJob make_fast_job(const KParams& P, u32 raw) {
   F.ntasks = rl32(raw, kJrNtasks);
   F.tmin = rl32(raw, kJrTmin);
   F.flags = rl32(raw, kJrFlags);
-  Req nv;
-  nv.cpu = (i64)jr64(raw, kJrNcpu); nv.mem = jr64(raw, kJrNmem);
-  nv.gtot = rl32(raw, kJrGtot); nv.gspec = jr64(raw, kJrGspec);
-  F.mv = compose(nv, (i64)jr64(raw, kJrTcpu), jr64(raw, kJrTmem), F.tmin);
+  F.mv.cpu = (i64)jr64(raw, kJdMcpu); F.mv.mem = jr64(raw, kJdMmem);  // composed by k_prep_jobs
+  F.mv.gtot = rl32(raw, kJrGtot); F.mv.gspec = jr64(raw, kJrGspec);
   F.orig = rl32(raw, kJrOrig);
   F.poff = jr64(raw, kJrPoff);
   return F;
@@ -361,6 +372,60 @@ __device__ __forceinline__ u64 type_ok_mask(const KParams& P, const Req& mv, con
 }
 __device__ __forceinline__ u64 type_ok_mask(const KParams& P, const JobCtx& J, const TypeLane& tl, u32 lane) {
   return type_ok_mask(P, J.min_view, tl, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_prep_jobs: job-parallel pre-pass (one thread per pending job of the cycle).  Everything about a job
+// that does not depend on the evolving node state is computed here, off the sequential chain: the
+// minimum view, the request side of the scanners' filters, the shape of the GRES request and the
+// "fits res_total" mask over the node types.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 nibbles_of(u64 cnt);
+__global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ Pp, u64 njobs) {
+  const KParams& P = *Pp;
+  const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= njobs) return;
+  u32* rec = const_cast<u32*>(P.jobrec) + i * kJobRecDwords;
+  auto g64 = [&](u32 f) { return ((u64)rec[f + 1] << 32) | rec[f]; };
+  Req nv;
+  nv.cpu = (i64)g64(kJrNcpu); nv.mem = g64(kJrNmem); nv.gtot = rec[kJrGtot]; nv.gspec = g64(kJrGspec);
+  const u32 k = rec[kJrK], ntasks = rec[kJrNtasks], tmin = rec[kJrTmin], flags = rec[kJrFlags];
+  const Req mv = compose(nv, (i64)g64(kJrTcpu), g64(kJrTmem), tmin);
+  const bool possible = !req_impossible(mv);
+  const u32 rq = nibbles_of(nv.gspec);
+  u32 gmode = 0, gsel = 0, gneed = 0;
+  if (flags & kJfGres) {
+    // most requests name ONE class ("gpu:a100:2") and / or ONE untyped total ("gpu:2"): those get a
+    // 3- / 8-instruction test per node in the scan instead of the general one
+    u32 nspec = 0, nname = 0, g0 = 0, a0 = 0;
+    for (u32 g = 0; g < 8; ++g)
+      if ((nv.gspec >> (8 * g)) & 0xFFull) { ++nspec; g0 = g; }
+    for (u32 a = 0; a < (u32)kMaxNames; ++a)
+      if ((nv.gtot >> (8 * a)) & 0xFFu) { ++nname; a0 = a; }
+    gmode = 4;
+    if (nspec <= 1 && nname <= 1) {
+      const u32 tot = (nv.gtot >> (8 * a0)) & 0xFFu, spec = (u32)((nv.gspec >> (8 * g0)) & 0xFFull);
+      gmode = (nspec ? 1u : 0u) | (nname ? 2u : 0u);
+      // a total that the specified class of the same name already covers adds nothing to the filter
+      if (gmode == 3 && ((P.gres.name_bytes[a0] >> (8 * g0)) & 0xFFull) != 0 && tot <= spec) gmode = 1;
+      gsel = (4 * g0) | (a0 << 8);
+      gneed = ((rq >> (4 * g0)) & 15u) | ((tot > 15u ? 15u : tot) << 8);
+    }
+  }
+  u64 tyok = 0;
+  for (u32 t = 0; t < P.num_types; ++t) {
+    const Res tt = P.type_total[t];
+    if (feasible_counts(mv, tt.cpu, tt.mem, (u32)(popc64(tt.clo) + popc64(tt.chi)), class_counts(tt.gres, P.gres), P.gres))
+      tyok |= 1ull << t;
+  }
+  rec[kJdMcpu] = (u32)(u64)mv.cpu; rec[kJdMcpu + 1] = (u32)((u64)mv.cpu >> 32);
+  rec[kJdMmem] = (u32)mv.mem; rec[kJdMmem + 1] = (u32)(mv.mem >> 32);
+  rec[kJdRc32] = (u32)(mv.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)mv.cpu);
+  rec[kJdRm16] = (mv.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(mv.mem >> 30);
+  rec[kJdRq] = rq;
+  rec[kJdShape] = (ntasks != k ? 1u : 0u) | (tmin == 1 ? 2u : 0u) | (possible ? 4u : 0u);
+  rec[kJdGmode] = gmode; rec[kJdGsel] = gsel; rec[kJdGneed] = gneed;
+  rec[kJdTyok] = (u32)tyok; rec[kJdTyok + 1] = (u32)(tyok >> 32);
 }
 
 constexpr u32 kScan = (kWaves - 1) * 64;  // 960 scanner lanes
@@ -1152,7 +1217,9 @@ __device__ __noinline__ void helper_verify(const KParams& P, const JobCtx* Jp, H
   const JobCtx J = *Jp;
   const u32 code = H[i].p;
   NodeHdr* hd; NodeHdr h; TlEntry e;
+  PROF_T(v0);
   load_block(P, qbeg + slot_of_code(code), lane, hd, h, e);
+  PROF_T(v1);
   Res f = res_zero(), m;
   bool ok = false;
   if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
@@ -1162,13 +1229,18 @@ __device__ __noinline__ void helper_verify(const KParams& P, const JobCtx* Jp, H
     ok = feasible(J.min_view, m, f, P.gres);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
   }
   if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
+  PROF_T(v2);
+  if (i == 0) { PROF_ADD(8, v0, v1); PROF_ADD(9, v1, v2); }  // helper of pick 0: block load / exact test
 }
 __device__ __noinline__ void helper_commit(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, u32 qbeg, i64 start,
                                            UpdRec* upd) {
   const u32 lane = threadIdx.x & 63u;
   const JobCtx J = *Jp;
   const HeapEnt x = H[i];
+  PROF_T(c0);
   commit_pick(P, J, x, i, qbeg, start, lane, upd, J.orig);
+  PROF_T(c1);
+  if (i == 0) PROF_ADD(10, c0, c1);  // helper of pick 0: block load + commit
   if (lane == 0) {  // placement record, ascending node index
     u32 rank = 0;
     for (u32 m = 0; m < J.k; ++m) rank += H[m].node < x.node ? 1u : 0u;
@@ -1236,271 +1308,23 @@ __device__ __forceinline__ u32 nibbles_of(u64 cnt) {  // byte g -> nibble g, sat
   x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
   return (u32)x;
 }
-
-// =====================================================================================================
-// Batch mode.  Inside a partition job j+1 depends on job j only through the ONE node j committed on: its
-// cost rises (exactly predictable: += time_limit * cpu_req / cpu_total, no time map needed) and what is free
-// on it now shrinks.  The worker therefore decides a whole batch of jobs back to back from node SUMMARIES:
-//   frontier  F = every node whose (cost, index) key is <= theta (a prefix of the cost order), held in the
-//               decider's registers, 4 entries per lane; all other nodes have larger keys, so a candidate
-//               found in F is the true first candidate in cost order;
-//   decision    filter + argmin over F, then the chosen entry gets its predicted cost and a conservative
-//               predicted summary; it leaves F if its key passes theta;
-//   then the 15 scanner waves run the exact tests of all decisions in parallel and, for the longest prefix
-//   of jobs whose every test passed, the commits in parallel; the rest of the batch is discarded (nothing of
-//   it was written) and the first rejected job goes through the sequential protocol.
-// A batch stops BEFORE a job it cannot decide exactly: a node would be touched twice, no candidate is inside
-// F, the job is exclusive / has node lists / needs priority_queue semantics, or it needs a multi-node backfill.
-// "No node can start this request now" is remembered per request shape: availability at `now` only shrinks
-// during a cycle, so once the sequential protocol found no start-now candidate for a shape, later jobs of the
-// same shape go straight to the res_total winner + backfill (kind 1).
-// =====================================================================================================
-__device__ __forceinline__ bool key_le(u64 c, u32 p, u64 tc, u32 tp) { return c < tc || (c == tc && p <= tp); }
-
-__device__ __forceinline__ bool job_batchable(u32 flags, u32 k, u32 ntasks, u32 tmin) {
-  return !(flags & (kJfExclusive | kJfIncl | kJfExcl)) && ntasks == k && tmin == 1 && k >= 1 && k <= kBatchMaxK;
-}
-
-// exact test of one decision on a helper wave
-__device__ __noinline__ void batch_verify(const KParams& P, BDec* D, u32 d, u64 jfirst, u32 qbeg) {
-  const u32 lane = threadIdx.x & 63u;
-  const u32 code = D[d].code, kind = D[d].kind;
-  const u64 ji = jfirst + D[d].jrel;
-  const JobCtx J = make_job(P, ji, fetch_job(P, ji));
-  NodeHdr* hd; NodeHdr h; TlEntry e;
-  load_block(P, qbeg + slot_of_code(code), lane, hd, h, e);
-  Res f = res_zero(), m;
-  bool ok = false;
-  i64 start = P.now;
-  int reason = 0;
-  if (kind == 0) {
-    if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                        class_counts(h.avail0.gres, P.gres), P.gres)) {                          // :6274
-      m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
-                              : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));              // :6278-6283
-      ok = feasible(J.min_view, m, f, P.gres);                                                   // :6285
-    }
-  } else {
-    if (!feasible(J.min_view, h.total, f, P.gres)) { if (lane == 0) set_fault(P, 3, J.orig, h.node, 5); }  // :6354-6356
-    i64 st;
-    if (h.len <= 64) st = next_fit_regs(e, h.len, f, J.L, P.now, lane);
-    else st = next_fit_wave(tl_of(hd), h.len, &f, J.L, P.now);
-    ok = st != kInf && st - P.now <= P.max_window;                                              // JobScheduler.h:815
-    start = st;
-    if (ok && st != P.now) reason = res_le(f, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;      // :6810-6831
-  }
-  if (lane == 0) {
-    D[d].ok = ok ? 1u : 0u; D[d].start = start; D[d].reason = reason; D[d].res = f; D[d].node = h.node;
-    D[d].L = J.L; D[d].poff = J.poff; D[d].orig = J.orig;
-  }
-}
-
-// commit of one accepted decision on a helper wave (time map, cost, owner update, placement record)
-__device__ __noinline__ void batch_commit(const KParams& P, BDec* D, u32 d, u32 qbeg, UpdRec* upd) {
-  const u32 lane = threadIdx.x & 63u;
-  const BDec x = D[d];
-  const u32 q = qbeg + slot_of_code(x.code);
-  NodeHdr* hd; NodeHdr h; TlEntry e;
-  load_block(P, q, lane, hd, h, e);
-  const i64 end = x.start + x.L;
-  const Res e0 = rl_res(e.r, 0);
-  u32 newlen;
-  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, x.start, end, x.res, lane, x.orig);
-  else newlen = tl_commit(P, hd, x.start, end, x.res, lane, x.orig);
-  const double ratio = ((double)x.res.cpu / 256.0) / ((double)h.total.cpu / 256.0);
-  const double ncost = __longlong_as_double((long long)x.cost) + (double)(end - x.start) * ratio;
-  if (lane == 0) {
-    UpdRec u;
-    u.p = x.code; u.len = newlen; u.cost = ncost;
-    u.has_front = (x.start == P.now) ? 1u : 0u;
-    Res f = e0;
-    if (u.has_front) res_sub(f, x.res);
-    u.fcpu = clamp_cpu(f.cpu); u.fmem = mem_mib_ceil(f.mem); u.fcnt = class_counts(f.gres, P.gres); u.pad = 0;
-    P.cost[q] = ncost;
-    if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
-    upd[d] = u;
-    u32 rank = 0;  // placement record, ascending node index inside the job
-    for (u32 m = x.first; m < x.first + x.k; ++m) rank += D[m].node < x.node ? 1u : 0u;
-    const u64 o = x.poff + rank;
-    P.o_node[o] = x.node; P.o_ntasks[o] = 1;
-    P.o_cpu[o] = x.res.cpu; P.o_mem[o] = x.res.mem; P.o_clo[o] = x.res.clo; P.o_chi[o] = x.res.chi;
-    P.o_gres[o] = x.res.gres;
-    if (d == x.first) { P.o_start[x.orig] = x.start; P.o_reason[x.orig] = (uint8_t)x.reason; }
-  }
-}
-
-struct BatchShared {
-  FrEnt* fr;        // [kFrMax] frontier proposals of the scanner waves
-  u64* mth_c;       // [kWaves-1] key of each wave's last proposal (~0 = the wave listed all its nodes)
-  u32* mth_p;
-  BDec* dec;        // [kMaxDec]
-  DeadShape* dead;  // [kMaxDead]
-  int* ndead;
-  int* nb;          // jobs decided
-  int* nd;          // node decisions
-};
-
-#ifdef CNS_PROF
-#define BPROF(slot) do { if (lane == 0) P.prof[(size_t)blockIdx.x * 32 + (slot)] += 1; } while (0)
-#else
-#define BPROF(slot)
-#endif
-// The decider (wave 0): decides jobs ji.. from the frontier until a stop condition; writes sh.dec / nb / nd.
-__device__ __noinline__ void batch_decide(const KParams& P, const BatchShared sh, u64 ji, u64 jend, u32 qbeg) {
-  const u32 lane = threadIdx.x & 63u;
-  // per-type data: lane t holds type t
-  const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();
-  TypeLane tyl;
-  tyl.cpu = ttot.cpu; tyl.mem = ttot.mem; tyl.ncores = (u32)(popc64(ttot.clo) + popc64(ttot.chi));
-  tyl.cnt = class_counts(ttot.gres, P.gres);
-  // theta = the smallest "last proposal" key over the waves: every node with key <= theta was proposed
-  u64 thc = lane < (u32)(kWaves - 1) ? sh.mth_c[lane] : ~0ull;
-  u32 thp = lane < (u32)(kWaves - 1) ? sh.mth_p[lane] : ~0u;
-  wave_argmin(thc, thp);
-  // frontier entries: lane l holds proposals l, l+64, l+128, l+192
-  u64 fc[4];
-  u32 fp[4], fmw[4], fgn[4];
-  int fcpu[4];
-  i64 ftot[4];   // cpu_total of the entry's node type (for the cost prediction)
-  u32 fvalid = 0, fpend = 0;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    const u32 idx = lane + 64u * (u32)e;
-    fc[e] = ~0ull; fp[e] = kNone; fmw[e] = 1023u << 16; fgn[e] = 0; fcpu[e] = 0;
-    if (idx < (u32)kFrMax) {
-      const FrEnt x = sh.fr[idx];
-      fc[e] = x.cost; fp[e] = x.code; fmw[e] = x.mw; fgn[e] = x.gn; fcpu[e] = x.fcpu;
-      if (x.code != kNone && key_le(x.cost, x.code, thc, thp)) fvalid |= 1u << e;
-    }
-    ftot[e] = __shfl(tyl.cpu, (int)(fmw[e] >> 26));
-  }
-  const u32 maxlen = P.max_jobs_per_node;
-  const u32 G8 = 0x80808080u;
-  u32 nme[kMaxNames], nmo[kMaxNames], name_classes[kMaxNames];
-#pragma unroll
-  for (int a = 0; a < kMaxNames; ++a) {
-    const u32 nb = (u32)((P.gres.name_bytes[a] & 0x0F0F0F0F0F0F0F0Full) != 0);
-    (void)nb;
-    u64 x = P.gres.name_bytes[a] & 0x0F0F0F0F0F0F0F0Full;   // byte g = 0x0F if class g belongs to name a
-    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
-    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
-    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
-    nme[a] = (u32)x & 0x0F0F0F0Fu;
-    nmo[a] = ((u32)x >> 4) & 0x0F0F0F0Fu;
-    name_classes[a] = (u32)__popcll(P.gres.name_bytes[a]) / 8u;
-  }
-  int nb = 0, nd = 0;
-  const int ndead = *sh.ndead;
-  u64 jj = ji;
-  while (jj < jend && nb < kMaxBatchJobs && nd + (int)kBatchMaxK <= kMaxDec) {
-    const u32 raw = fetch_job(P, jj);
-    const FastJob F = make_fast_job(P, raw);
-    if (!job_batchable(F.flags, F.k, F.ntasks, F.tmin) || req_impossible(F.mv)) { BPROF(24); break; }
-    const u64 tyok = type_ok_mask(P, F.mv, tyl, lane);
-    // is this request shape known to have no start-now node left?
-    bool dead = false;
-    for (int i = 0; i < ndead; ++i) {
-      const DeadShape ds = sh.dead[i];
-      dead = dead || (ds.cpu == F.mv.cpu && ds.mem == F.mv.mem && ds.gspec == F.mv.gspec && ds.gtot == F.mv.gtot);
-    }
-    if (dead && F.k != 1) { BPROF(25); break; }  // multi-node backfill needs the joint earliest start: sequential protocol
-    const u32 kind = dead ? 1u : 0u;
-    const bool has_gres = (F.flags & kJfGres) != 0;
-    const int rc32 = F.mv.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)F.mv.cpu;
-    const u32 rm16 = (F.mv.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(F.mv.mem >> 30);
-    const u32 rq = nibbles_of(F.mv.gspec);
-    const u32 rqe = rq & 0x0F0F0F0Fu, rqo = (rq >> 4) & 0x0F0F0F0Fu;
-    // candidate bits of this lane's entries for this job (same filters as the scanners' bmask / amask)
-    u32 cand = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const u32 w = fmw[e];
-      bool c = ((fvalid >> e) & 1u) && ((tyok >> (w >> 26)) & 1ull) != 0 && ((w >> 16) & 0x3FFu) < maxlen;
-      if (kind == 0) {
-        c = c && rc32 <= fcpu[e] && rm16 <= (w & 0xFFFFu);
-        if (c && has_gres) {
-          const u32 ce = fgn[e] & 0x0F0F0F0Fu, co = (fgn[e] >> 4) & 0x0F0F0F0Fu;
-          c = ((((ce | G8) - rqe) & G8) == G8) && ((((co | G8) - rqo) & G8) == G8);
-          for (int g = 0; g < kMaxNames; ++g) {
-            const u32 tot = (F.mv.gtot >> (8 * g)) & 0xFFu;
-            const u32 have = __builtin_amdgcn_sad_u8(ce & nme[g], 0u, __builtin_amdgcn_sad_u8(co & nmo[g], 0u, 0u));
-            if (tot && have < (tot > 15u ? 15u : tot)) c = false;
-          }
-        }
-      }
-      cand |= (c ? 1u : 0u) << e;
-    }
-    // the first k candidates in (cost, index) order
-    bool stop = false;
-    u32 taken = 0;
-    for (u32 pk = 0; pk < F.k; ++pk) {
-      u64 bc = ~0ull;
-      u32 bp = kNone;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool c = ((cand >> e) & 1u) && !((taken >> e) & 1u);
-        if (c && (fc[e] < bc || (fc[e] == bc && fp[e] < bp))) { bc = fc[e]; bp = fp[e]; }
-      }
-      wave_argmin(bc, bp);
-      if (bp == kNone) { stop = true; if (kind) BPROF(27); else if (pk) BPROF(28); else BPROF(26); break; }   // not inside the frontier: the sequential protocol decides
-      bool mine_pending = false;
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (fp[e] == bp && ((fvalid >> e) & 1u)) { taken |= 1u << e; mine_pending = (fpend >> e) & 1u; }
-      if (__any(mine_pending)) { stop = true; BPROF(29); break; }  // the node was already touched in this batch
-      if (lane == 0) {
-        BDec x;
-        x.cost = bc; x.code = bp; x.jrel = (u32)nb; x.first = (u32)nd; x.k = F.k; x.kind = kind; x.ok = 0;
-        x.start = 0; x.L = F.L; x.poff = F.poff; x.orig = F.orig; x.node = 0; x.reason = 0; x.pad = 0;
-        x.res = res_zero();
-        sh.dec[nd + (int)pk] = x;
-      }
-    }
-    if (stop) break;
-    // predicted state of the chosen nodes after this job's commit
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (!((taken >> e) & 1u)) continue;
-      // MinCpuTimeRatioFirst::UpdateCost (JobScheduler.h:47-53): alloc.cpu == the request's cpu
-      const double ratio = ((double)F.mv.cpu / 256.0) / ((double)ftot[e] / 256.0);
-      const double nc = __longlong_as_double((long long)fc[e]) + (double)F.L * ratio;
-      fc[e] = cost_key(nc);
-      fpend |= 1u << e;
-      if (kind == 0) {  // what is free now shrinks (conservatively: never below the true value)
-        fcpu[e] -= rc32;
-        u32 w = fmw[e];
-        const u32 m16 = w & 0xFFFFu;
-        const u32 sub = rm16 > m16 ? m16 : rm16;
-        fmw[e] = (w & ~0xFFFFu) | (m16 == 0xFFFFu ? m16 : m16 - sub);
-        if (has_gres) {  // per class: specified counts; a name's untyped remainder only if it has one class
-          u32 g = fgn[e];
-          for (int c = 0; c < kMaxClasses; ++c) {
-            u32 cur = (g >> (4 * c)) & 0xFu;
-            if (cur == 15u) continue;  // saturated: unknown true value
-            u32 dec = (u32)((F.mv.gspec >> (8 * c)) & 0xFFu);
-            const u32 a = (P.gres.class_name_packed >> (4 * c)) & 0xFu;
-            const u32 tot = (F.mv.gtot >> (8 * a)) & 0xFFu;
-            if (c < (int)P.gres.num_classes && name_classes[a] == 1u && tot > dec) dec = tot;
-            dec = dec > cur ? cur : dec;
-            g = (g & ~(0xFu << (4 * c))) | ((cur - dec) << (4 * c));
-          }
-          fgn[e] = g;
-        }
-      }
-      if (!key_le(fc[e], fp[e], thc, thp)) fvalid &= ~(1u << e);  // left the frontier
-    }
-    nd += (int)F.k;
-    ++nb;
-    ++jj;
-  }
-  if (jj >= jend) BPROF(30); else if (nb >= kMaxBatchJobs || nd + (int)kBatchMaxK > kMaxDec) BPROF(31);
-  if (lane == 0) { *sh.nb = nb; *sh.nd = nd; }
+// inverse direction for the worker's merge: nibble g -> byte g; a saturated nibble (15 = "15 or more")
+// becomes 127, the largest count a request byte can hold (req_impossible), so the test stays necessary
+__device__ __forceinline__ u64 bytes_of_nibbles(u32 nb) {
+  u64 lo = nb & 0xFFFFu, hi = nb >> 16;
+  u64 v = lo | (hi << 32);                       // 4 nibbles per 32-bit half
+  v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+  v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+  const u64 sat = (v + 0x0101010101010101ull) & 0x1010101010101010ull;  // byte == 15 -> bit 4 set
+  return v | ((sat >> 4) * 0x70ull);             // 15 -> 127
 }
 
 // included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
 // whose bit is set in bmask; out of line: rare, and it touches no tile register.
-__device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 incl_b, u64 incl_e, u64 excl_b, u64 excl_e,
-                                      u32 bmask, u32 slot0, u32 npl) {
+__device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 ji, u32 bmask, u32 slot0, u32 npl) {
+  const u32* rec = Pp->jobrec + ji * kJobRecDwords;  // rare path: the list bounds are read from the record itself
+  const u64 incl_b = ((u64)rec[kJrInclB + 1] << 32) | rec[kJrInclB], incl_e = ((u64)rec[kJrInclE + 1] << 32) | rec[kJrInclE];
+  const u64 excl_b = ((u64)rec[kJrExclB + 1] << 32) | rec[kJrExclB], excl_e = ((u64)rec[kJrExclE + 1] << 32) | rec[kJrExclE];
   u32 lm = 0;
   for (u32 r = 0; r < npl; ++r) {
     if (!((bmask >> r) & 1u)) continue;
@@ -1512,6 +1336,8 @@ __device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 incl_b, 
   }
   return lm;
 }
+
+template <u32 V> struct ModeTag { static constexpr u32 value = V; };
 
 template <int NPL>
 __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParams* __restrict__ Pg) {
@@ -1534,9 +1360,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ u32 s_pp[kWaves];   // cannot change (everything but this job's round-0 winners)
   __shared__ u64 s_ptc[kWaves];
   __shared__ u32 s_ptp[kWaves];
-  __shared__ u64 s_tyok_n;       // res_total-fits mask per node type for the next job (from the scanners)
   __shared__ u64 s_win_c[2];     // winners of the next job as merged by the worker: [0] = A, [1] = T
   __shared__ u32 s_win_p[2];
+  __shared__ u32 s_on[4];        // scan summary of this job's T winner (fcpu, mw, gn), posted by its owner lane
   __shared__ i64 s_start;  // multi-node backfill: the common start time found by the worker
   __shared__ int s_flag;
   __shared__ int s_r0;   // worker -> scanners: this job may be followed by the worker-side merge
@@ -1544,18 +1370,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ UpdRec s_upd[kMaxUpd];
   __shared__ HeapEnt s_heap[kLdsHeap];
   __shared__ JobCtx s_job;
-  // batch mode
-  __shared__ FrEnt s_fr[kFrMax];
-  __shared__ u64 s_mth_c[kWaves - 1];
-  __shared__ u32 s_mth_p[kWaves - 1];
-  __shared__ BDec s_dec[kMaxDec];
-  __shared__ UpdRec s_bupd[kMaxDec];
-  __shared__ DeadShape s_dead[kMaxDead];
-  __shared__ int s_ndead;
-  __shared__ int s_nb, s_nd;
   __shared__ int s_ty_cpu[CNS_MAX_NODE_TYPES_DEV];  // per node type: what "completely free" looks like
   __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
   __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
+  __shared__ u32 s_nme[kMaxNames], s_nmo[kMaxNames];  // GRES name masks in the split-nibble domain (even / odd nibbles as bytes)
 
   const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();  // lane t holds node type t
   TypeLane tyl;
@@ -1574,6 +1392,11 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     s_ty_cpu[lane] = clamp_cpu(ttot.cpu);
     s_ty_m16[lane] = mem_gib16(mem_mib_ceil(ttot.mem));
     s_ty_gn[lane] = nibbles_of(tyl.cnt);
+    if (lane < (u32)kMaxNames) {
+      const u32 nb = nibbles_of(P.gres.name_bytes[lane] & 0x0F0F0F0F0F0F0F0Full);  // nibble g = 0xF if class g is in the name
+      s_nme[lane] = nb & 0x0F0F0F0Fu;
+      s_nmo[lane] = (nb >> 4) & 0x0F0F0F0Fu;
+    }
     wg_barrier();  // type tables visible to the scanners
     WorkerShared sh;
     sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap;
@@ -1587,52 +1410,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     bool pre_valid = false;   // winners of this job already known from the previous iteration's merge
     u64 wc = ~0ull, tc = ~0ull;
     u32 wcode = kNone, tcode = kNone;
-#ifdef CNS_ENABLE_BATCH
-    const bool bm = P.batch_mode != 0;
-#else
-    const bool bm = false;  // batch mode is compiled out by default: measured slower than the pipelined protocol
-#endif
-    BatchShared bsh;
-    bsh.fr = s_fr; bsh.mth_c = s_mth_c; bsh.mth_p = s_mth_p; bsh.dec = s_dec; bsh.dead = s_dead; bsh.ndead = &s_ndead;
-    bsh.nb = &s_nb; bsh.nd = &s_nd;
-    if (lane == 0) s_ndead = 0;
     u64 ji = jbeg;
     while (ji < jend) {
       PROF_T(p0);
-      if (bm) {
-        // ---- batch attempt: decide as many jobs as possible from the frontier, helpers test + commit them ----
-        raw = fetch_job(P, ji);
-        if (job_batchable(rl32(raw, kJrFlags), rl32(raw, kJrK), rl32(raw, kJrNtasks), rl32(raw, kJrTmin))) {
-          PROF_T(q0);
-          wg_barrier();  // R: the scanners proposed the frontier
-          batch_decide(PG, bsh, ji, jend, qbeg);
-          PROF_T(q1);
-          PROF_ADD(8, q0, q1);  // worker: frontier wait + deciding
-          wg_barrier();  // D: decisions listed
-          const int nd = s_nd;
-          u32 nacc = 0;
-          if (nd > 0) {
-            wg_barrier();  // V: exact tests done
-            for (int d = 0; d < nd;) {  // longest prefix of jobs whose every node passed
-              const u32 kk = s_dec[d].k;
-              bool okj = true;
-              for (u32 i = 0; i < kk; ++i) okj = okj && s_dec[d + (int)i].ok != 0;
-              if (!okj) break;
-              d += (int)kk;
-              ++nacc;
-            }
-            wg_barrier();  // C: commits done
-          }
-          PROF_T(q2);
-          PROF_ADD(9, q1, q2);  // worker: waiting for the helpers
-#ifdef CNS_PROF
-          if (lane == 0) { P.prof[(size_t)blockIdx.x * 32 + 22] += nacc; P.prof[(size_t)blockIdx.x * 32 + 23] += 1; }
-#endif
-          ji += nacc;
-          if (nacc) continue;
-        }
-        pre_valid = false;
-      }
       const FastJob F = make_fast_job(P, raw);
       const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
       const bool fast = simple && F.k == 1 && F.tmin == 1;
@@ -1650,39 +1430,18 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       }
       PROF_T(p1);
       PROF_ADD(0, p0, p1);  // worker: wait for the scanners (only when the pre-scan could not be used)
-      if (bm && wcode == kNone && job_batchable(F.flags, F.k, F.ntasks, F.tmin) && s_ndead < kMaxDead) {
-        // a full scan found no node that could start this request now: availability at `now` only shrinks
-        // within a cycle, so this request shape stays without start-now candidates (see batch mode)
-        const int nde = s_ndead;
-        bool known = false;
-        for (int i = 0; i < nde; ++i) {
-          const DeadShape ds = s_dead[i];
-          known = known || (ds.cpu == F.mv.cpu && ds.mem == F.mv.mem && ds.gspec == F.mv.gspec && ds.gtot == F.mv.gtot);
-        }
-        if (!known && lane == 0) {
-          DeadShape ds; ds.cpu = F.mv.cpu; ds.mem = F.mv.mem; ds.gspec = F.mv.gspec; ds.gtot = F.mv.gtot; ds.pad = 0;
-          s_dead[nde] = ds;
-          s_ndead = nde + 1;
-        }
-      }
-
       bool round0 = true;       // this job may be followed by the worker-side merge
       NodeSum cn, on;           // scan summaries after this job: the committed / examined node, the other winner
       cn.code = kNone; cn.cost = 0; cn.len = 0; cn.type = 0; cn.fcpu = 0; cn.fmem = 0; cn.fcnt = 0;
       on = cn;
 
       bool divert = !fast;      // leave the inline path (multi-node / general / exclusive / long time map)
+      bool have_on = false;     // `on` is the T winner: its summary sits in s_on after B2
       if (fast) {
-        // The T winner's summary is needed for the merge when this job commits on the A winner: fetch it
-        // now, ahead of the commit's stores (gfx9 counts loads and stores on one in-order counter).
-        if (!bm && wcode != kNone && tcode != kNone && tcode != wcode) {
-          drain_stores();  // its summary may have been stored by the previous job's commit
-          const u32 qt = qbeg + slot_of_code(tcode);
-          const NodeHdr* ht = hdr_of(P, qt);
-          on.code = tcode; on.cost = tc;
-          on.len = uni32(ht->len); on.type = uni32(ht->type);
-          on.fcpu = (int)uni32((u32)P.f_cpu[qt]); on.fmem = uni32(P.f_mem[qt]); on.fcnt = uni64(P.f_cnt[qt]);
-        }
+        // The T winner's summary is needed for the merge when this job commits on the A winner; its owner
+        // lane posts it in LDS (s_on) before B2 — no HBM round trip on the serial chain.
+        have_on = wcode != kNone && tcode != kNone && tcode != wcode;
+        if (have_on) { on.code = tcode; on.cost = tc; }
         // ---- fast path, Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) ------
         bool done = false;
         while (wcode != kNone) {
@@ -1732,6 +1491,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_T(b0);
           int code = 0;
           on.code = kNone;
+          have_on = false;
           NodeHdr* hd = nullptr; NodeHdr h; TlEntry e;
           if (tcode != kNone) {
             load_block(P, qbeg + slot_of_code(tcode), lane, hd, h, e);
@@ -1770,8 +1530,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         // out-of-line continuation from the current round: same barrier schedule, general code
         round0 = false;
         if (lane == 0) s_r0 = 0;
-        job_to_lds(PG, ji, raw, &s_job);
         PROF_T(d0);
+        job_to_lds(PG, ji, raw, &s_job);
+        PROF_T(d1);
+        PROF_ADD(24, d0, d1);  // job record -> LDS
         if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1) {
           // ---- multi-node job, parallel protocol: selection-only rounds among the scanners (no exact test
           // in between), then the k candidates are verified and committed in parallel by the scanner waves
@@ -1788,14 +1550,21 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             par ^= 1;
             ccode = uni32(ccode);
           }
+          PROF_T(d2);
+          PROF_ADD(25, d1, d2);  // selection rounds (start-now candidates)
           if (ncand == F.k) {  // k start-now candidates exist: exact tests run on the helpers
             wg_barrier();  // Bv1: candidate list complete
             wg_barrier();  // Bv2: verdicts in
+            PROF_T(d3);
+            PROF_ADD(26, d2, d3);  // helpers verify
             u32 nok = 0;
             for (u32 i = 0; i < F.k; ++i) nok += s_heap[i].ntasks != 0 ? 1u : 0u;
             if (nok == F.k) {  // :6294-6297 reached with the first k nodes in cost order: start now (:6326)
               if (lane == 0) { s_nupd = (int)F.k; P.o_start[F.orig] = P.now; P.o_reason[F.orig] = 0; }
               wg_barrier();  // Bc: helpers committed
+              PROF_T(d4);
+              PROF_ADD(27, d3, d4);  // helpers commit
+              PROF_CNT(30);
             } else {
               fallback = true;  // a candidate failed its exact test (rare): redo this job sequentially
             }
@@ -1812,10 +1581,15 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               par ^= 1;
               ccode = uni32(ccode);
             }
+            PROF_T(d5);
+            PROF_ADD(28, d2, d5);  // selection rounds (res_total candidates)
             if (nt == F.k) {
               wg_barrier();  // Bt1: the k nodes are listed
               int reason = 0;
               const i64 st = multi_backfill(PG, &s_job, s_heap, qbeg, &reason);
+              PROF_T(d6);
+              PROF_ADD(29, d5, d6);  // common earliest start
+              PROF_CNT(31);
               const int code = st != kInf ? 2 : 0;
               if (lane == 0) {
                 s_flag = code; s_start = st; s_nupd = (int)F.k;
@@ -1843,7 +1617,6 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       // ---- next job: if the scanners' pre-scan is usable, merge the (at most two) nodes this job could
       // have changed into it right here — the scanners are not on the critical path ------------------------
       PROF_T(m0);
-      if (bm) { ++ji; continue; }  // batch mode re-reads the queue position; no pre-scan pipeline
       if (ji + 1 >= jend) break;
       raw = raw_n;
       raw_n = ji + 2 < jend ? fetch_job(P, ji + 2) : 0u;
@@ -1858,7 +1631,15 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         reduce16(ac, ap);
         reduce16(tcs, tp);
         ac = uni64(ac); ap = uni32(ap); tcs = uni64(tcs); tp = uni32(tp);
-        const u64 tyok = s_tyok_n;
+        const u64 tyok = jr64(raw, kJdTyok);
+        if (have_on) {  // expand the tile words of the T winner (saturated fields stay conservative)
+          const u32 ocpu = uni32(s_on[0]), omw = uni32(s_on[1]), ogn = uni32(s_on[2]);
+          on.fcpu = (int)ocpu;
+          on.len = (omw >> 16) & 0x3FFu;
+          on.type = omw >> 26;
+          on.fmem = (omw & 0xFFFFu) == 0xFFFFu ? 0xFFFFFFFFu : ((omw & 0xFFFFu) << 10);
+          on.fcnt = bytes_of_nibbles(ogn);
+        }
         bool b, a;
         eval_node(P, Fn.mv, Fn.flags, tyok, cn, b, a);
         if (a && (cn.cost < ac || (cn.cost == ac && cn.code < ap))) { ac = cn.cost; ap = cn.code; }
@@ -1898,22 +1679,80 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         cost[r] = 0.0; fcpu[r] = 0; mw[r] = 1023u << 16; gn[r] = 0;
       }
     }
-    // name masks in the split-nibble domain (even nibbles / odd nibbles as bytes)
-    u32 nme[kMaxNames], nmo[kMaxNames];
-#pragma unroll
-    for (int a = 0; a < kMaxNames; ++a) {
-      const u32 nb = nibbles_of(P.gres.name_bytes[a] & 0x0F0F0F0F0F0F0F0Full);  // nibble g = 0xF if class g is in name a
-      nme[a] = nb & 0x0F0F0F0Fu;
-      nmo[a] = (nb >> 4) & 0x0F0F0F0Fu;
-    }
-    wg_barrier();  // type tables written by the worker
+    wg_barrier();  // type / name tables written by the worker
 
-    u32 raw = fetch_job(P, jbeg);
-    JobCtx J = make_job(P, jbeg, raw);
-    u64 typeok = type_ok_mask(P, J, tyl, lane);
-    if (jbeg + 1 < jend) raw = fetch_job(P, jbeg + 1);
     const u32 maxlen = P.max_jobs_per_node;
     const u32 G8 = 0x80808080u;
+    // Static part of the "may host the job at all" filter, one bit per row of the lane:
+    //   okbits: the row holds a node and its time map has room (len < kAlgoMaxJobNumPerNode, :6194);
+    //           refreshed by the owner update, the only place a length changes
+    //   wave_types: node types present in this wave's tile (a job that fits all of them needs no per-row
+    //           type test)
+    u32 okbits = 0;
+    u64 wave_types = 0;
+#pragma unroll
+    for (int r = 0; r < NPL; ++r) {
+      const u32 len = (mw[r] >> 16) & 0x3FFu;
+      okbits |= (len < maxlen ? 1u : 0u) << r;  // "no node" rows carry len = 1023
+      if (len != 1023u) wave_types |= 1ull << (mw[r] >> 26);
+    }
+    wave_types = wave_or_u64(wave_types);
+
+    // What a scanner keeps of a job: the request side of the filters, ~10 scalars (the full JobCtx only
+    // exists in LDS for the out-of-line paths).  Decoded from the lane-striped record with v_readlane.
+    struct ScanJob {
+      u32 flags, k;
+      u32 shape;   // bit 0: ntasks != node_num (general), bit 1: tpn_min == 1, bit 2: request is satisfiable at all
+      int rc32;    // min-view cpu, clamped to the 32-bit front summary
+      u32 rm16;    // min-view mem in GiB, rounded down, saturating
+      u32 rq;      // specified GRES counts per class, nibbles saturating at 15 (like the node side)
+      u32 gtot;    // untyped totals per name (bytes)
+      u32 gmode;   // 0 no GRES; bit 0: one specified class, bit 1: one untyped total (1..3 = short tests); 4 general
+      u32 gsel;    // nibble shift of that class | index of that name << 8
+      u32 gneed;   // its count | the total << 8, both saturated at 15
+    };
+    auto decode = [&](u32 raw, u64& tyok) {
+      ScanJob S;
+      S.flags = rl32(raw, kJrFlags);
+      S.k = rl32(raw, kJrK);
+      S.shape = rl32(raw, kJdShape);
+      S.rc32 = (int)rl32(raw, kJdRc32);
+      S.rm16 = rl32(raw, kJdRm16);
+      S.rq = rl32(raw, kJdRq);
+      S.gtot = rl32(raw, kJrGtot);
+      S.gmode = rl32(raw, kJdGmode);
+      S.gsel = rl32(raw, kJdGsel);
+      S.gneed = rl32(raw, kJdGneed);
+      tyok = jr64(raw, kJdTyok);
+      return S;
+    };
+
+    // Filters of job S on ONE node given its tile words:
+    //   b: the node may host the job at all (len < 1000 :6194, res_total fits :6222)
+    //   a: ... and may start it now (front filter: necessary for :6274-6285 — the entry at `now` is in every window)
+    // gme / gmo: the name masks of mode 2 (even / odd nibbles), hoisted by the caller.
+    auto row_pred = [&](const ScanJob& S, u64 tyok, u32 gme, u32 gmo, u32 w, int fc, u32 g, bool& b, bool& a) {
+      b = ((S.shape & 4u) != 0) & (((tyok >> (w >> 26)) & 1ull) != 0) & (((w >> 16) & 0x3FFu) < maxlen);
+      a = b & (S.rc32 <= fc) & (S.rm16 <= (w & 0xFFFFu));
+      if (S.gmode & 1u) a = a & (((g >> (S.gsel & 0xFFu)) & 15u) >= (S.gneed & 0xFFu));
+      if (S.gmode & 2u) {
+        const u32 ce = g & 0x0F0F0F0Fu, co = (g >> 4) & 0x0F0F0F0Fu;
+        a = a & (__builtin_amdgcn_sad_u8(ce & gme, 0u, __builtin_amdgcn_sad_u8(co & gmo, 0u, 0u)) >= (S.gneed >> 8));
+      }
+      if (S.gmode == 4) {
+        u32 gr = g;
+        asm volatile("" : "+v"(gr));  // pins the GRES arithmetic inside this (job-uniform) branch
+        const u32 ce = gr & 0x0F0F0F0Fu, co = (gr >> 4) & 0x0F0F0F0Fu;
+        const u32 rqe = S.rq & 0x0F0F0F0Fu, rqo = (S.rq >> 4) & 0x0F0F0F0Fu;
+        a = a & ((((ce | G8) - rqe) & G8) == G8) & ((((co | G8) - rqo) & G8) == G8);
+#pragma unroll
+        for (int n = 0; n < kMaxNames; ++n) {
+          const u32 tot = (S.gtot >> (8 * n)) & 0xFFu;
+          const u32 have = __builtin_amdgcn_sad_u8(ce & s_nme[n], 0u, __builtin_amdgcn_sad_u8(co & s_nmo[n], 0u, 0u));
+          a = a & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
+        }
+      }
+    };
 
     // argmin of (cost, code) over the lane's nodes whose bit is set in `mask`; ties keep the lower r
     auto lane_argmin = [&](u32 mask, u64& bc, u32& bp) {
@@ -1930,53 +1769,68 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     };
 
     // Candidate sets of one job as per-lane bitmasks + their lane-local argmins.  Nothing the filters look
-    // at changes during a job (commits happen at its end), so this runs ONCE per job:
-    //   bmask: node may host the job at all  (len < 1000 :6194, res_total fits :6222, lists :6202-6220)
-    //   amask: ... and may start it now      (front filter: necessary for :6274-6285 / :6251-6257)
+    // at changes during a job (commits happen at its end), so this runs ONCE per job.
     // `skip` masks out nodes whose state is about to change (speculative pre-scan, see below).
-    auto scan_job = [&](const JobCtx& X, u64 tyok, u32 skip, u32& bmask, u32& amask, u64& ac, u32& ap, u64& tcs,
-                        u32& tp) {
-      const bool possible = !job_impossible(X);
-      const bool has_gres = (X.flags & kJfGres) != 0;
-      const int rc32 = X.min_view.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)X.min_view.cpu;
-      const u32 rm16 = (X.min_view.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(X.min_view.mem >> 30);
-      const u32 rq = nibbles_of(X.node_view.gspec);  // specified counts, saturating at 15 like the node side
-      const u32 rqe = rq & 0x0F0F0F0Fu, rqo = (rq >> 4) & 0x0F0F0F0Fu;
-      const u32 gtot = X.node_view.gtot;
-      bmask = 0; amask = 0;
+    auto scan_job = [&](const ScanJob& S, u64 sji, u64 tyok, u32 skip, u32& bmask, u32& amask, u64& ac, u32& ap,
+                        u64& tcs, u32& tp) {
+      // bmask in one go: static bits & type bits & not skipped
+      u32 tybits = (1u << NPL) - 1u;
+      if ((tyok & wave_types) != wave_types) {  // some type present here cannot host the job (uniform, rare)
+        tybits = 0;
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) tybits |= (u32)((tyok >> (mw[r] >> 26)) & 1ull) << r;
+      }
+      const u32 bl = (S.shape & 4u) ? (okbits & tybits & ~skip) : 0u;
+      u32 gme = 0, gmo = 0;
+      if (S.gmode & 2u) { gme = uni32(s_nme[S.gsel >> 8]); gmo = uni32(s_nmo[S.gsel >> 8]); }
+      u32 am = 0;
       ac = ~0ull; tcs = ~0ull;
       u32 ar = 0xFFu, tr = 0xFFu;
+      // the row loop, specialised on the shape of the GRES request (job-uniform): 0 none, 1 short tests, 4 general
+      auto rows = [&](auto mode) {
+        constexpr u32 M = decltype(mode)::value;
+        const u32 sh1 = S.gsel & 0xFFu, need1 = S.gneed & 0xFFu, need2 = S.gneed >> 8;
+        const u32 rqe = S.rq & 0x0F0F0F0Fu, rqo = (S.rq >> 4) & 0x0F0F0F0Fu;
 #pragma unroll
-      for (int r = 0; r < NPL; ++r) {
-        const u32 w = mw[r];
-        const bool b = possible & (((tyok >> (w >> 26)) & 1ull) != 0) & (((w >> 16) & 0x3FFu) < maxlen) &
-                       (((skip >> r) & 1u) == 0);
-        bool a = b & (rc32 <= fcpu[r]) & (rm16 <= (w & 0xFFFFu));  // the entry at `now` is in every window
-        if (has_gres) {
-          u32 gr = gn[r];
-          asm volatile("" : "+v"(gr));  // pins the GRES arithmetic inside this (job-uniform) branch
-          const u32 ce = gr & 0x0F0F0F0Fu, co = (gr >> 4) & 0x0F0F0F0Fu;
-          a = a & ((((ce | G8) - rqe) & G8) == G8) & ((((co | G8) - rqo) & G8) == G8);
-#pragma unroll
-          for (int g = 0; g < kMaxNames; ++g) {
-            const u32 tot = (gtot >> (8 * g)) & 0xFFu;
-            const u32 have = __builtin_amdgcn_sad_u8(ce & nme[g], 0u, __builtin_amdgcn_sad_u8(co & nmo[g], 0u, 0u));
-            a = a & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
+        for (int r = 0; r < NPL; ++r) {
+          const bool b = ((bl >> r) & 1u) != 0;
+          bool a = b & (S.rc32 <= fcpu[r]) & (S.rm16 <= (mw[r] & 0xFFFFu));  // the entry at `now` is in every window
+          if (M == 1) {
+            const u32 g = gn[r];
+            if (S.gmode & 1u) a = a & (((g >> sh1) & 15u) >= need1);
+            if (S.gmode & 2u) {
+              const u32 ce = g & 0x0F0F0F0Fu, co = (g >> 4) & 0x0F0F0F0Fu;
+              a = a & (__builtin_amdgcn_sad_u8(ce & gme, 0u, __builtin_amdgcn_sad_u8(co & gmo, 0u, 0u)) >= need2);
+            }
           }
+          if (M == 4) {
+            const u32 g = gn[r];
+            const u32 ce = g & 0x0F0F0F0Fu, co = (g >> 4) & 0x0F0F0F0Fu;
+            a = a & ((((ce | G8) - rqe) & G8) == G8) & ((((co | G8) - rqo) & G8) == G8);
+#pragma unroll
+            for (int n = 0; n < kMaxNames; ++n) {
+              const u32 tot = (S.gtot >> (8 * n)) & 0xFFu;
+              const u32 have = __builtin_amdgcn_sad_u8(ce & s_nme[n], 0u, __builtin_amdgcn_sad_u8(co & s_nmo[n], 0u, 0u));
+              a = a & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
+            }
+          }
+          const u64 ck = cost_key(cost[r]);
+          const bool ta = a & (ck < ac);
+          ac = ta ? ck : ac;
+          ar = ta ? (u32)r : ar;
+          const bool tt = b & (ck < tcs);
+          tcs = tt ? ck : tcs;
+          tr = tt ? (u32)r : tr;
+          am |= (a ? 1u : 0u) << r;
         }
-        const u64 ck = cost_key(cost[r]);
-        const bool ta = a & (ck < ac);
-        ac = ta ? ck : ac;
-        ar = ta ? (u32)r : ar;
-        const bool tt = b & (ck < tcs);
-        tcs = tt ? ck : tcs;
-        tr = tt ? (u32)r : tr;
-        bmask |= (b ? 1u : 0u) << r;
-        amask |= (a ? 1u : 0u) << r;
-      }
+      };
+      if (S.gmode == 0) rows(ModeTag<0>{});
+      else if (S.gmode < 4) rows(ModeTag<1>{});
+      else rows(ModeTag<4>{});
+      bmask = bl; amask = am;
       ap = ar == 0xFFu ? kNone : ((ar << 10) | t);
       tp = tr == 0xFFu ? kNone : ((tr << 10) | t);
-      if (X.flags & kJfExclusive) {  // exclusive: the node must be completely free now (necessary for :6251-6257)
+      if (S.flags & kJfExclusive) {  // exclusive: the node must be completely free now (necessary for :6251-6257)
         amask = 0;
 #pragma unroll
         for (int r = 0; r < NPL; ++r) {
@@ -1988,8 +1842,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         }
         lane_argmin(amask, ac, ap);
       }
-      if (X.flags & (kJfIncl | kJfExcl)) {  // included / excluded node lists (rare)
-        const u32 lm = list_mask(Pg, X.flags, X.incl_b, X.incl_e, X.excl_b, X.excl_e, bmask, qbeg + t, (u32)NPL);
+      if (S.flags & (kJfIncl | kJfExcl)) {  // included / excluded node lists (rare)
+        const u32 lm = list_mask(Pg, S.flags, sji, bmask, qbeg + t, (u32)NPL);
         bmask &= lm;
         amask &= lm;
         lane_argmin(amask, ac, ap);
@@ -1997,110 +1851,68 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       }
     };
 
+    u32 raw = fetch_job(P, jbeg);
+    u64 typeok;
+    ScanJob J = decode(raw, typeok);
+    if (jbeg + 1 < jend) raw = fetch_job(P, jbeg + 1);
+
     u32 bmask = 0, amask = 0;
     u64 ac = ~0ull, tcs = ~0ull;
     u32 ap = kNone, tp = kNone;
     // state carried from the previous iteration's pre-scan
-    u32 bmask_n = 0, amask_n = 0, skipm = 0;
+    u32 bmask_n = 0, amask_n = 0;
     bool pre_valid = false;  // the winners of this job came from the worker's merge of the pre-scan
     u64 wc = ~0ull, tc = ~0ull;
     u32 wcode = kNone, tcode = kNone;
 
-    // owner lanes refresh their registers from an update record
-    auto apply_upd = [&](const UpdRec& u) {
-      const int rr = (int)(u.p >> 10);
+    // `up` (slot code) is wave-uniform: the row select is a scalar branch, only the owner lane writes
+    auto apply_upd = [&](const UpdRec& u, u32 up) {
+      const int rr = (int)(up >> 10);
+      const bool own = (up & 1023u) == t;
+      const double ucost = u.cost;
+      const u32 ulen = u.len, ufront = u.has_front;
+      const int ucpu = u.fcpu;
+      const u32 um16 = mem_gib16(u.fmem), ugn = nibbles_of(u.fcnt);
 #pragma unroll
       for (int r = 0; r < NPL; ++r)
         if (r == rr) {
-          cost[r] = u.cost;
-          u32 w = (mw[r] & ~(0x3FFu << 16)) | (u.len << 16);
-          if (u.has_front) {
-            fcpu[r] = u.fcpu;
-            w = (w & ~0xFFFFu) | mem_gib16(u.fmem);
-            gn[r] = nibbles_of(u.fcnt);
-          }
-          mw[r] = w;
+          u32 w = (mw[r] & ~(0x3FFu << 16)) | (ulen << 16);
+          if (ufront) w = (w & ~0xFFFFu) | um16;
+          cost[r] = own ? ucost : cost[r];
+          mw[r] = own ? w : mw[r];
+          okbits = own ? ((okbits & ~(1u << r)) | ((ulen < maxlen ? 1u : 0u) << r)) : okbits;
+          fcpu[r] = (own && ufront) ? ucpu : fcpu[r];
+          gn[r] = (own && ufront) ? ugn : gn[r];
         }
     };
-#ifdef CNS_ENABLE_BATCH
-    const bool bm = P.batch_mode != 0;
-#else
-    const bool bm = false;  // batch mode is compiled out by default: measured slower than the pipelined protocol
-#endif
+    // One node that the pre-scan of job Sn skipped (a round-0 winner of the job before it): evaluate Sn's
+    // filters on its refreshed registers and complete the pre-scanned candidate sets.  `code` is
+    // wave-uniform and lies in this wave.
+    auto fix_row = [&](const ScanJob& Sn, u64 tyok_n, u32 code) {
+      const int rr = (int)(code >> 10);
+      u32 w = 0, g = 0;
+      int fc = 0;
+#pragma unroll
+      for (int r = 0; r < NPL; ++r)
+        if (r == rr) { w = mw[r]; fc = fcpu[r]; g = gn[r]; }
+      u32 gme = 0, gmo = 0;
+      if (Sn.gmode & 2u) { gme = uni32(s_nme[Sn.gsel >> 8]); gmo = uni32(s_nmo[Sn.gsel >> 8]); }
+      bool b, a;
+      row_pred(Sn, tyok_n, gme, gmo, w, fc, g, b, a);
+      const bool own = (code & 1023u) == t;
+      bmask_n |= ((own & b) ? 1u : 0u) << rr;
+      amask_n |= ((own & a) ? 1u : 0u) << rr;
+    };
+
     u64 ji = jbeg;
     while (ji < jend) {
       PROF_T(s6);
-      if (bm) {
-        raw = fetch_job(P, ji);
-        J = make_job(P, ji, raw);
-        typeok = type_ok_mask(P, J, tyl, lane);
-        if (job_batchable(J.flags, J.k, J.ntasks, J.tmin)) {
-          // ---- batch attempt.  Frontier proposal: this wave's kFrPerWave smallest (cost, index) keys with
-          // their summaries; theta = the smallest "last proposal" over the waves, so every node with a key
-          // <= theta is in some wave's list (a prefix of the global cost order).
-          u32 exist = 0;
-#pragma unroll
-          for (int r = 0; r < NPL; ++r) exist |= ((((mw[r] >> 16) & 0x3FFu) != 1023u) ? 1u : 0u) << r;
-          u32 listed = 0;
-          u64 lastc = ~0ull;
-          u32 lastp = kNone;
-          for (int i = 0; i < kFrPerWave; ++i) {
-            u64 c;
-            u32 code;
-            lane_argmin(exist & ~listed, c, code);
-            wave_argmin(c, code);
-            const u32 slot = (wave - 1) * kFrPerWave + (u32)i;
-            if (code != kNone && (code & 1023u) == t) {
-              const int rr = (int)(code >> 10);
-              FrEnt x;
-              x.cost = c; x.code = code; x.fcpu = 0; x.mw = 0; x.gn = 0;
-#pragma unroll
-              for (int r = 0; r < NPL; ++r)
-                if (r == rr) { x.fcpu = fcpu[r]; x.mw = mw[r]; x.gn = gn[r]; }
-              s_fr[slot] = x;
-              listed |= 1u << rr;
-            }
-            if (code == kNone && lane == 0) {
-              FrEnt x;
-              x.cost = ~0ull; x.code = kNone; x.fcpu = 0; x.mw = 1023u << 16; x.gn = 0;
-              s_fr[slot] = x;
-            }
-            lastc = c; lastp = code;
-          }
-          if (lane == 0) { s_mth_c[wave - 1] = lastp == kNone ? ~0ull : lastc; s_mth_p[wave - 1] = lastp == kNone ? ~0u : lastp; }
-          wg_barrier();  // R
-          wg_barrier();  // D: the worker decided
-          const int nd = s_nd;
-          u32 nacc = 0;
-          if (nd > 0) {
-            for (int d = (int)wave - 1; d < nd; d += kWaves - 1) batch_verify(PG, s_dec, (u32)d, ji, qbeg);
-            wg_barrier();  // V
-            int ndacc = 0;
-            for (int d = 0; d < nd;) {  // longest prefix of jobs whose every node passed
-              const u32 kkd = s_dec[d].k;
-              bool okj = true;
-              for (u32 i = 0; i < kkd; ++i) okj = okj && s_dec[d + (int)i].ok != 0;
-              if (!okj) break;
-              d += (int)kkd;
-              ndacc = d;
-              ++nacc;
-            }
-            for (int d = (int)wave - 1; d < ndacc; d += kWaves - 1) batch_commit(PG, s_dec, (u32)d, qbeg, s_bupd);
-            wg_barrier();  // C
-            for (int d = 0; d < ndacc; ++d)
-              if ((s_bupd[d].p & 1023u) == t) apply_upd(s_bupd[d]);
-          }
-          ji += nacc;
-          if (nacc) continue;
-        }
-        pre_valid = false;
-      }
       const bool excl_job = (J.flags & kJfExclusive) != 0;
       const u32 kk = J.k;
-      const bool general = J.general;
+      const bool general = (J.shape & 1u) != 0;
       if (!pre_valid) {
         // ---- full scan of this job, publish both argmins ------------------------------------------------
-        scan_job(J, typeok, 0u, bmask, amask, ac, ap, tcs, tp);
+        scan_job(J, ji, typeok, 0u, bmask, amask, ac, ap, tcs, tp);
         wave_argmin(ac, ap);
         wave_argmin(tcs, tp);
         if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; s_tc[wave] = tcs; s_tp[wave] = tp; }
@@ -2113,42 +1925,41 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         reduce16(tc, tcode);
         par ^= 1;
       } else {
-        // winners came from the worker; complete the pre-scanned candidate sets with the skipped nodes
-        // (their registers are up to date now) — only needed if this job goes beyond round 0
+        // winners came from the worker's merge; the pre-scanned candidate sets were completed with the
+        // skipped nodes right after the previous job's owner update (fix_row)
         bmask = bmask_n; amask = amask_n;
-        if (__ballot(skipm != 0) != 0ull) {
-          u32 b2, a2, ap2, tp2;
-          u64 ac2, tcs2;
-          scan_job(J, typeok, ~skipm, b2, a2, ac2, ap2, tcs2, tp2);
-          bmask |= b2; amask |= a2;
-        }
       }
       PROF_T(s2);
-      PROF_ADDS(17, s6, s2);  // scanner: scan / mask completion + B1
+      PROF_ADDS(17, s6, s2);  // scanner: full scan + B1 (only when the pre-scan could not be used)
 
       // ---- while the worker examines the winner: decode the next job and PRE-SCAN it ----------------------
       // The only nodes this job can change (if it resolves in round 0, as ~99.9 % of single-node jobs do)
       // are the two round-0 winners.  The next job's candidate sets and argmins are computed now over all
       // OTHER nodes and published; after its commit the WORKER merges the winners' new state into them.
-      JobCtx Jn = J;
+      wcode = uni32(wcode); tcode = uni32(tcode);
+      ScanJob Jn = J;
       u64 typeok_n = typeok;
-      const bool have_next = !bm && ji + 1 < jend;
+      const bool have_next = ji + 1 < jend;
       const bool spec_ok = !excl_job && !general && kk == 1;  // this job touches one node, a round-0 winner
-      skipm = 0;
+      u32 skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= 1u << (wcode >> 10);
-      if ((tcode & 1023u) == t && tcode != kNone) skipm |= 1u << (tcode >> 10);
+      if ((tcode & 1023u) == t && tcode != kNone) {
+        skipm |= 1u << (tcode >> 10);
+        const int rr = (int)(tcode >> 10);
+#pragma unroll
+        for (int r = 0; r < NPL; ++r)
+          if (r == rr) { s_on[0] = (u32)fcpu[r]; s_on[1] = mw[r]; s_on[2] = gn[r]; }
+      }
       if (have_next) {
-        Jn = make_job(P, ji + 1, raw);
-        typeok_n = type_ok_mask(P, Jn, tyl, lane);
+        Jn = decode(raw, typeok_n);
         if (ji + 2 < jend) raw = fetch_job(P, ji + 2);
         if (spec_ok) {
           u64 pc, ptc;
           u32 pp, ptp;
-          scan_job(Jn, typeok_n, skipm, bmask_n, amask_n, pc, pp, ptc, ptp);
+          scan_job(Jn, ji + 1, typeok_n, skipm, bmask_n, amask_n, pc, pp, ptc, ptp);
           wave_argmin(pc, pp);
           wave_argmin(ptc, ptp);
           if (lane == 0) { s_pc[wave] = pc; s_pp[wave] = pp; s_ptc[wave] = ptc; s_ptp[wave] = ptp; }
-          if (tid == 64) s_tyok_n = typeok_n;
         }
       }
       PROF_T(s3);
@@ -2158,7 +1969,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       u32 used = 0;
       bool round0 = true;  // resolved without a second scan round
       bool sequential = true;  // run the one-candidate-per-round protocol below
-      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMaxUpd && J.tmin == 1) {
+      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMaxUpd && (J.shape & 2u)) {
         // ---- multi-node job, parallel protocol (mirror of the worker's): selection-only rounds, then this
         // wave verifies / commits candidates i = wave-1, wave-1+15, ... as a helper ---------------------------
         sequential = false;
@@ -2191,6 +2002,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           for (u32 i = 0; i < kk; ++i) nok += s_heap[i].ntasks != 0 ? 1u : 0u;
           if (nok == kk) {
             for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_commit(PG, &s_job, s_heap, i, qbeg, P.now, s_upd);
+            drain_stores();  // the worker reads these blocks again in later jobs
             wg_barrier();  // Bc
             verdict = 2;
           } else {
@@ -2225,6 +2037,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             if (s_flag == 2) {
               const i64 st = s_start;
               for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_commit(PG, &s_job, s_heap, i, qbeg, st, s_upd);
+              drain_stores();
               wg_barrier();  // Bt3
               verdict = 2;
             }
@@ -2232,8 +2045,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         }
       }
       // ---- Phase A ----------------------------------------------------------------------------------
-      while (sequential && wcode != kNone) {
-        if ((wcode & 1023u) == t) used |= 1u << (wcode >> 10);
+      u32 acode = wcode;
+      while (sequential && acode != kNone) {
+        if ((acode & 1023u) == t) used |= 1u << (acode >> 10);
         wg_barrier();  // B2
         verdict = s_flag;
         if (verdict == 2) break;
@@ -2242,9 +2056,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         wave_argmin(ac, ap);
         if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; }
         wg_barrier();  // B1
-        wc = s_wc[par][lane & (kWaves - 1)];
-        wcode = s_wp[par][lane & (kWaves - 1)];
-        reduce16(wc, wcode);
+        u64 c2 = s_wc[par][lane & (kWaves - 1)];
+        acode = s_wp[par][lane & (kWaves - 1)];
+        reduce16(c2, acode);
         par ^= 1;
       }
       // ---- Phase B ----------------------------------------------------------------------------------
@@ -2283,13 +2097,18 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         const int nu = s_nupd;
         const UpdRec* const ub = nu <= kMaxUpd ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
         for (int i = 0; i < nu; ++i) {
-          const u32 up = ub[i].p;
-          if ((up & 1023u) == t) apply_upd(ub[i]);
+          const u32 up = uni32(ub[i].p);
+          if (((up & 1023u) >> 6) + 1u == wave) apply_upd(ub[i], up);  // only the owner's wave does any work
         }
       }
-      PROF_T(s5);
-      PROF_ADDS(20, s4, s5);  // scanner: owner update
       pre_valid = have_next && spec_ok && round0 && !(Jn.flags & (kJfExclusive | kJfIncl | kJfExcl));
+      if (pre_valid) {
+        // complete the next job's pre-scanned sets with the nodes its pre-scan had to skip
+        if (wcode != kNone && ((wcode & 1023u) >> 6) + 1u == wave) fix_row(Jn, typeok_n, wcode);
+        if (tcode != kNone && tcode != wcode && ((tcode & 1023u) >> 6) + 1u == wave) fix_row(Jn, typeok_n, tcode);
+      }
+      PROF_T(s5);
+      PROF_ADDS(20, s4, s5);  // scanner: owner update + completion of the pre-scanned sets
       if (pre_valid) {
         wg_barrier();  // B1': the worker merged the winners into the pre-scan
         wc = s_win_c[0]; wcode = s_win_p[0]; tc = s_win_c[1]; tcode = s_win_p[1];
@@ -2303,11 +2122,13 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   }
 }
 
+#ifndef CNS_ONLY_NPL9
 template __global__ void k_select<1>(const KParams, const KParams*);
 template __global__ void k_select<2>(const KParams, const KParams*);
 template __global__ void k_select<3>(const KParams, const KParams*);
 template __global__ void k_select<5>(const KParams, const KParams*);
-template __global__ void k_select<9>(const KParams, const KParams*);
 template __global__ void k_select<18>(const KParams, const KParams*);
+#endif
+template __global__ void k_select<9>(const KParams, const KParams*);
 
 }  // namespace cns
