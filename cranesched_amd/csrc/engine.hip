@@ -271,8 +271,8 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   }
   part_off[P] = (u32)slot_node.size();
   const u32 S = (u32)slot_node.size();
-  if (max_np > (u32)(kBlock - 64) * 18u)
-    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than 17280 schedulable nodes");
+  if (max_np > (u32)(kBlock - 64) * (u32)CNS_NPL_MAX)
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string((kBlock - 64) * CNS_NPL_MAX) + " schedulable nodes");
   // node types = distinct res_total records
   std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
@@ -503,16 +503,15 @@ int cns_run_resident(cns_handle* h, int64_t now) {
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
   if (h->Jg) {
     const u32 np = h->max_np;
-#ifdef CNS_ONLY_NPL9   // experiment builds: one tile width only (partitions of <= 8640 nodes)
-    if (np > 8640) return fail(h, CNS_ERR_UNSUPPORTED, "experiment build: partition > 8640 nodes");
-    launch_select<9>(h, K);
+#ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
+    if (np > (u32)(kBlock - 64) * CNS_ONLY_NPL) return fail(h, CNS_ERR_UNSUPPORTED, "experiment build: partition too large for its one tile width");
+    launch_select<CNS_ONLY_NPL>(h, K);
 #else
-    if (np <= 960) launch_select<1>(h, K);
-    else if (np <= 1920) launch_select<2>(h, K);
-    else if (np <= 2880) launch_select<3>(h, K);
-    else if (np <= 4800) launch_select<5>(h, K);
-    else if (np <= 8640) launch_select<9>(h, K);
-    else launch_select<18>(h, K);
+    bool launched = false;
+#define CNS_TRY_WIDTH(w) if (!launched && np <= (u32)(kBlock - 64) * (w)) { launch_select<w>(h, K); launched = true; }
+    CNS_NPL_LIST(CNS_TRY_WIDTH)
+#undef CNS_TRY_WIDTH
+    if (!launched) return fail(h, CNS_ERR_UNSUPPORTED, "partition too large for the widest register tile");
 #endif
     HIPCHK(h, hipGetLastError());
   }

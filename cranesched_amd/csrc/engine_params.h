@@ -10,11 +10,28 @@
 
 namespace cns {
 
-constexpr int kBlock = 1024;         // threads of the per-partition workgroup (16 wave64)
+// Threads of the per-partition workgroup.  512 = 8 wave64 = 2 waves per SIMD, i.e. 256 VGPRs per lane: the
+// register-resident node tile and the worker's state fit without spills (at 1024 threads the 128-VGPR cap
+// made the hot loops spill whenever cold code changed), and the worker shares its SIMD with one scanner only.
+#ifndef CNS_BLOCK
+#define CNS_BLOCK 512
+#endif
+constexpr int kBlock = CNS_BLOCK;
+// Tile widths (nodes per scanner lane) the selection kernel is instantiated for; a partition uses the
+// smallest width w with (kWaves - 1) * 64 * w >= its node count.
+#if CNS_BLOCK == 512
+#define CNS_NPL_LIST(X) X(1) X(3) X(10) X(19) X(39)
+#define CNS_NPL_MAX 39
+#elif CNS_BLOCK == 1024
+#define CNS_NPL_LIST(X) X(1) X(2) X(3) X(5) X(9) X(18)
+#define CNS_NPL_MAX 18
+#else
+#error "CNS_BLOCK must be 512 or 1024 (the wave count must be a power of two)"
+#endif
 constexpr int kWaves = kBlock / 64;
-constexpr int kMaxNpl = 16;          // nodes per lane held in registers -> <= 16384 nodes per partition
 constexpr u32 kTlCap = 1008;         // >= kAlgoMaxJobNumPerNode - 1 + 2 entries per node
 constexpr int kMaxUpd = 32;          // per-job owner updates broadcast through LDS
+constexpr int kMultiK = kWaves;      // node_num handled by the parallel multi-node protocol (one helper wave per node, the worker included)
 constexpr int kLdsHeap = 33;         // heap / pick entries kept in LDS when node_num < this
 constexpr i64 kInf = INT64_MAX;      // absl::InfiniteFuture()
 constexpr u32 kNone = 0xFFFFFFFFu;

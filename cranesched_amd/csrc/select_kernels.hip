@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
   rec[kJdTyok] = (u32)tyok; rec[kJdTyok + 1] = (u32)(tyok >> 32);
 }
 
-constexpr u32 kScan = (kWaves - 1) * 64;  // 960 scanner lanes
+constexpr u32 kScan = (kWaves - 1) * 64;  // scanner lanes
 __device__ __forceinline__ u32 slot_of_code(u32 code) { return (code >> 10) * kScan + (code & 1023u); }
 
 // ---------------------------------------------------------------------------------------------
@@ -1212,82 +1212,134 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
 
 // ---- multi-node jobs: candidate i of the selection is verified / committed by ONE wave, all candidates in
 // parallel on the scanner waves ("helpers").  H[i] carries (cost, slot code) in, (node, allocation, ok) out.
-__device__ __noinline__ void helper_verify(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, u32 qbeg) {
-  const u32 lane = threadIdx.x & 63u;
-  const JobCtx J = *Jp;
-  const u32 code = H[i].p;
-  NodeHdr* hd; NodeHdr h; TlEntry e;
-  PROF_T(v0);
-  load_block(P, qbeg + slot_of_code(code), lane, hd, h, e);
-  PROF_T(v1);
-  Res f = res_zero(), m;
-  bool ok = false;
-  if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                      class_counts(h.avail0.gres, P.gres), P.gres)) {                          // :6274
-    m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
-                            : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));              // :6278-6283
-    ok = feasible(J.min_view, m, f, P.gres);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
-  }
-  if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
-  PROF_T(v2);
-  if (i == 0) { PROF_ADD(8, v0, v1); PROF_ADD(9, v1, v2); }  // helper of pick 0: block load / exact test
-}
-__device__ __noinline__ void helper_commit(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, u32 qbeg, i64 start,
-                                           UpdRec* upd) {
-  const u32 lane = threadIdx.x & 63u;
-  const JobCtx J = *Jp;
-  const HeapEnt x = H[i];
-  PROF_T(c0);
-  commit_pick(P, J, x, i, qbeg, start, lane, upd, J.orig);
-  PROF_T(c1);
-  if (i == 0) PROF_ADD(10, c0, c1);  // helper of pick 0: block load + commit
-  if (lane == 0) {  // placement record, ascending node index
-    u32 rank = 0;
-    for (u32 m = 0; m < J.k; ++m) rank += H[m].node < x.node ? 1u : 0u;
+// ---------------------------------------------------------------------------------------------
+// Parallel protocol for multi-node jobs (2 <= node_num <= kMultiK, ntasks == node_num, shared nodes).
+// The k candidate nodes are listed in H[0..k) (cost order).  ALL 16 waves call these routines (they
+// contain workgroup barriers); wave i+1 is the helper of candidate i (`active`), the others only follow
+// the barriers.  A helper reads its node block ONCE and keeps it in registers from the exact test to
+// the commit.
+// ---------------------------------------------------------------------------------------------
+// Commit of candidate i from the helper's registers + owner update i + its placement record.
+__device__ __forceinline__ void helper_commit_regs(const KParams& P, const JobCtx& J, const HeapEnt* H, u32 i, u32 p,
+                                                   double cost0, NodeHdr* hd, const NodeHdr& h, const TlEntry& e,
+                                                   const Res& res, i64 start, u32 lane, UpdRec* upd, u32 q) {
+  const i64 end = start + J.L;
+  const Res e0 = rl_res(e.r, 0);  // entry at `now`
+  u32 newlen;
+  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, res, lane, J.orig);
+  else newlen = tl_commit(P, hd, start, end, res, lane, J.orig);
+  // MinCpuTimeRatioFirst::UpdateCost, JobScheduler.h:47-53 — ratio first, then x seconds, then +=
+  const double ratio = ((double)res.cpu / 256.0) / ((double)h.total.cpu / 256.0);
+  const double ncost = cost0 + (double)(end - start) * ratio;
+  if (lane == 0) {
+    UpdRec u;
+    u.p = p; u.len = newlen; u.cost = ncost;
+    u.has_front = (start == P.now) ? 1u : 0u;
+    Res f = e0;
+    if (u.has_front) res_sub(f, res);
+    u.fcpu = clamp_cpu(f.cpu); u.fmem = mem_mib_ceil(f.mem); u.fcnt = class_counts(f.gres, P.gres); u.pad = 0;
+    P.cost[q] = ncost;
+    if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
+    upd[i] = u;
+    u32 rank = 0;  // placement records are listed by ascending node index
+    for (u32 m = 0; m < J.k; ++m) rank += H[m].node < h.node ? 1u : 0u;
     const u64 o = J.poff + rank;
-    P.o_node[o] = x.node; P.o_ntasks[o] = 1;
-    P.o_cpu[o] = x.res.cpu; P.o_mem[o] = x.res.mem; P.o_clo[o] = x.res.clo; P.o_chi[o] = x.res.chi;
-    P.o_gres[o] = x.res.gres;
+    P.o_node[o] = h.node; P.o_ntasks[o] = 1;
+    P.o_cpu[o] = res.cpu; P.o_mem[o] = res.mem; P.o_clo[o] = res.clo; P.o_chi[o] = res.chi; P.o_gres[o] = res.gres;
   }
 }
-// Phase B of a multi-node job on the worker: allocations against res_total, earliest common start
-// (fixed point over the k nodes), pending reason.  Returns the start time or kInf.
-__device__ __noinline__ i64 multi_backfill(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 qbeg, int* reason_out) {
+
+// Start-now ending (:6188-6333 with the first k nodes in cost order): exact test of every candidate in
+// parallel; if all pass, commit them at `now`.  Returns false (nothing written) if any candidate failed.
+__device__ __noinline__ bool multi_verify_commit(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, bool active,
+                                                 u32 qbeg, UpdRec* upd, int* nupd) {
   const u32 lane = threadIdx.x & 63u;
   const JobCtx J = *Jp;
-  drain_stores();
-  bool bad = false, notle = false;
-  if (lane < J.k) {  // allocation against res_total (:6353-6361)
-    HeapEnt x = H[lane];
-    const NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
-    x.node = hd->node;
-    x.ntasks = 1;
-    Res a = res_zero();
-    if (!feasible(J.min_view, hd->total, a, P.gres)) bad = true;
-    x.res = a;
-    notle = !res_le(a, hd->avail0);
-    H[lane] = x;
+  NodeHdr* hd = nullptr;
+  NodeHdr h;
+  TlEntry e;
+  Res f = res_zero();
+  u32 p = 0, q = 0;
+  double cost0 = 0.0;
+  h.len = 0;
+  if (active) {
+    p = H[i].p;
+    cost0 = H[i].cost;
+    q = qbeg + slot_of_code(p);
+    load_block(P, q, lane, hd, h, e);
+    bool ok = false;
+    if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
+                        class_counts(h.avail0.gres, P.gres), P.gres)) {                          // :6274
+      const Res m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
+                                        : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));    // :6278-6283
+      ok = feasible(J.min_view, m, f, P.gres);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
+    }
+    if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
   }
-  if (__any(bad) && lane == 0) set_fault(P, 3, J.orig, 0, 2);
-  notle = __any(notle);
-  __threadfence_block();
+  wg_barrier();  // M3: verdicts in
+  u32 nok = 0;
+  for (u32 m = 0; m < J.k; ++m) nok += H[m].ntasks != 0 ? 1u : 0u;
+  if (nok != J.k) return false;  // (rare) the caller falls back to the sequential protocol
+  if (active) {
+    helper_commit_regs(P, J, H, i, p, cost0, hd, h, e, f, P.now, lane, upd, q);
+    drain_stores();  // the worker reads this block again in later jobs
+  }
+  if (threadIdx.x == 0) *nupd = (int)J.k;
+  wg_barrier();  // M4: commits + owner updates visible
+  return true;
+}
+
+// Backfill ending (:6335-6376): allocations against res_total, earliest common start as the fixed point
+// t <- max_i next_fit_i(t) (each helper evaluates its own node, one barrier per iteration), commit at t.
+// Returns the start time or kInf (nothing written).  nf: 2 x kMultiK exchange slots in LDS.
+__device__ __noinline__ i64 multi_backfill_par(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, bool active,
+                                               u32 qbeg, UpdRec* upd, int* nupd, i64* nf, int* reason_out) {
+  const u32 lane = threadIdx.x & 63u;
+  const JobCtx J = *Jp;
+  NodeHdr* hd = nullptr;
+  NodeHdr h;
+  TlEntry e;
+  Res alloc = res_zero();
+  u32 p = 0, q = 0;
+  double cost0 = 0.0;
+  h.len = 0;
+  if (active) {
+    p = H[i].p;
+    cost0 = H[i].cost;
+    q = qbeg + slot_of_code(p);
+    load_block(P, q, lane, hd, h, e);
+    if (!feasible(J.min_view, h.total, alloc, P.gres)) {  // :6354-6356
+      if (lane == 0) set_fault(P, 3, J.orig, h.node, 2);
+    }
+    if (lane == 0) { H[i].node = h.node; H[i].ntasks = 1; H[i].res = alloc; H[i].pad = res_le(alloc, h.avail0) ? 0u : 1u; }
+  }
   i64 t = P.now;
   bool found = false;
+  int par2 = 0;
   for (u32 iter = 0; iter < (1u << 20); ++iter) {
+    if (active) {
+      const i64 sx = h.len <= 64 ? next_fit_regs(e, h.len, alloc, J.L, t, lane) : next_fit_wave(tl_of(hd), h.len, &alloc, J.L, t);
+      if (lane == 0) nf[par2 * kMultiK + (int)i] = sx;
+    }
+    wg_barrier();
     i64 Tm = t;
-    for (u32 i = 0; i < J.k; ++i) {
-      const HeapEnt x = H[i];
-      NodeHdr* hd; NodeHdr h; TlEntry e;
-      load_block(P, qbeg + slot_of_code(x.p), lane, hd, h, e);
-      i64 sx;
-      if (h.len <= 64) sx = next_fit_regs(e, h.len, x.res, J.L, t, lane);
-      else sx = next_fit_wave(tl_of(hd), h.len, &x.res, J.L, t);
+    for (u32 m = 0; m < J.k; ++m) {
+      const i64 sx = nf[par2 * kMultiK + (int)m];
       Tm = sx > Tm ? sx : Tm;
     }
+    par2 ^= 1;
     if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
     if (Tm == t) { found = true; break; }
     t = Tm;
   }
+  bool notle = false;
+  for (u32 m = 0; m < J.k; ++m) notle = notle || H[m].pad != 0;
+  if (found && active) {
+    helper_commit_regs(P, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q);
+    drain_stores();
+  }
+  if (found && threadIdx.x == 0) *nupd = (int)J.k;
+  wg_barrier();  // commits + owner updates visible (or: nothing happened)
   *reason_out = (found && t != P.now) ? (notle ? 2 : 1) : 0;  // :6810-6831
   return found ? t : kInf;
 }
@@ -1321,23 +1373,25 @@ __device__ __forceinline__ u64 bytes_of_nibbles(u32 nb) {
 
 // included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
 // whose bit is set in bmask; out of line: rare, and it touches no tile register.
-__device__ __noinline__ u32 list_mask(const KParams* Pp, u32 flags, u64 ji, u32 bmask, u32 slot0, u32 npl) {
+__device__ __noinline__ u64 list_mask(const KParams* Pp, u32 flags, u64 ji, u64 bmask, u32 slot0, u32 npl) {
   const u32* rec = Pp->jobrec + ji * kJobRecDwords;  // rare path: the list bounds are read from the record itself
   const u64 incl_b = ((u64)rec[kJrInclB + 1] << 32) | rec[kJrInclB], incl_e = ((u64)rec[kJrInclE + 1] << 32) | rec[kJrInclE];
   const u64 excl_b = ((u64)rec[kJrExclB + 1] << 32) | rec[kJrExclB], excl_e = ((u64)rec[kJrExclE + 1] << 32) | rec[kJrExclE];
-  u32 lm = 0;
+  u64 lm = 0;
   for (u32 r = 0; r < npl; ++r) {
-    if (!((bmask >> r) & 1u)) continue;
+    if (!((bmask >> r) & 1ull)) continue;
     const u32 n = Pp->slot_node[slot0 + r * kScan];
     bool okl = true;
     if ((flags & kJfIncl) && !in_list(Pp->incl_nodes, incl_b, incl_e, n)) okl = false;
     if ((flags & kJfExcl) && in_list(Pp->excl_nodes, excl_b, excl_e, n)) okl = false;
-    lm |= (okl ? 1u : 0u) << r;
+    lm |= (u64)(okl ? 1u : 0u) << r;
   }
   return lm;
 }
 
 template <u32 V> struct ModeTag { static constexpr u32 value = V; };
+template <bool Wide> struct RowMask { using type = u32; };
+template <> struct RowMask<true> { using type = u64; };
 
 template <int NPL>
 __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParams* __restrict__ Pg) {
@@ -1363,7 +1417,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ u64 s_win_c[2];     // winners of the next job as merged by the worker: [0] = A, [1] = T
   __shared__ u32 s_win_p[2];
   __shared__ u32 s_on[4];        // scan summary of this job's T winner (fcpu, mw, gn), posted by its owner lane
-  __shared__ i64 s_start;  // multi-node backfill: the common start time found by the worker
+  __shared__ u64 s_lc[(kWaves - 1) * kMultiK];  // multi-node jobs: per-wave sorted candidate lists (cost keys / slot codes)
+  __shared__ u32 s_lp[(kWaves - 1) * kMultiK];
+  __shared__ i64 s_nf[2 * kMultiK];             // ... and the next-fit exchange of the backfill fixed point
+  __shared__ int s_mode;                        // ... worker -> scanners: 1 start-now list complete, 2 need res_total lists, 3 res_total list complete, 0 give up
   __shared__ int s_flag;
   __shared__ int s_r0;   // worker -> scanners: this job may be followed by the worker-side merge
   __shared__ int s_nupd;
@@ -1534,75 +1591,77 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         job_to_lds(PG, ji, raw, &s_job);
         PROF_T(d1);
         PROF_ADD(24, d0, d1);  // job record -> LDS
-        if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1) {
-          // ---- multi-node job, parallel protocol: selection-only rounds among the scanners (no exact test
-          // in between), then the k candidates are verified and committed in parallel by the scanner waves
+        if (simple && F.k > 1 && F.k <= (u32)kMultiK && F.tmin == 1) {
+          // ---- multi-node job, parallel protocol: every scanner wave lists its k best candidates, the
+          // worker merges the 15 sorted lists into the first k nodes in cost order, then the candidates are
+          // verified and committed in parallel, one helper wave per node ----------------------------------
+          // k-way merge: lane w < 15 holds the head of wave w's list
+          auto merge_lists = [&]() -> u32 {
+            u32 idx = 0, n = 0;
+            u64 hc = lane < kWaves - 1 ? s_lc[lane * kMultiK] : ~0ull;
+            u32 hp = lane < kWaves - 1 ? s_lp[lane * kMultiK] : kNone;
+            for (u32 i = 0; i < F.k; ++i) {
+              u64 c = hc;
+              u32 pc = hp;
+              reduce16(c, pc);
+              if (pc == kNone) break;
+              if (lane == 0) {
+                HeapEnt x; x.ntasks = 0; x.p = pc; x.node = 0; x.pad = 0;
+                x.cost = __longlong_as_double((long long)c); x.res = res_zero();
+                s_heap[i] = x;
+              }
+              ++n;
+              if (lane == ((pc & 1023u) >> 6)) {  // the winning wave's list advances
+                ++idx;
+                hc = idx < F.k ? s_lc[lane * kMultiK + idx] : ~0ull;
+                hp = idx < F.k ? s_lp[lane * kMultiK + idx] : kNone;
+              }
+            }
+            return n;
+          };
           bool fallback = false;
-          u32 ncand = 0;
-          u64 cc = wc;
-          u32 ccode = wcode;
-          while (ccode != kNone) {   // mirror of the scanners' selection rounds
-            if (++ncand == F.k) break;
-            wg_barrier();
-            cc = s_wc[par][lane & (kWaves - 1)];
-            ccode = s_wp[par][lane & (kWaves - 1)];
-            reduce16(cc, ccode);
-            par ^= 1;
-            ccode = uni32(ccode);
-          }
+          wg_barrier();  // M1: start-now lists posted
+          u32 n = merge_lists();
+          if (lane == 0) s_mode = n == F.k ? 1 : 2;
           PROF_T(d2);
-          PROF_ADD(25, d1, d2);  // selection rounds (start-now candidates)
-          if (ncand == F.k) {  // k start-now candidates exist: exact tests run on the helpers
-            wg_barrier();  // Bv1: candidate list complete
-            wg_barrier();  // Bv2: verdicts in
-            PROF_T(d3);
-            PROF_ADD(26, d2, d3);  // helpers verify
-            u32 nok = 0;
-            for (u32 i = 0; i < F.k; ++i) nok += s_heap[i].ntasks != 0 ? 1u : 0u;
-            if (nok == F.k) {  // :6294-6297 reached with the first k nodes in cost order: start now (:6326)
-              if (lane == 0) { s_nupd = (int)F.k; P.o_start[F.orig] = P.now; P.o_reason[F.orig] = 0; }
-              wg_barrier();  // Bc: helpers committed
-              PROF_T(d4);
-              PROF_ADD(27, d3, d4);  // helpers commit
+          PROF_ADD(25, d1, d2);  // start-now lists + merge
+          wg_barrier();  // M2
+          if (n == F.k) {  // k start-now candidates exist (:6294-6297 if their exact tests pass)
+            if (multi_verify_commit(PG, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd)) {
+              if (lane == 0) { P.o_start[F.orig] = P.now; P.o_reason[F.orig] = 0; }  // :6326
               PROF_CNT(30);
             } else {
               fallback = true;  // a candidate failed its exact test (rare): redo this job sequentially
             }
-          } else {  // fewer than k nodes can start it now -> top-k by res_total + backfill (:6335-6376)
-            u32 nt = 0;
-            cc = tc;
-            ccode = tcode;
-            while (ccode != kNone) {
-              if (++nt == F.k) break;
-              wg_barrier();
-              cc = s_wc[par][lane & (kWaves - 1)];
-              ccode = s_wp[par][lane & (kWaves - 1)];
-              reduce16(cc, ccode);
-              par ^= 1;
-              ccode = uni32(ccode);
-            }
+            PROF_T(d3);
+            PROF_ADD(26, d2, d3);  // helpers verify + commit
+          } else {  // fewer than k nodes can start it now -> first k by res_total + backfill (:6335-6376)
+            wg_barrier();  // M5: res_total lists posted
+            n = merge_lists();
+            if (lane == 0) s_mode = n == F.k ? 3 : 0;
             PROF_T(d5);
-            PROF_ADD(28, d2, d5);  // selection rounds (res_total candidates)
-            if (nt == F.k) {
-              wg_barrier();  // Bt1: the k nodes are listed
+            PROF_ADD(28, d2, d5);  // res_total lists + merge
+            wg_barrier();  // M6
+            if (n == F.k) {
               int reason = 0;
-              const i64 st = multi_backfill(PG, &s_job, s_heap, qbeg, &reason);
+              const i64 st = multi_backfill_par(PG, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd, s_nf, &reason);
               PROF_T(d6);
-              PROF_ADD(29, d5, d6);  // common earliest start
+              PROF_ADD(29, d5, d6);  // common earliest start + commit
               PROF_CNT(31);
-              const int code = st != kInf ? 2 : 0;
               if (lane == 0) {
-                s_flag = code; s_start = st; s_nupd = (int)F.k;
-                if (code == 2) { P.o_start[F.orig] = st; P.o_reason[F.orig] = (uint8_t)reason; }
+                if (st != kInf) { P.o_start[F.orig] = st; P.o_reason[F.orig] = (uint8_t)reason; }
                 else { P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2; }  // "Resource", :6768
               }
-              wg_barrier();  // Bt2: decision + allocations visible
-              if (code == 2) wg_barrier();  // Bt3: helpers committed
             } else if (lane == 0) {
               P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2;  // not even k nodes fit res_total (:6335-6343)
             }
           }
           if (fallback) par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
+          PROF_T(p8);
+          PROF_ADD(6, d0, p8);
+          PROF_CNT(15);
+        } else if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1) {
+          par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);  // 15 < k <= 32: sequential protocol
           PROF_T(p8);
           PROF_ADD(6, d0, p8);
           PROF_CNT(15);
@@ -1661,6 +1720,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     // SCANNERS — register-resident node tile: slot p = r*960 + t, code = r<<10 | t
     // =============================================================================================
     const u32 t = tid - 64u;
+    using RM = typename RowMask<(NPL > 32)>::type;  // one bit per row of the lane
+    const RM kOne = 1;
     double cost[NPL];
     int fcpu[NPL];
     u32 mw[NPL];   // fmem GiB (16) | len (10) << 16 | type (6) << 26 ; len = 1023 marks "no node"
@@ -1688,12 +1749,12 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     //           refreshed by the owner update, the only place a length changes
     //   wave_types: node types present in this wave's tile (a job that fits all of them needs no per-row
     //           type test)
-    u32 okbits = 0;
+    RM okbits = 0;
     u64 wave_types = 0;
 #pragma unroll
     for (int r = 0; r < NPL; ++r) {
       const u32 len = (mw[r] >> 16) & 0x3FFu;
-      okbits |= (len < maxlen ? 1u : 0u) << r;  // "no node" rows carry len = 1023
+      okbits |= (RM)(len < maxlen ? 1u : 0u) << r;  // "no node" rows carry len = 1023
       if (len != 1023u) wave_types |= 1ull << (mw[r] >> 26);
     }
     wave_types = wave_or_u64(wave_types);
@@ -1755,7 +1816,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     };
 
     // argmin of (cost, code) over the lane's nodes whose bit is set in `mask`; ties keep the lower r
-    auto lane_argmin = [&](u32 mask, u64& bc, u32& bp) {
+    auto lane_argmin = [&](RM mask, u64& bc, u32& bp) {
       bc = ~0ull;
       u32 br = 0xFFu;
 #pragma unroll
@@ -1771,19 +1832,19 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     // Candidate sets of one job as per-lane bitmasks + their lane-local argmins.  Nothing the filters look
     // at changes during a job (commits happen at its end), so this runs ONCE per job.
     // `skip` masks out nodes whose state is about to change (speculative pre-scan, see below).
-    auto scan_job = [&](const ScanJob& S, u64 sji, u64 tyok, u32 skip, u32& bmask, u32& amask, u64& ac, u32& ap,
+    auto scan_job = [&](const ScanJob& S, u64 sji, u64 tyok, RM skip, RM& bmask, RM& amask, u64& ac, u32& ap,
                         u64& tcs, u32& tp) {
       // bmask in one go: static bits & type bits & not skipped
-      u32 tybits = (1u << NPL) - 1u;
+      RM tybits = (RM)(((u64)1 << NPL) - 1ull);
       if ((tyok & wave_types) != wave_types) {  // some type present here cannot host the job (uniform, rare)
         tybits = 0;
 #pragma unroll
-        for (int r = 0; r < NPL; ++r) tybits |= (u32)((tyok >> (mw[r] >> 26)) & 1ull) << r;
+        for (int r = 0; r < NPL; ++r) tybits |= (RM)((tyok >> (mw[r] >> 26)) & 1ull) << r;
       }
-      const u32 bl = (S.shape & 4u) ? (okbits & tybits & ~skip) : 0u;
+      const RM bl = (S.shape & 4u) ? (RM)(okbits & tybits & ~skip) : (RM)0;
       u32 gme = 0, gmo = 0;
       if (S.gmode & 2u) { gme = uni32(s_nme[S.gsel >> 8]); gmo = uni32(s_nmo[S.gsel >> 8]); }
-      u32 am = 0;
+      RM am = 0;
       ac = ~0ull; tcs = ~0ull;
       u32 ar = 0xFFu, tr = 0xFFu;
       // the row loop, specialised on the shape of the GRES request (job-uniform): 0 none, 1 short tests, 4 general
@@ -1821,7 +1882,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           const bool tt = b & (ck < tcs);
           tcs = tt ? ck : tcs;
           tr = tt ? (u32)r : tr;
-          am |= (a ? 1u : 0u) << r;
+          am |= (RM)(a ? 1u : 0u) << r;
         }
       };
       if (S.gmode == 0) rows(ModeTag<0>{});
@@ -1838,12 +1899,12 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           const u32 ty = w >> 26;
           const bool a = ((bmask >> r) & 1u) & (fcpu[r] >= s_ty_cpu[ty]) & ((w & 0xFFFFu) >= s_ty_m16[ty]) &
                          (gn[r] == s_ty_gn[ty]);
-          amask |= (a ? 1u : 0u) << r;
+          amask |= (RM)(a ? 1u : 0u) << r;
         }
         lane_argmin(amask, ac, ap);
       }
       if (S.flags & (kJfIncl | kJfExcl)) {  // included / excluded node lists (rare)
-        const u32 lm = list_mask(Pg, S.flags, sji, bmask, qbeg + t, (u32)NPL);
+        const RM lm = (RM)list_mask(Pg, S.flags, sji, bmask, qbeg + t, (u32)NPL);
         bmask &= lm;
         amask &= lm;
         lane_argmin(amask, ac, ap);
@@ -1856,11 +1917,11 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     ScanJob J = decode(raw, typeok);
     if (jbeg + 1 < jend) raw = fetch_job(P, jbeg + 1);
 
-    u32 bmask = 0, amask = 0;
+    RM bmask = 0, amask = 0;
     u64 ac = ~0ull, tcs = ~0ull;
     u32 ap = kNone, tp = kNone;
     // state carried from the previous iteration's pre-scan
-    u32 bmask_n = 0, amask_n = 0;
+    RM bmask_n = 0, amask_n = 0;
     bool pre_valid = false;  // the winners of this job came from the worker's merge of the pre-scan
     u64 wc = ~0ull, tc = ~0ull;
     u32 wcode = kNone, tcode = kNone;
@@ -1880,7 +1941,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           if (ufront) w = (w & ~0xFFFFu) | um16;
           cost[r] = own ? ucost : cost[r];
           mw[r] = own ? w : mw[r];
-          okbits = own ? ((okbits & ~(1u << r)) | ((ulen < maxlen ? 1u : 0u) << r)) : okbits;
+          okbits = own ? (RM)((okbits & ~(kOne << r)) | ((RM)(ulen < maxlen ? 1u : 0u) << r)) : okbits;
           fcpu[r] = (own && ufront) ? ucpu : fcpu[r];
           gn[r] = (own && ufront) ? ugn : gn[r];
         }
@@ -1900,8 +1961,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       bool b, a;
       row_pred(Sn, tyok_n, gme, gmo, w, fc, g, b, a);
       const bool own = (code & 1023u) == t;
-      bmask_n |= ((own & b) ? 1u : 0u) << rr;
-      amask_n |= ((own & a) ? 1u : 0u) << rr;
+      bmask_n |= (RM)((own & b) ? 1u : 0u) << rr;
+      amask_n |= (RM)((own & a) ? 1u : 0u) << rr;
     };
 
     u64 ji = jbeg;
@@ -1941,10 +2002,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       u64 typeok_n = typeok;
       const bool have_next = ji + 1 < jend;
       const bool spec_ok = !excl_job && !general && kk == 1;  // this job touches one node, a round-0 winner
-      u32 skipm = 0;
-      if ((wcode & 1023u) == t && wcode != kNone) skipm |= 1u << (wcode >> 10);
+      RM skipm = 0;
+      if ((wcode & 1023u) == t && wcode != kNone) skipm |= kOne << (wcode >> 10);
       if ((tcode & 1023u) == t && tcode != kNone) {
-        skipm |= 1u << (tcode >> 10);
+        skipm |= kOne << (tcode >> 10);
         const int rr = (int)(tcode >> 10);
 #pragma unroll
         for (int r = 0; r < NPL; ++r)
@@ -1966,88 +2027,53 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       PROF_ADDS(18, s2, s3);  // scanner: next-job prep + pre-scan (hidden behind the worker)
 
       int verdict = 0;
-      u32 used = 0;
+      RM used = 0;
       bool round0 = true;  // resolved without a second scan round
       bool sequential = true;  // run the one-candidate-per-round protocol below
-      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMaxUpd && (J.shape & 2u)) {
-        // ---- multi-node job, parallel protocol (mirror of the worker's): selection-only rounds, then this
-        // wave verifies / commits candidates i = wave-1, wave-1+15, ... as a helper ---------------------------
+      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMultiK && (J.shape & 2u)) {
+        // ---- multi-node job, parallel protocol (mirror of the worker's): this wave lists its k best
+        // candidates (sorted), the worker merges the lists, then wave i+1 verifies / commits candidate i ----
         sequential = false;
         round0 = false;
-        u32 ncand = 0;
-        u64 cc = wc;
-        u32 ccode = wcode;
-        while (ccode != kNone) {
-          if (tid == 64) {
-            HeapEnt x; x.ntasks = 0; x.p = ccode; x.node = 0; x.pad = 0;
-            x.cost = __longlong_as_double((long long)cc); x.res = res_zero();
-            s_heap[ncand] = x;
+        auto post_topk = [&](RM mask) {
+          RM m = mask;
+          bool dry = false;
+          for (u32 i = 0; i < kk; ++i) {
+            u64 c = ~0ull;
+            u32 pc = kNone;
+            if (!dry) {
+              lane_argmin(m, c, pc);
+              wave_argmin(c, pc);
+            }
+            if (lane == 0) { s_lc[(wave - 1) * kMultiK + i] = c; s_lp[(wave - 1) * kMultiK + i] = pc; }
+            if (pc == kNone) dry = true;
+            else if ((pc & 1023u) == t) m &= ~(kOne << (pc >> 10));
           }
-          if ((ccode & 1023u) == t) used |= 1u << (ccode >> 10);
-          if (++ncand == kk) break;
-          lane_argmin(amask & ~used, ac, ap);
-          wave_argmin(ac, ap);
-          if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; }
-          wg_barrier();
-          cc = s_wc[par][lane & (kWaves - 1)];
-          ccode = s_wp[par][lane & (kWaves - 1)];
-          reduce16(cc, ccode);
-          par ^= 1;
-        }
-        if (ncand == kk) {
-          wg_barrier();  // Bv1
-          for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_verify(PG, &s_job, s_heap, i, qbeg);
-          wg_barrier();  // Bv2
-          u32 nok = 0;
-          for (u32 i = 0; i < kk; ++i) nok += s_heap[i].ntasks != 0 ? 1u : 0u;
-          if (nok == kk) {
-            for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_commit(PG, &s_job, s_heap, i, qbeg, P.now, s_upd);
-            drain_stores();  // the worker reads these blocks again in later jobs
-            wg_barrier();  // Bc
+        };
+        post_topk(amask);
+        wg_barrier();  // M1
+        wg_barrier();  // M2: the worker merged the lists
+        if (s_mode == 1) {
+          if (multi_verify_commit(PG, &s_job, s_heap, wave - 1, wave - 1 < kk, qbeg, s_upd, &s_nupd)) {
             verdict = 2;
           } else {
             sequential = true;  // rare: fall back to the sequential protocol from round 0
-            used = 0;
           }
         } else {
-          u32 nt = 0;
-          used = 0;
-          cc = tc;
-          ccode = tcode;
-          while (ccode != kNone) {
-            if (tid == 64) {
-              HeapEnt x; x.ntasks = 1; x.p = ccode; x.node = 0; x.pad = 0;
-              x.cost = __longlong_as_double((long long)cc); x.res = res_zero();
-              s_heap[nt] = x;
-            }
-            if ((ccode & 1023u) == t) used |= 1u << (ccode >> 10);
-            if (++nt == kk) break;
-            lane_argmin(bmask & ~used, tcs, tp);
-            wave_argmin(tcs, tp);
-            if (lane == 0) { s_wc[par][wave] = tcs; s_wp[par][wave] = tp; }
-            wg_barrier();
-            cc = s_wc[par][lane & (kWaves - 1)];
-            ccode = s_wp[par][lane & (kWaves - 1)];
-            reduce16(cc, ccode);
-            par ^= 1;
-          }
-          if (nt == kk) {
-            wg_barrier();  // Bt1
-            wg_barrier();  // Bt2: the worker's backfill decision
-            if (s_flag == 2) {
-              const i64 st = s_start;
-              for (u32 i = wave - 1; i < kk; i += kWaves - 1) helper_commit(PG, &s_job, s_heap, i, qbeg, st, s_upd);
-              drain_stores();
-              wg_barrier();  // Bt3
-              verdict = 2;
-            }
+          post_topk(bmask);
+          wg_barrier();  // M5
+          wg_barrier();  // M6
+          if (s_mode == 3) {
+            int reason = 0;
+            const i64 st = multi_backfill_par(PG, &s_job, s_heap, wave - 1, wave - 1 < kk, qbeg, s_upd, &s_nupd, s_nf, &reason);
+            if (st != kInf) verdict = 2;
           }
         }
       }
       // ---- Phase A ----------------------------------------------------------------------------------
       u32 acode = wcode;
       while (sequential && acode != kNone) {
-        if ((acode & 1023u) == t) used |= 1u << (acode >> 10);
+        if ((acode & 1023u) == t) used |= kOne << (acode >> 10);
         wg_barrier();  // B2
         verdict = s_flag;
         if (verdict == 2) break;
@@ -2068,7 +2094,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           u32 nsel = 0;
           u32 ccode = tcode;
           while (ccode != kNone) {
-            if ((ccode & 1023u) == t) used |= 1u << (ccode >> 10);
+            if ((ccode & 1023u) == t) used |= kOne << (ccode >> 10);
             if (!general) {
               if (++nsel == kk) break;
             } else {
@@ -2122,13 +2148,12 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   }
 }
 
-#ifndef CNS_ONLY_NPL9
-template __global__ void k_select<1>(const KParams, const KParams*);
-template __global__ void k_select<2>(const KParams, const KParams*);
-template __global__ void k_select<3>(const KParams, const KParams*);
-template __global__ void k_select<5>(const KParams, const KParams*);
-template __global__ void k_select<18>(const KParams, const KParams*);
+#ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
+template __global__ void k_select<CNS_ONLY_NPL>(const KParams, const KParams*);
+#else
+#define CNS_INSTANTIATE(w) template __global__ void k_select<w>(const KParams, const KParams*);
+CNS_NPL_LIST(CNS_INSTANTIATE)
+#undef CNS_INSTANTIATE
 #endif
-template __global__ void k_select<9>(const KParams, const KParams*);
 
 }  // namespace cns
