@@ -271,8 +271,8 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   }
   part_off[P] = (u32)slot_node.size();
   const u32 S = (u32)slot_node.size();
-  if (max_np > (u32)(kBlock - 64) * (u32)CNS_NPL_MAX)
-    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string((kBlock - 64) * CNS_NPL_MAX) + " schedulable nodes");
+  if (max_np > kScan * (u32)CNS_NPL_MAX)
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(kScan * CNS_NPL_MAX) + " schedulable nodes");
   // node types = distinct res_total records
   std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
@@ -504,11 +504,11 @@ int cns_run_resident(cns_handle* h, int64_t now) {
   if (h->Jg) {
     const u32 np = h->max_np;
 #ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
-    if (np > (u32)(kBlock - 64) * CNS_ONLY_NPL) return fail(h, CNS_ERR_UNSUPPORTED, "experiment build: partition too large for its one tile width");
+    if (np > kScan * CNS_ONLY_NPL) return fail(h, CNS_ERR_UNSUPPORTED, "experiment build: partition too large for its one tile width");
     launch_select<CNS_ONLY_NPL>(h, K);
 #else
     bool launched = false;
-#define CNS_TRY_WIDTH(w) if (!launched && np <= (u32)(kBlock - 64) * (w)) { launch_select<w>(h, K); launched = true; }
+#define CNS_TRY_WIDTH(w) if (!launched && np <= kScan * (w)) { launch_select<w>(h, K); launched = true; }
     CNS_NPL_LIST(CNS_TRY_WIDTH)
 #undef CNS_TRY_WIDTH
     if (!launched) return fail(h, CNS_ERR_UNSUPPORTED, "partition too large for the widest register tile");

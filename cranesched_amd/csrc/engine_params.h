@@ -10,23 +10,27 @@
 
 namespace cns {
 
-// Threads of the per-partition workgroup.  512 = 8 wave64 = 2 waves per SIMD, i.e. 256 VGPRs per lane: the
+// The per-partition workgroup: 512 threads = 8 wave64 = 2 waves per SIMD, i.e. 256 VGPRs per lane — the
 // register-resident node tile and the worker's state fit without spills (at 1024 threads the 128-VGPR cap
-// made the hot loops spill whenever cold code changed), and the worker shares its SIMD with one scanner only.
-#ifndef CNS_BLOCK
-#define CNS_BLOCK 512
+// made the hot loops spill whenever cold code changed).  Wave 0 is the worker, waves 1..7 scan.
+// Waves w and w+4 share a SIMD and the issue arbiter favours the older wave, so wave 4 scans in the
+// worker's issue gaps; measured on C4 / C5 that still beats leaving it without nodes (kIdleWave = 4:
+// 786 vs 742 ms), so every non-worker wave holds nodes (kIdleWave = kWaves = none).
+constexpr int kBlock = 512;
+#ifndef CNS_IDLE_WAVE
+#define CNS_IDLE_WAVE 8
 #endif
-constexpr int kBlock = CNS_BLOCK;
+constexpr int kIdleWave = CNS_IDLE_WAVE;     // a wave without nodes (8 = none); it still follows the protocol
+constexpr int kScanWaves = kBlock / 64 - 1 - (kIdleWave < kBlock / 64 ? 1 : 0);
+constexpr unsigned kScan = kScanWaves * 64;  // scanner lanes = nodes per tile row
 // Tile widths (nodes per scanner lane) the selection kernel is instantiated for; a partition uses the
-// smallest width w with (kWaves - 1) * 64 * w >= its node count.
-#if CNS_BLOCK == 512
+// smallest width w with kScan * w >= its node count.
+#if CNS_IDLE_WAVE < 8
+#define CNS_NPL_LIST(X) X(1) X(3) X(11) X(22) X(43)
+#define CNS_NPL_MAX 43
+#else
 #define CNS_NPL_LIST(X) X(1) X(3) X(10) X(19) X(39)
 #define CNS_NPL_MAX 39
-#elif CNS_BLOCK == 1024
-#define CNS_NPL_LIST(X) X(1) X(2) X(3) X(5) X(9) X(18)
-#define CNS_NPL_MAX 18
-#else
-#error "CNS_BLOCK must be 512 or 1024 (the wave count must be a power of two)"
 #endif
 constexpr int kWaves = kBlock / 64;
 constexpr u32 kTlCap = 1008;         // >= kAlgoMaxJobNumPerNode - 1 + 2 entries per node

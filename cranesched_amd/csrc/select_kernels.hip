@@ -428,8 +428,13 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
   rec[kJdTyok] = (u32)tyok; rec[kJdTyok + 1] = (u32)(tyok >> 32);
 }
 
-constexpr u32 kScan = (kWaves - 1) * 64;  // scanner lanes
+// slot code = row << 10 | t, t = scanner lane 0..kScan-1; partition-local slot = row * kScan + t
 __device__ __forceinline__ u32 slot_of_code(u32 code) { return (code >> 10) * kScan + (code & 1023u); }
+// wave that owns the slot: scanner index t / 64 -> waves 1,2,3,5,6,7 (wave kIdleWave holds no nodes)
+__device__ __forceinline__ u32 owner_wave(u32 code) {
+  const u32 sid = (code & 1023u) >> 6;
+  return sid + 1u + (sid + 1u >= (u32)kIdleWave ? 1u : 0u);
+}
 
 // ---------------------------------------------------------------------------------------------
 // worker routines (all 64 lanes of wave 0 execute them)
@@ -1405,6 +1410,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   const u32 nn = P.part_off[part + 1] - qbeg;
   const u64 jbeg = P.pj_off[part], jend = P.pj_off[part + 1];
   if (jbeg >= jend) return;
+#ifdef CNS_HWID
+  if (lane == 0 && part == 0) printf("wave %u hw_id %08x simd %u\n", wave, (unsigned)__builtin_amdgcn_s_getreg(63492), ((unsigned)__builtin_amdgcn_s_getreg(63492) >> 4) & 3u);
+#endif
 
   __shared__ u64 s_wc[2][kWaves];
   __shared__ u32 s_wp[2][kWaves];
@@ -1460,7 +1468,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     HeapEnt* const gheap = P.heap + qbeg + part;
     // The worker is the serial chain of the whole partition and shares its SIMD with three scanner waves
     // that pre-scan the next job at the same time: let its instructions issue first.
+#ifndef CNS_NO_PRIO
     __builtin_amdgcn_s_setprio(3);
+#endif
     if (lane == 0) { s_pc[0] = ~0ull; s_pp[0] = kNone; s_ptc[0] = ~0ull; s_ptp[0] = kNone; }
     u32 raw = fetch_job(P, jbeg);       // record of the job being processed
     u32 raw_n = jbeg + 1 < jend ? fetch_job(P, jbeg + 1) : 0u;  // next job's record: in flight during this job
@@ -1611,7 +1621,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
                 s_heap[i] = x;
               }
               ++n;
-              if (lane == ((pc & 1023u) >> 6)) {  // the winning wave's list advances
+              if (lane == owner_wave(pc) - 1u) {  // the winning wave's list advances
                 ++idx;
                 hc = idx < F.k ? s_lc[lane * kMultiK + idx] : ~0ull;
                 hp = idx < F.k ? s_lp[lane * kMultiK + idx] : kNone;
@@ -1719,7 +1729,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     // =============================================================================================
     // SCANNERS — register-resident node tile: slot p = r*960 + t, code = r<<10 | t
     // =============================================================================================
-    const u32 t = tid - 64u;
+    const bool idle = wave == (u32)kIdleWave;  // the worker's SIMD mate: no nodes, follows the barriers, helps with multi-node jobs
+    const u32 t = idle ? 1023u : (wave - 1u - (wave > (u32)kIdleWave ? 1u : 0u)) * 64u + lane;
     using RM = typename RowMask<(NPL > 32)>::type;  // one bit per row of the lane
     const RM kOne = 1;
     double cost[NPL];
@@ -1729,7 +1740,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 #pragma unroll
     for (int r = 0; r < NPL; ++r) {
       const u32 p = (u32)r * kScan + t;
-      if (p < nn) {
+      if (!idle && p < nn) {
         const u32 q = qbeg + p;
         const NodeHdr* hd = hdr_of(P, q);
         cost[r] = P.cost[q];
@@ -1834,6 +1845,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     // `skip` masks out nodes whose state is about to change (speculative pre-scan, see below).
     auto scan_job = [&](const ScanJob& S, u64 sji, u64 tyok, RM skip, RM& bmask, RM& amask, u64& ac, u32& ap,
                         u64& tcs, u32& tp) {
+      if (idle) { bmask = 0; amask = 0; ac = ~0ull; ap = kNone; tcs = ~0ull; tp = kNone; return; }
       // bmask in one go: static bits & type bits & not skipped
       RM tybits = (RM)(((u64)1 << NPL) - 1ull);
       if ((tyok & wave_types) != wave_types) {  // some type present here cannot host the job (uniform, rare)
@@ -1974,8 +1986,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       if (!pre_valid) {
         // ---- full scan of this job, publish both argmins ------------------------------------------------
         scan_job(J, ji, typeok, 0u, bmask, amask, ac, ap, tcs, tp);
-        wave_argmin(ac, ap);
-        wave_argmin(tcs, tp);
+        if (!idle) {
+          wave_argmin(ac, ap);
+          wave_argmin(tcs, tp);
+        }
         if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; s_tc[wave] = tcs; s_tp[wave] = tp; }
         wg_barrier();  // B1
         wc = s_wc[par][lane & (kWaves - 1)];
@@ -2018,8 +2032,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           u64 pc, ptc;
           u32 pp, ptp;
           scan_job(Jn, ji + 1, typeok_n, skipm, bmask_n, amask_n, pc, pp, ptc, ptp);
-          wave_argmin(pc, pp);
-          wave_argmin(ptc, ptp);
+          if (!idle) {
+            wave_argmin(pc, pp);
+            wave_argmin(ptc, ptp);
+          }
           if (lane == 0) { s_pc[wave] = pc; s_pp[wave] = pp; s_ptc[wave] = ptc; s_ptp[wave] = ptp; }
         }
       }
@@ -2037,7 +2053,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         round0 = false;
         auto post_topk = [&](RM mask) {
           RM m = mask;
-          bool dry = false;
+          bool dry = idle;
           for (u32 i = 0; i < kk; ++i) {
             u64 c = ~0ull;
             u32 pc = kNone;
@@ -2124,14 +2140,14 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         const UpdRec* const ub = nu <= kMaxUpd ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
         for (int i = 0; i < nu; ++i) {
           const u32 up = uni32(ub[i].p);
-          if (((up & 1023u) >> 6) + 1u == wave) apply_upd(ub[i], up);  // only the owner's wave does any work
+          if (owner_wave(up) == wave) apply_upd(ub[i], up);  // only the owner's wave does any work
         }
       }
       pre_valid = have_next && spec_ok && round0 && !(Jn.flags & (kJfExclusive | kJfIncl | kJfExcl));
       if (pre_valid) {
         // complete the next job's pre-scanned sets with the nodes its pre-scan had to skip
-        if (wcode != kNone && ((wcode & 1023u) >> 6) + 1u == wave) fix_row(Jn, typeok_n, wcode);
-        if (tcode != kNone && tcode != wcode && ((tcode & 1023u) >> 6) + 1u == wave) fix_row(Jn, typeok_n, tcode);
+        if (wcode != kNone && owner_wave(wcode) == wave) fix_row(Jn, typeok_n, wcode);
+        if (tcode != kNone && tcode != wcode && owner_wave(tcode) == wave) fix_row(Jn, typeok_n, tcode);
       }
       PROF_T(s5);
       PROF_ADDS(20, s4, s5);  // scanner: owner update + completion of the pre-scanned sets
