@@ -15,17 +15,24 @@ namespace cns {
 // made the hot loops spill whenever cold code changed).  Wave 0 is the worker, waves 1..7 scan.
 // Waves w and w+4 share a SIMD and the issue arbiter favours the older wave, so wave 4 scans in the
 // worker's issue gaps; measured on C4 / C5 that still beats leaving it without nodes (kIdleWave = 4:
-// 786 vs 742 ms), so every non-worker wave holds nodes (kIdleWave = kWaves = none).
-constexpr int kBlock = 512;
-#ifndef CNS_IDLE_WAVE
-#define CNS_IDLE_WAVE 8
+// 786 vs 742 ms), so every non-worker wave holds nodes (kIdleWave >= kWaves: none).
+#ifndef CNS_BLOCK
+#define CNS_BLOCK 512
 #endif
-constexpr int kIdleWave = CNS_IDLE_WAVE;     // a wave without nodes (8 = none); it still follows the protocol
+constexpr int kBlock = CNS_BLOCK;            // 512 (2 waves / SIMD, 256 VGPRs); 768 (3 / SIMD, 168 VGPRs) measured 3 % slower
+constexpr int kRed = 16;                     // width of the per-wave result exchange (reduce16): >= kWaves
+#ifndef CNS_IDLE_WAVE
+#define CNS_IDLE_WAVE 99
+#endif
+constexpr int kIdleWave = CNS_IDLE_WAVE;     // a wave without nodes (>= kWaves: none); it still follows the protocol
 constexpr int kScanWaves = kBlock / 64 - 1 - (kIdleWave < kBlock / 64 ? 1 : 0);
 constexpr unsigned kScan = kScanWaves * 64;  // scanner lanes = nodes per tile row
 // Tile widths (nodes per scanner lane) the selection kernel is instantiated for; a partition uses the
 // smallest width w with kScan * w >= its node count.
-#if CNS_IDLE_WAVE < 8
+#if CNS_BLOCK == 768
+#define CNS_NPL_LIST(X) X(1) X(3) X(6) X(12) X(24)
+#define CNS_NPL_MAX 24
+#elif CNS_IDLE_WAVE < 8
 #define CNS_NPL_LIST(X) X(1) X(3) X(11) X(22) X(43)
 #define CNS_NPL_MAX 43
 #else
@@ -35,7 +42,7 @@ constexpr unsigned kScan = kScanWaves * 64;  // scanner lanes = nodes per tile r
 constexpr int kWaves = kBlock / 64;
 constexpr u32 kTlCap = 1008;         // >= kAlgoMaxJobNumPerNode - 1 + 2 entries per node
 constexpr int kMaxUpd = 32;          // per-job owner updates broadcast through LDS
-constexpr int kMultiK = kWaves;      // node_num handled by the parallel multi-node protocol (one helper wave per node, the worker included)
+constexpr int kMultiK = kWaves < 8 ? kWaves : 8;      // node_num handled by the parallel multi-node protocol (one helper wave per node, the worker included)
 constexpr int kLdsHeap = 33;         // heap / pick entries kept in LDS when node_num < this
 constexpr i64 kInf = INT64_MAX;      // absl::InfiniteFuture()
 constexpr u32 kNone = 0xFFFFFFFFu;

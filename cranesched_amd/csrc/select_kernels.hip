@@ -851,8 +851,8 @@ __device__ __noinline__ bool distribute_and_alloc(const KParams& P, const JobCtx
 //                 W: allocations vs res_total, earliest start, commit -> verdict       B3
 // ---------------------------------------------------------------------------------------------
 struct WorkerShared {
-  u64 (*wc)[kWaves];
-  u32 (*wp)[kWaves];
+  u64 (*wc)[kRed];
+  u32 (*wp)[kRed];
   int* flag;
   int* nupd;
   UpdRec* upd;
@@ -947,8 +947,8 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     wg_barrier();  // B2: verdict (and, on success, the owner updates) visible to the scanners
     if (code == 2) return par;
     wg_barrier();  // B1 of the next round
-    wc = sh.wc[par][lane & (kWaves - 1)];
-    wcode = sh.wp[par][lane & (kWaves - 1)];
+    wc = sh.wc[par][lane & (kRed - 1)];
+    wcode = sh.wp[par][lane & (kRed - 1)];
     reduce16(wc, wcode);
     par ^= 1;
     wc = uni64(wc); wcode = uni32(wcode);
@@ -990,8 +990,8 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       if (stop) { complete = true; break; }
     }
     wg_barrier();  // B1
-    cc = sh.wc[par][lane & (kWaves - 1)];
-    ccode = sh.wp[par][lane & (kWaves - 1)];
+    cc = sh.wc[par][lane & (kRed - 1)];
+    ccode = sh.wp[par][lane & (kRed - 1)];
     reduce16(cc, ccode);
     par ^= 1;
     cc = uni64(cc); ccode = uni32(ccode);
@@ -1139,8 +1139,8 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
     wg_barrier();  // B2
     if (code == 2) return par;
     wg_barrier();  // B1 of the next round
-    wc = sh.wc[par][lane & (kWaves - 1)];
-    wcode = sh.wp[par][lane & (kWaves - 1)];
+    wc = sh.wc[par][lane & (kRed - 1)];
+    wcode = sh.wp[par][lane & (kRed - 1)];
     reduce16(wc, wcode);
     par ^= 1;
     wc = uni64(wc); wcode = uni32(wcode);
@@ -1161,8 +1161,8 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
     ++nsel;
     if (nsel == J.k) { complete = true; break; }
     wg_barrier();  // B1
-    cc = sh.wc[par][lane & (kWaves - 1)];
-    ccode = sh.wp[par][lane & (kWaves - 1)];
+    cc = sh.wc[par][lane & (kRed - 1)];
+    ccode = sh.wp[par][lane & (kRed - 1)];
     reduce16(cc, ccode);
     par ^= 1;
     cc = uni64(cc); ccode = uni32(ccode);
@@ -1414,14 +1414,14 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   if (lane == 0 && part == 0) printf("wave %u hw_id %08x simd %u\n", wave, (unsigned)__builtin_amdgcn_s_getreg(63492), ((unsigned)__builtin_amdgcn_s_getreg(63492) >> 4) & 3u);
 #endif
 
-  __shared__ u64 s_wc[2][kWaves];
-  __shared__ u32 s_wp[2][kWaves];
-  __shared__ u64 s_tc[kWaves];
-  __shared__ u32 s_tp[kWaves];
-  __shared__ u64 s_pc[kWaves];   // pre-scan of the NEXT job: per-wave A / T argmins over the nodes that
-  __shared__ u32 s_pp[kWaves];   // cannot change (everything but this job's round-0 winners)
-  __shared__ u64 s_ptc[kWaves];
-  __shared__ u32 s_ptp[kWaves];
+  __shared__ u64 s_wc[2][kRed];
+  __shared__ u32 s_wp[2][kRed];
+  __shared__ u64 s_tc[kRed];
+  __shared__ u32 s_tp[kRed];
+  __shared__ u64 s_pc[kRed];   // pre-scan of the NEXT job: per-wave A / T argmins over the nodes that
+  __shared__ u32 s_pp[kRed];   // cannot change (everything but this job's round-0 winners)
+  __shared__ u64 s_ptc[kRed];
+  __shared__ u32 s_ptp[kRed];
   __shared__ u64 s_win_c[2];     // winners of the next job as merged by the worker: [0] = A, [1] = T
   __shared__ u32 s_win_p[2];
   __shared__ u32 s_on[4];        // scan summary of this job's T winner (fcpu, mw, gn), posted by its owner lane
@@ -1450,9 +1450,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     // =============================================================================================
     // WORKER
     // =============================================================================================
-    if (lane == 0) {
-      s_wc[0][0] = ~0ull; s_wc[1][0] = ~0ull; s_wp[0][0] = kNone; s_wp[1][0] = kNone;
-      s_tc[0] = ~0ull; s_tp[0] = kNone;
+    if (lane < (u32)kRed && (lane == 0 || lane >= (u32)kWaves)) {  // exchange slots no scanner writes: identity
+      s_wc[0][lane] = ~0ull; s_wc[1][lane] = ~0ull; s_wp[0][lane] = kNone; s_wp[1][lane] = kNone;
+      s_tc[lane] = ~0ull; s_tp[lane] = kNone;
+      s_pc[lane] = ~0ull; s_pp[lane] = kNone; s_ptc[lane] = ~0ull; s_ptp[lane] = kNone;
     }
     s_ty_cpu[lane] = clamp_cpu(ttot.cpu);
     s_ty_m16[lane] = mem_gib16(mem_mib_ceil(ttot.mem));
@@ -1471,7 +1472,6 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 #ifndef CNS_NO_PRIO
     __builtin_amdgcn_s_setprio(3);
 #endif
-    if (lane == 0) { s_pc[0] = ~0ull; s_pp[0] = kNone; s_ptc[0] = ~0ull; s_ptp[0] = kNone; }
     u32 raw = fetch_job(P, jbeg);       // record of the job being processed
     u32 raw_n = jbeg + 1 < jend ? fetch_job(P, jbeg + 1) : 0u;  // next job's record: in flight during this job
     bool pre_valid = false;   // winners of this job already known from the previous iteration's merge
@@ -1486,10 +1486,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 
       if (!pre_valid) {
         wg_barrier();  // B1 (round 0): A and T argmins published by the scanners
-        wc = s_wc[par][lane & (kWaves - 1)];
-        wcode = s_wp[par][lane & (kWaves - 1)];
-        tc = s_tc[lane & (kWaves - 1)];
-        tcode = s_tp[lane & (kWaves - 1)];
+        wc = s_wc[par][lane & (kRed - 1)];
+        wcode = s_wp[par][lane & (kRed - 1)];
+        tc = s_tc[lane & (kRed - 1)];
+        tcode = s_tp[lane & (kRed - 1)];
         reduce16(wc, wcode);
         reduce16(tc, tcode);
         par ^= 1;
@@ -1544,8 +1544,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_CNT(14);         // rejected candidate
           round0 = false;
           wg_barrier();  // B1 of the next round
-          wc = s_wc[par][lane & (kWaves - 1)];
-          wcode = s_wp[par][lane & (kWaves - 1)];
+          wc = s_wc[par][lane & (kRed - 1)];
+          wcode = s_wp[par][lane & (kRed - 1)];
           reduce16(wc, wcode);
           par ^= 1;
           wc = uni64(wc); wcode = uni32(wcode);
@@ -1693,10 +1693,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl));
       if (nv) {
         const FastJob Fn = make_fast_job(P, raw);
-        u64 ac = s_pc[lane & (kWaves - 1)];
-        u32 ap = s_pp[lane & (kWaves - 1)];
-        u64 tcs = s_ptc[lane & (kWaves - 1)];
-        u32 tp = s_ptp[lane & (kWaves - 1)];
+        u64 ac = s_pc[lane & (kRed - 1)];
+        u32 ap = s_pp[lane & (kRed - 1)];
+        u64 tcs = s_ptc[lane & (kRed - 1)];
+        u32 tp = s_ptp[lane & (kRed - 1)];
         reduce16(ac, ap);
         reduce16(tcs, tp);
         ac = uni64(ac); ap = uni32(ap); tcs = uni64(tcs); tp = uni32(tp);
@@ -1992,10 +1992,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         }
         if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; s_tc[wave] = tcs; s_tp[wave] = tp; }
         wg_barrier();  // B1
-        wc = s_wc[par][lane & (kWaves - 1)];
-        wcode = s_wp[par][lane & (kWaves - 1)];
-        tc = s_tc[lane & (kWaves - 1)];
-        tcode = s_tp[lane & (kWaves - 1)];
+        wc = s_wc[par][lane & (kRed - 1)];
+        wcode = s_wp[par][lane & (kRed - 1)];
+        tc = s_tc[lane & (kRed - 1)];
+        tcode = s_tp[lane & (kRed - 1)];
         reduce16(wc, wcode);
         reduce16(tc, tcode);
         par ^= 1;
@@ -2098,8 +2098,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         wave_argmin(ac, ap);
         if (lane == 0) { s_wc[par][wave] = ac; s_wp[par][wave] = ap; }
         wg_barrier();  // B1
-        u64 c2 = s_wc[par][lane & (kWaves - 1)];
-        acode = s_wp[par][lane & (kWaves - 1)];
+        u64 c2 = s_wc[par][lane & (kRed - 1)];
+        acode = s_wp[par][lane & (kRed - 1)];
         reduce16(c2, acode);
         par ^= 1;
       }
@@ -2121,8 +2121,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             wave_argmin(tcs, tp);
             if (lane == 0) { s_wc[par][wave] = tcs; s_wp[par][wave] = tp; }
             wg_barrier();  // B1
-            u64 cc = s_wc[par][lane & (kWaves - 1)];
-            ccode = s_wp[par][lane & (kWaves - 1)];
+            u64 cc = s_wc[par][lane & (kRed - 1)];
+            ccode = s_wp[par][lane & (kRed - 1)];
             reduce16(cc, ccode);
             par ^= 1;
           }
