@@ -78,3 +78,22 @@ def test_deep_backfill_long_time_maps(engine_cls, name, J, N):
 def test_deep_backfill_heterogeneous(engine_cls):
     c, j, now, run = helpers.random_case(11, N=10, J=2500, P=1, running=6)
     _run(engine_cls, c, j, now, running=run, tag="deep hetero")
+
+
+@pytest.mark.parametrize("seed", [7, 8])
+def test_wide_multi_node_jobs(engine_cls, seed):
+    # node_num from 2 to 40 on a small cluster: the parallel helper protocol (k <= 8, start-now and common
+    # earliest start), the sequential one-candidate-per-round protocol (9..32) and the general path (> 32),
+    # interleaved with single-node jobs so that the pre-scan pipeline is broken and refilled all the time
+    c, j, now, run = helpers.random_case(seed, N=160, J=500, P=2, running=30, general=False, lists=False,
+                                         exclusive=False)
+    rng = np.random.default_rng(1000 + seed)
+    wide = rng.random(j.num_jobs) < 0.35
+    k = np.where(wide, rng.choice([2, 3, 5, 8, 9, 12, 16, 31, 32, 33, 40], j.num_jobs), j.node_num).astype(np.uint32)
+    j.node_num[:] = k
+    j.ntasks[:] = k
+    j.ntasks_per_node_min[:] = 1
+    j.ntasks_per_node_max[:] = 1
+    got, _ = _run(engine_cls, c, j, now, running=run, tag=f"wide{seed}")
+    r = got.reason[:j.num_jobs]
+    assert ((r == 0) & wide).sum() > 10 and ((r == 1) & wide).sum() > 10, "wide jobs must start now and backfill"
