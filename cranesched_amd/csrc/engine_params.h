@@ -36,8 +36,8 @@ constexpr unsigned kScan = kScanWaves * 64;  // scanner lanes = nodes per tile r
 #define CNS_NPL_LIST(X) X(1) X(3) X(11) X(22) X(43)
 #define CNS_NPL_MAX 43
 #else
-#define CNS_NPL_LIST(X) X(1) X(3) X(10) X(19) X(39)
-#define CNS_NPL_MAX 39
+#define CNS_NPL_LIST(X) X(1) X(3) X(10) X(19) X(28) X(37)
+#define CNS_NPL_MAX 37
 #endif
 constexpr int kWaves = kBlock / 64;
 constexpr u32 kTlCap = 1008;         // >= kAlgoMaxJobNumPerNode - 1 + 2 entries per node

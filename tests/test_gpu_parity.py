@@ -58,9 +58,9 @@ def test_batch_limit(engine_cls):
     assert (got.reason[400:1000] == 1).all()
 
 
-@pytest.mark.parametrize("N", [380, 1100, 4100, 8192, 10000])
+@pytest.mark.parametrize("N", [380, 1100, 4100, 8192, 10000, 13000])
 def test_tile_widths(engine_cls, N):
-    # every register-tile width (nodes per scanner lane 1,3,10,19,39 at 7 scanner waves)
+    # every register-tile width (nodes per scanner lane 1,3,10,19,28,37 at 7 scanner waves)
     c, j, now = synth.make_config("C3", J=3000, N=(N // 4) * 4, P=1)
     _run(engine_cls, c, j, now, tag=f"tile N={N}")
 
