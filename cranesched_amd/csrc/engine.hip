@@ -18,8 +18,11 @@
 #include <vector>
 
 #include "../../include/crane_gpu/node_select.h"
+#include "../../include/crane_gpu/priority.h"
+#include <limits>
 #include "engine_params.h"
 #include "select_kernels.hip"  // single translation unit: kernels + their launches (no -fgpu-rdc needed)
+#include "priority_kernels.hip"
 
 using namespace cns;
 
@@ -69,6 +72,10 @@ struct cns_engine {
   struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, total; } ro{};
   cns_timing timing{};
   i64 last_now = 0;
+  // MultiFactorPriority (priority_host.inc)
+  DevBuf d_prio[27];
+  double prio_ms = 0.0;
+  u64 prio_bytes = 0;
 };
 
 namespace {
@@ -213,6 +220,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_gupd, &h->d_fault, &h->d_pj_off, &h->d_jobs,
                     &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof})
     b->release();
+  for (DevBuf& b : h->d_prio) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -628,5 +636,7 @@ int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint
   }
   return CNS_OK;
 }
+
+#include "priority_host.inc"
 
 }  // extern "C"

@@ -28,6 +28,8 @@ ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy",
                "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
                "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline",
                "cns_debug_get_prof")
+# ... and include/crane_gpu/priority.h
+PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
 
 
 class EngineError(RuntimeError):
@@ -75,6 +77,28 @@ class GpuNodeSelector:
         if rc != 0:
             msg = self._L.cns_last_error(self._h)
             raise EngineError(rc, msg.decode() if msg else "")
+
+    # -- MultiFactorPriority (include/crane_gpu/priority.h) ---------------------------------------
+    def priority_order(self, now: int, cfg, num_accounts: int, pending, running=None, limit: int | None = None):
+        """IPrioritySorter::GetOrderedJobPtrVec for PriorityType multifactor (JobScheduler.cpp:7606-7631).
+        Returns (order, priority, num_ordered): order[i] = input index of the i-th job by descending priority
+        (ties: ascending index), priority[j] per input job, num_ordered = min(J, limit)."""
+        J = pending.num_jobs
+        order = np.empty(max(J, 1), np.uint32)
+        prio = np.empty(max(J, 1), np.float64)
+        nord = C.c_uint64(0)
+        c_cfg, c_pd = cfg.to_c(), pending.to_c()
+        c_rn = running.to_c() if running is not None else None
+        self._check(self._L.cns_priority_order(
+            self._h, C.c_int64(now), C.byref(c_cfg), C.c_uint32(num_accounts), C.byref(c_pd),
+            C.byref(c_rn) if c_rn is not None else None, C.c_uint64(J if limit is None else limit),
+            order.ctypes.data_as(C.c_void_p), prio.ctypes.data_as(C.c_void_p), C.byref(nord)))
+        return order[:J], prio[:J], int(nord.value)
+
+    def priority_timing(self):
+        ms, nb = C.c_double(0), C.c_uint64(0)
+        self._check(self._L.cns_priority_timing(self._h, C.byref(ms), C.byref(nb)))
+        return {"kernels_ms": ms.value, "algorithmic_bytes": int(nb.value)}
 
     def close(self):
         if self._h:

@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "../../include/crane_gpu/node_select.h"
+#include "../../include/crane_gpu/priority.h"
 
 namespace crane {
 
@@ -76,6 +77,7 @@ GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(int device, uint64_t scheduled_batch_
   cfg.abi_version = CNS_ABI_VERSION;
   cfg.device = device;
   cfg.scheduled_batch_size = scheduled_batch_size;
+  batch_ = scheduled_batch_size;
   status_ = cns_create(&cfg, &impl_->h);
   if (status_ != 0) error_ = cns_last_error(nullptr);
 }
@@ -196,15 +198,22 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   int st = cns_set_running(I.h, rs.num_jobs ? &rs : nullptr);
   if (st != 0) return fail_all(st, cns_last_error(I.h));
 
-  // ---- pending jobs -------------------------------------------------------------------------------------
-  const size_t J = pending_jobs.size();
+  // ---- pending jobs, in the sorter's order (JobScheduler.cpp:6735) ---------------------------------------
+  std::vector<PdJobInScheduler*> ord;
+  if (sorter_) {
+    sorter_->GetOrderedJobPtrVec(now, pending_jobs, running_jobs, batch_ ? (size_t)batch_ : pending_jobs.size(), ord);
+  } else {
+    ord.reserve(pending_jobs.size());
+    for (const auto& j : pending_jobs) ord.push_back(j.get());
+  }
+  const size_t J = ord.size();
   std::vector<uint32_t> part(J), k(J), nt(J), tmin(J), tmax(J);
   std::vector<int64_t> L(J), ncpu(J), tcpu(J);
   std::vector<uint64_t> nmem(J), tmem(J), ioff{0}, eoff{0};
   std::vector<uint8_t> excl(J), skip(J), gtot(J * CNS_MAX_GRES_NAMES, 0), gspec(J * CNS_MAX_GRES_CLASSES, 0);
   std::vector<uint32_t> inodes, enodes;
   for (size_t j = 0; j < J; ++j) {
-    const PdJobInScheduler& p = *pending_jobs[j];
+    const PdJobInScheduler& p = *ord[j];
     auto pit = I.part_idx.find(p.partition_id);
     part[j] = pit == I.part_idx.end() ? 0xFFFFFFFFu : pit->second;  // -> "Partition Not Found" (cpp:6748-6752)
     L[j] = p.time_limit;
@@ -259,7 +268,7 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
 
   // ---- write back (what JobScheduler.cpp:1492-1600 consumes) --------------------------------------------
   for (size_t j = 0; j < J; ++j) {
-    PdJobInScheduler& p = *pending_jobs[j];
+    PdJobInScheduler& p = *ord[j];
     const uint8_t r = o_reason[j];
     if (r == CNS_REASON_SKIPPED) continue;  // the caller's reason stays
     p.reason = kReasonStr[r];
@@ -276,6 +285,80 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
       res.memory_sw_bytes = p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o_nt[q];
       p.allocated_res[cid] = std::move(res);
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// GpuMultiFactorPriority
+// ---------------------------------------------------------------------------------------------------------
+GpuMultiFactorPriority::GpuMultiFactorPriority(const PriorityConfig& cfg, int device) : cfg_(cfg) {
+  cns_config c{};
+  c.abi_version = CNS_ABI_VERSION;
+  c.device = device;
+  status_ = cns_create(&c, &h_);
+  if (status_ != 0) error_ = cns_last_error(nullptr);
+}
+GpuMultiFactorPriority::~GpuMultiFactorPriority() {
+  if (h_) cns_destroy(h_);
+}
+
+void GpuMultiFactorPriority::GetOrderedJobPtrVec(const TimeSec& now,
+                                                 const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                                 const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
+                                                 size_t limit, std::vector<PdJobInScheduler*>& job_ptr_vec) {
+  const size_t J = pending_jobs.size(), R = running_jobs.size();
+  job_ptr_vec.clear();
+  job_ptr_vec.reserve(J);
+  auto keep_input_order = [&](int st, const std::string& msg) {
+    status_ = st; error_ = msg;
+    for (const auto& j : pending_jobs) job_ptr_vec.push_back(j.get());
+  };
+  if (!h_) return keep_input_order(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
+  // dense account ids (the reference keys its service-value map by account name, cpp:7667,7744)
+  std::unordered_map<std::string, uint32_t> acc_id;
+  auto id_of = [&](const std::string& a) { return acc_id.emplace(a, (uint32_t)acc_id.size()).first->second; };
+  std::vector<int64_t> submit(J), cpu(J), r_start(R), r_cpu(R);
+  std::vector<uint32_t> qos(J), part(J), nn(J), acc(J), r_qos(R), r_part(R), r_nn(R), r_acc(R);
+  std::vector<uint64_t> mem(J), r_mem(R);
+  std::vector<double> cached(J);
+  for (size_t i = 0; i < J; ++i) {
+    const PdJobInScheduler& p = *pending_jobs[i];
+    submit[i] = p.submit_time; qos[i] = p.qos_priority; part[i] = p.partition_priority; nn[i] = p.node_num;
+    cpu[i] = p.req_total_res_view.cpu_count.raw; mem[i] = p.req_total_res_view.memory_bytes;
+    acc[i] = id_of(p.account); cached[i] = p.priority;
+  }
+  for (size_t i = 0; i < R; ++i) {
+    const RnJobInScheduler& r = *running_jobs[i];
+    r_start[i] = r.start_time; r_qos[i] = r.qos_priority; r_part[i] = r.partition_priority;
+    r_nn[i] = r.node_num ? r.node_num : (uint32_t)r.allocated_res.size();
+    r_cpu[i] = r.allocated_res_view.cpu_count.raw; r_mem[i] = r.allocated_res_view.memory_bytes;
+    r_acc[i] = id_of(r.account);
+  }
+  cns_priority_config c{};
+  c.max_age_sec = cfg_.MaxAge; c.weight_age = cfg_.WeightAge; c.weight_fair_share = cfg_.WeightFairShare;
+  c.weight_job_size = cfg_.WeightJobSize; c.weight_partition = cfg_.WeightPartition; c.weight_qos = cfg_.WeightQoS;
+  c.favor_small = cfg_.FavorSmall ? 1u : 0u;
+  cns_prio_pending_soa pd{};
+  pd.num_jobs = (uint32_t)J; pd.submit_sec = submit.data(); pd.qos_priority = qos.data(); pd.partition_priority = part.data();
+  pd.node_num = nn.data(); pd.total_cpu_raw = cpu.data(); pd.total_mem = mem.data(); pd.account = acc.data();
+  pd.cached_priority = cached.data();
+  cns_prio_running_soa rn{};
+  rn.num_jobs = (uint32_t)R; rn.start_sec = r_start.data(); rn.qos_priority = r_qos.data(); rn.partition_priority = r_part.data();
+  rn.node_num = r_nn.data(); rn.alloc_cpu_raw = r_cpu.data(); rn.alloc_mem = r_mem.data(); rn.account = r_acc.data();
+  std::vector<uint32_t> order(J + 1);
+  std::vector<double> prio(J + 1);
+  uint64_t nord = 0;
+  const int st = cns_priority_order(h_, now, &c, (uint32_t)acc_id.size(), &pd, R ? &rn : nullptr, limit, order.data(),
+                                    prio.data(), &nord);
+  if (st != 0) return keep_input_order(st, cns_last_error(h_));
+  status_ = 0;
+  error_.clear();
+  for (size_t i = 0; i < J; ++i) pending_jobs[i]->priority = prio[i];       // cpp:7616-7618
+  for (size_t i = 0; i < J; ++i) {
+    PdJobInScheduler* j = pending_jobs[order[i]].get();
+    if (i < nord) job_ptr_vec.push_back(j);
+    else j->reason = "Priority";                                             // cpp:7625-7630
   }
 }
 

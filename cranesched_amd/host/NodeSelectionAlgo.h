@@ -82,6 +82,12 @@ struct RnJobInScheduler {  // JobScheduler.h:57-90
   TimeSec start_time{0};
   TimeSec end_time{0};
   ResourceV3 allocated_res;
+  // read by MultiFactorPriority (JobScheduler.cpp:7692-7746)
+  std::string account;
+  uint32_t qos_priority{0};
+  uint32_t partition_priority{0};
+  uint32_t node_num{0};               // uninitialised in the reference (h:70,76-89); here: allocated_res.size() when 0
+  ResourceView allocated_res_view;    // cpu_count + memory_bytes of the whole allocation
 };
 
 struct PdJobInScheduler {  // JobScheduler.h:92-170
@@ -106,6 +112,13 @@ struct PdJobInScheduler {  // JobScheduler.h:92-170
   std::vector<CranedId> craned_ids;
   std::string reason;
   bool is_scheduled() const { return reason.empty(); }
+  // read / written by MultiFactorPriority (JobScheduler.cpp:7616, :7664-7690, :7759-7767)
+  TimeSec submit_time{0};
+  std::string account;
+  uint32_t qos_priority{0};
+  uint32_t partition_priority{0};
+  double priority{0.0};               // cached across cycles: 0.0 = compute (cpp:7616)
+  ResourceView req_total_res_view;    // req_node * node_num + req_task * ntasks (cpp:7156)
 };
 
 // What NodeSelect's prologue reads from g_meta_container (JobScheduler.cpp:6563-6617): per craned its
@@ -121,6 +134,45 @@ struct CranedMeta {
 struct ClusterSnapshot {
   std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
   std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
+};
+
+// g_config.PriorityConfig, CtldPublicDefs.h:162-174
+struct PriorityConfig {
+  bool FavorSmall{true};
+  uint64_t MaxAge{14 * 24 * 3600};
+  uint32_t WeightAge{500}, WeightFairShare{10000}, WeightJobSize{0}, WeightPartition{1000}, WeightQoS{1000000};
+};
+
+// JobScheduler.h:174-181: what NodeSelect calls at JobScheduler.cpp:6735 before its ordered loop.
+class IPrioritySorter {
+ public:
+  virtual ~IPrioritySorter() = default;
+  virtual void GetOrderedJobPtrVec(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                   const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs, size_t limit,
+                                   std::vector<PdJobInScheduler*>& job_ptr_vec) = 0;
+};
+
+// MultiFactorPriority (JobScheduler.h:203-231, JobScheduler.cpp:7606-7819) on the MI355X: bounds, service
+// values, priorities and the ordering run on the device (include/crane_gpu/priority.h).  Writes job->priority,
+// fills job_ptr_vec with the first `limit` jobs by descending priority (ties: input order) and marks the rest
+// "Priority" (cpp:7625-7630).  On an engine error the vector keeps input order and LastError() says why.
+class GpuMultiFactorPriority final : public IPrioritySorter {
+ public:
+  explicit GpuMultiFactorPriority(const PriorityConfig& cfg, int device = 0);
+  ~GpuMultiFactorPriority() override;
+  GpuMultiFactorPriority(const GpuMultiFactorPriority&) = delete;
+  GpuMultiFactorPriority& operator=(const GpuMultiFactorPriority&) = delete;
+  void GetOrderedJobPtrVec(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                           const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs, size_t limit,
+                           std::vector<PdJobInScheduler*>& job_ptr_vec) override;
+  bool Ok() const { return status_ == 0; }
+  const std::string& LastError() const { return error_; }
+
+ private:
+  PriorityConfig cfg_;
+  cns_engine* h_{nullptr};
+  int status_{0};
+  std::string error_;
 };
 
 class INodeSelectionAlgo {
@@ -143,6 +195,9 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // Per-cycle snapshot (the reference re-reads the meta container inside NodeSelect; here the caller
   // hands the snapshot over before the call).
   void SetClusterSnapshot(const ClusterSnapshot& snap);
+  // Optional: the sorter NodeSelect consults first (SchedulerAlgo's ctor argument, JobScheduler.h:247);
+  // nullptr = BasicPriority (input order, JobScheduler.h:185-200).  Not owned.
+  void SetPrioritySorter(IPrioritySorter* sorter) { sorter_ = sorter; }
 
   void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
                   const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) override;
@@ -154,6 +209,8 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
+  IPrioritySorter* sorter_{nullptr};
+  uint64_t batch_{0};
   int status_{0};
   std::string error_;
 };

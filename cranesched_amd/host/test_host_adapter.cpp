@@ -105,6 +105,50 @@ int main(int argc, char** argv) {
     CHECK(pd[1]->is_scheduled() && pd[1]->craned_ids[0] == "gn1");
     CHECK((pd[1]->allocated_res.at("gn1").gres.at("gpu").at("a100") == std::set<SlotId>{"/dev/nvidia0", "/dev/nvidia1"}));
 
+    // --- MultiFactorPriority in front of the selection (JobScheduler.cpp:6735) ------------------------------
+    {
+      PriorityConfig pc;
+      pc.MaxAge = 500; pc.WeightAge = 1000; pc.WeightFairShare = 2000; pc.WeightJobSize = 300; pc.WeightPartition = 40; pc.WeightQoS = 5;
+      GpuMultiFactorPriority sorter(pc, 0);
+      CHECK(sorter.Ok());
+      snap.craned_metas = {node("cn0", 8, 64)};
+      snap.partitions = {{"CPU", {"cn0"}}};
+      algo.SetClusterSnapshot(snap);
+      algo.SetPrioritySorter(&sorter);
+      pd.clear();
+      // same numbers as tests/test_priority.py::_kat -> expected order job 3, job 1, job 2
+      auto mk = [&](job_id_t id, int64_t age, uint32_t qos, uint32_t part, uint32_t nodes, int cpus, uint64_t gib, const char* acc) {
+        auto j = job(id, cpus, 100);
+        j->submit_time = now - age; j->qos_priority = qos; j->partition_priority = part; j->account = acc;
+        j->req_total_res_view.cpu_count = cpu_t(cpus); j->req_total_res_view.memory_bytes = gib << 30;
+        j->node_num = 1; (void)nodes;
+        return j;
+      };
+      pd.push_back(mk(1, 100, 0, 1, 1, 1, 1, "a0"));
+      pd.push_back(mk(2, 300, 10, 1, 1, 4, 4, "a1"));
+      pd.push_back(mk(3, 9999, 10, 5, 1, 2, 2, "a0"));
+      std::vector<std::unique_ptr<RnJobInScheduler>> rj;
+      auto r0 = std::make_unique<RnJobInScheduler>();
+      r0->start_time = now - 1000; r0->end_time = now + 5; r0->account = "a0"; r0->node_num = 1;
+      r0->allocated_res_view.cpu_count = cpu_t(2); r0->allocated_res_view.memory_bytes = 2ull << 30; r0->partition_priority = 1;
+      auto r1 = std::make_unique<RnJobInScheduler>();
+      r1->start_time = now - 2000; r1->end_time = now + 5; r1->account = "a1"; r1->node_num = 4; r1->qos_priority = 10;
+      r1->allocated_res_view.cpu_count = cpu_t(8); r1->allocated_res_view.memory_bytes = 8ull << 30; r1->partition_priority = 5;
+      rj.push_back(std::move(r0)); rj.push_back(std::move(r1));
+      std::vector<PdJobInScheduler*> ordered;
+      sorter.GetOrderedJobPtrVec(now, pd, rj, 2, ordered);
+      CHECK(sorter.Ok());
+      CHECK(ordered.size() == 2 && ordered[0]->job_id == 3 && ordered[1]->job_id == 1);
+      CHECK(pd[1]->reason == "Priority");                      // past the limit (cpp:7625-7630)
+      CHECK(pd[2]->priority > pd[0]->priority && pd[0]->priority > pd[1]->priority);
+      pd[1]->reason.clear();
+      algo.NodeSelect(now, running, pd);                       // the 8-cpu node takes them in priority order
+      CHECK(pd[2]->is_scheduled() && pd[0]->is_scheduled() && pd[1]->is_scheduled());
+      CHECK(pd[2]->allocated_res.at("cn0").cpu_set.core_ids == (std::set<uint32_t>{0, 1}));   // first served: lowest cores
+      CHECK(pd[0]->allocated_res.at("cn0").cpu_set.core_ids == (std::set<uint32_t>{2}));
+      algo.SetPrioritySorter(nullptr);
+    }
+
     // --- a running job shapes the snapshot (cost and availability) ------------------------------------------
     snap.craned_metas = {node("cn0", 2, 8), node("cn1", 2, 8)};
     snap.partitions = {{"CPU", {"cn0", "cn1"}}};

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "sched_oracle.hpp"
+#include "prio_oracle.hpp"
 
 using namespace ora;
 
@@ -234,5 +235,29 @@ int ora_get_timeline(void* h, uint32_t node, uint32_t capacity, uint32_t* len, i
 }
 
 void ora_free(void* h) { delete static_cast<OracleRun*>(h); }
+
+
+// MultiFactorPriority restatement (prio_oracle.hpp).  Arrays as in include/crane_gpu/priority.h.
+int ora_priority_order(int64_t now, uint64_t max_age, uint32_t w_age, uint32_t w_fair, uint32_t w_size, uint32_t w_part,
+                       uint32_t w_qos, uint32_t favor_small, uint32_t num_accounts, uint32_t J, const int64_t* submit,
+                       const uint32_t* qos, const uint32_t* part, const uint32_t* node_num, const int64_t* cpu_raw,
+                       const uint64_t* mem, const uint32_t* account, const double* cached, uint32_t R,
+                       const int64_t* r_start, const uint32_t* r_qos, const uint32_t* r_part, const uint32_t* r_node_num,
+                       const int64_t* r_cpu_raw, const uint64_t* r_mem, const uint32_t* r_account, uint32_t* order_out,
+                       double* prio_out) {
+  ora::PrioConfig cfg{max_age, w_age, w_fair, w_size, w_part, w_qos, favor_small != 0};
+  std::vector<ora::PrioPending> pd(J);
+  for (uint32_t i = 0; i < J; ++i)
+    pd[i] = ora::PrioPending{submit[i], qos[i], part[i], node_num[i], cpu_raw[i], mem[i], account[i], cached ? cached[i] : 0.0};
+  std::vector<ora::PrioRunning> rn(R);
+  for (uint32_t i = 0; i < R; ++i)
+    rn[i] = ora::PrioRunning{r_start[i], r_qos[i], r_part[i], r_node_num[i], r_cpu_raw[i], r_mem[i], r_account[i]};
+  for (uint32_t i = 0; i < J; ++i) if (account[i] >= num_accounts) return -1;
+  for (uint32_t i = 0; i < R; ++i) if (r_account[i] >= num_accounts) return -1;
+  std::vector<double> prio;
+  const std::vector<uint32_t> order = ora::priority_order(now, cfg, num_accounts, pd, rn, prio);
+  for (uint32_t i = 0; i < J; ++i) { order_out[i] = order[i]; prio_out[i] = prio[i]; }
+  return 0;
+}
 
 }  // extern "C"

@@ -35,7 +35,7 @@ class OraReq(C.Structure):
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp", "prio_oracle.hpp")]
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "node_select.h"))
     stale = force or not os.path.exists(path) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
@@ -139,3 +139,27 @@ def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running 
     if rc != 0:
         raise RuntimeError(f"ora_select failed: {rc}")
     return OracleRun(h, out, cluster)
+
+
+def priority_order(now: int, cfg, num_accounts: int, pending, running=None):
+    """CPU restatement of MultiFactorPriority (oracle/prio_oracle.hpp).  Returns (order, priority)."""
+    L = lib()
+    J = pending.num_jobs
+    R = running.num_jobs if running is not None else 0
+    order = np.empty(max(J, 1), np.uint32)
+    prio = np.empty(max(J, 1), np.float64)
+    p = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    z = lambda: None
+    rc = L.ora_priority_order(
+        C.c_int64(now), C.c_uint64(cfg.max_age_sec), C.c_uint32(cfg.weight_age), C.c_uint32(cfg.weight_fair_share),
+        C.c_uint32(cfg.weight_job_size), C.c_uint32(cfg.weight_partition), C.c_uint32(cfg.weight_qos),
+        C.c_uint32(1 if cfg.favor_small else 0), C.c_uint32(num_accounts), C.c_uint32(J), p(pending.submit_sec),
+        p(pending.qos_priority), p(pending.partition_priority), p(pending.node_num), p(pending.total_cpu_raw),
+        p(pending.total_mem), p(pending.account), p(pending.cached_priority), C.c_uint32(R),
+        p(running.start_sec) if R else z(), p(running.qos_priority) if R else z(),
+        p(running.partition_priority) if R else z(), p(running.node_num) if R else z(),
+        p(running.alloc_cpu_raw) if R else z(), p(running.alloc_mem) if R else z(), p(running.account) if R else z(),
+        p(order), p(prio))
+    if rc != 0:
+        raise ValueError("ora_priority_order: account id out of range")
+    return order[:J], prio[:J]

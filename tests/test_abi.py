@@ -9,8 +9,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "crane_gpu", "node_select.h")).read()
+def header_functions(name="node_select.h"):
+    src = open(os.path.join(ROOT, "include", "crane_gpu", name)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(cns_[a-z_0-9]+)\s*\(", src)))
 
@@ -24,6 +24,12 @@ def test_header_symbols_exported(built):
         assert hasattr(lib, n), f"{n} declared in node_select.h but not exported"
     assert set(names) == set(engine.ABI_SYMBOLS), "engine.ABI_SYMBOLS out of sync with the header"
     assert lib.cns_abi_version() == 1
+    # every header under include/crane_gpu/: priority.h (MultiFactorPriority)
+    pnames = header_functions("priority.h")
+    assert set(pnames) == set(engine.PRIORITY_ABI_SYMBOLS)
+    for n in pnames:
+        assert hasattr(lib, n), f"{n} declared in priority.h but not exported"
+    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "priority.h"]
 
 
 def test_no_gpu_means_loud_failure(built):
