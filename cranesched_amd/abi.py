@@ -14,19 +14,21 @@ from typing import Optional
 
 import numpy as np
 
-CNS_ABI_VERSION = 1
+CNS_ABI_VERSION = 2
+RESV_NONE = 0xFFFFFFFF
 MAX_GRES_CLASSES = 8
 MAX_GRES_NAMES = 4
 MAX_NODE_TYPES = 64
 NODE_NONE = 0xFFFFFFFF
 
 REASON_NONE, REASON_PRIORITY, REASON_RESOURCE, REASON_RESOURCE_RESERVED, \
-    REASON_PARTITION_NOT_FOUND, REASON_SKIPPED = range(6)
+    REASON_PARTITION_NOT_FOUND, REASON_SKIPPED, REASON_RESERVATION_NOT_FOUND = range(7)
 # cns_reason <-> the reference's reason strings (JobScheduler.cpp:6750-6831, JobScheduler.h:198)
 REASON_STR = {
     REASON_NONE: "", REASON_PRIORITY: "Priority", REASON_RESOURCE: "Resource",
     REASON_RESOURCE_RESERVED: "Resource Reserved",
     REASON_PARTITION_NOT_FOUND: "Partition Not Found", REASON_SKIPPED: "<caller-set>",
+    REASON_RESERVATION_NOT_FOUND: "Reservation Not Found",
 }
 
 STATUS_STR = {0: "CNS_OK", -1: "CNS_ERR_INVALID_ARG", -2: "CNS_ERR_NO_DEVICE", -3: "CNS_ERR_HIP",
@@ -58,6 +60,12 @@ class CnsNodeSoa(C.Structure):
 class CnsRunningSoa(C.Structure):
     _fields_ = [("num_jobs", C.c_uint32), ("num_allocs", C.c_uint32), ("end_sec", _P),
                 ("alloc_offsets", _P), ("alloc_node", _P), ("alloc_cpu_raw", _P), ("alloc_mem", _P),
+                ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P), ("reservation", _P)]
+
+
+class CnsResvSoa(C.Structure):
+    _fields_ = [("num_resv", C.c_uint32), ("num_allocs", C.c_uint32), ("start_sec", _P), ("end_sec", _P),
+                ("alloc_offsets", _P), ("alloc_node", _P), ("alloc_cpu_raw", _P), ("alloc_mem", _P),
                 ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P)]
 
 
@@ -67,7 +75,7 @@ class CnsJobSoa(C.Structure):
                 ("node_num", _P), ("ntasks", _P), ("ntasks_per_node_min", _P),
                 ("ntasks_per_node_max", _P), ("exclusive", _P), ("gres_total", _P),
                 ("gres_spec", _P), ("incl_offsets", _P), ("incl_nodes", _P), ("excl_offsets", _P),
-                ("excl_nodes", _P), ("skip", _P)]
+                ("excl_nodes", _P), ("skip", _P), ("reservation", _P)]
 
 
 class CnsPlacementSoa(C.Structure):
@@ -166,9 +174,12 @@ class Running:
     alloc_core_lo: np.ndarray
     alloc_core_hi: np.ndarray
     alloc_gres: np.ndarray
+    reservation: Optional[np.ndarray] = None   # [R] reservation index or RESV_NONE
 
     def __post_init__(self):
         self.end_sec = _arr(self.end_sec, np.int64)
+        if self.reservation is not None:
+            self.reservation = _arr(self.reservation, np.uint32, len(self.end_sec))
         self.alloc_offsets = _arr(self.alloc_offsets, np.uint32, len(self.end_sec) + 1)
         m = int(self.alloc_offsets[-1]) if len(self.alloc_offsets) else 0
         self.alloc_node = _arr(self.alloc_node, np.uint32, m)
@@ -183,6 +194,46 @@ class Running:
         s.num_jobs, s.num_allocs = len(self.end_sec), len(self.alloc_node)
         s.end_sec, s.alloc_offsets, s.alloc_node = _ptr(self.end_sec), _ptr(self.alloc_offsets), _ptr(self.alloc_node)
         s.alloc_cpu_raw, s.alloc_mem = _ptr(self.alloc_cpu_raw), _ptr(self.alloc_mem)
+        s.alloc_core_lo, s.alloc_core_hi, s.alloc_gres = _ptr(self.alloc_core_lo), _ptr(self.alloc_core_hi), _ptr(self.alloc_gres)
+        s.reservation = _ptr(self.reservation)
+        return s
+
+
+@dataclass
+class Reservations:
+    """Reservations of the cycle (cns_resv_soa): start / end and the reserved resources per node."""
+    start_sec: np.ndarray
+    end_sec: np.ndarray
+    alloc_offsets: np.ndarray
+    alloc_node: np.ndarray
+    alloc_cpu_raw: np.ndarray
+    alloc_mem: np.ndarray
+    alloc_core_lo: np.ndarray
+    alloc_core_hi: np.ndarray
+    alloc_gres: np.ndarray
+
+    def __post_init__(self):
+        self.start_sec = _arr(self.start_sec, np.int64)
+        v = len(self.start_sec)
+        self.end_sec = _arr(self.end_sec, np.int64, v)
+        self.alloc_offsets = _arr(self.alloc_offsets, np.uint32, v + 1)
+        m = int(self.alloc_offsets[-1]) if len(self.alloc_offsets) else 0
+        self.alloc_node = _arr(self.alloc_node, np.uint32, m)
+        self.alloc_cpu_raw = _arr(self.alloc_cpu_raw, np.int64, m)
+        self.alloc_mem = _arr(self.alloc_mem, np.uint64, m)
+        self.alloc_core_lo = _arr(self.alloc_core_lo, np.uint64, m)
+        self.alloc_core_hi = _arr(self.alloc_core_hi, np.uint64, m)
+        self.alloc_gres = _arr(self.alloc_gres, np.uint64, m)
+
+    @property
+    def num_resv(self):
+        return len(self.start_sec)
+
+    def to_c(self) -> CnsResvSoa:
+        s = CnsResvSoa()
+        s.num_resv, s.num_allocs = len(self.start_sec), len(self.alloc_node)
+        s.start_sec, s.end_sec, s.alloc_offsets = _ptr(self.start_sec), _ptr(self.end_sec), _ptr(self.alloc_offsets)
+        s.alloc_node, s.alloc_cpu_raw, s.alloc_mem = _ptr(self.alloc_node), _ptr(self.alloc_cpu_raw), _ptr(self.alloc_mem)
         s.alloc_core_lo, s.alloc_core_hi, s.alloc_gres = _ptr(self.alloc_core_lo), _ptr(self.alloc_core_hi), _ptr(self.alloc_gres)
         return s
 
@@ -208,9 +259,12 @@ class Jobs:
     excl_offsets: Optional[np.ndarray] = None
     excl_nodes: Optional[np.ndarray] = None
     skip: Optional[np.ndarray] = None
+    reservation: Optional[np.ndarray] = None   # [J] reservation index or RESV_NONE
 
     def __post_init__(self):
         j = len(self.partition)
+        if self.reservation is not None:
+            self.reservation = _arr(self.reservation, np.uint32, j)
         self.partition = _arr(self.partition, np.uint32)
         self.time_limit_sec = _arr(self.time_limit_sec, np.int64, j)
         self.node_mem = _arr(self.node_mem, np.uint64, j)

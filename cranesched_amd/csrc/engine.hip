@@ -62,6 +62,18 @@ struct cns_engine {
   GresDev gres{};
   bool have_nodes = false, have_jobs = false, have_run = false;
 
+  // layout: slots [0, S_real) are the partitions' nodes, slots [S_real, S) the virtual nodes of the reservations
+  // (one extra "partition" P_real + v per reservation v, JobScheduler.cpp:6657-6668)
+  u32 P_real = 0, S_real = 0, V = 0;
+  std::vector<Res> node_total;                       // res_total per node (host copy)
+  std::vector<Res> slot_total;                       // res_total per slot (virtual slots: the reserved share)
+  std::vector<i64> slot_end;                         // end of the slot's time map (INF, or the reservation's end)
+  std::vector<i64> resv_start, resv_end;             // per reservation
+  std::vector<std::map<u32, u32>> resv_node_slot;    // per reservation: node -> slot
+  std::vector<u32> rv_off;                           // [S+1] reservation entries touching a REAL slot
+  std::vector<i64> rv_start, rv_endt;
+  std::vector<Res> rv_res;
+  DevBuf d_slot_total, d_slot_end, d_slot_type, d_rv_off, d_rv_start, d_rv_end, d_rv_res, d_first_resv, d_resv_se;
   // device buffers
   DevBuf d_part_off, d_slot_node, d_total, d_ntype, d_type_total, d_blocks, d_cost, d_fcpu,
       d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
@@ -131,8 +143,16 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.max_window = h->cfg.max_time_window_sec;
   K.part_off = h->d_part_off.as<u32>();
   K.slot_node = h->d_slot_node.as<u32>();
-  K.total = h->d_total.as<Res>();
-  K.ntype = h->d_ntype.as<uint8_t>();
+  K.slot_total = h->d_slot_total.as<Res>();
+  K.slot_end = h->d_slot_end.as<i64>();
+  K.slot_type = h->d_slot_type.as<uint8_t>();
+  K.rv_off = h->d_rv_off.as<u32>();
+  K.rv_start = h->d_rv_start.as<i64>();
+  K.rv_end = h->d_rv_end.as<i64>();
+  K.rv_res = h->d_rv_res.as<Res>();
+  K.first_resv = h->d_first_resv.as<i64>();
+  K.resv_se = h->d_resv_se.as<i64>();
+  K.num_real_parts = h->P_real;
   K.type_total = h->d_type_total.as<Res>();
   K.blocks = h->d_blocks.as<char>();
   K.block_stride = kBlockStride;
@@ -168,6 +188,73 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
 template <int NPL>
 void launch_select(cns_engine* h, const KParams& K) {
   hipLaunchKernelGGL((k_select<NPL>), dim3(h->P), dim3(kBlock), 0, h->stream, K, h->d_params.as<KParams>());
+}
+
+// Everything that depends on the slot list (real + virtual): per-slot res_total / time-map end, node types
+// (= distinct res_total records), the device copies and the per-slot buffers.
+int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr) {
+  const u32 S = h->S;
+  h->slot_total.resize(S);
+  h->slot_end.assign(S, INT64_MAX);
+  for (u32 q = 0; q < h->S_real; ++q) h->slot_total[q] = h->node_total[h->slot_node[q]];
+  for (u32 q = h->S_real; q < S; ++q) h->slot_total[q] = (*virt_total)[q - h->S_real];
+  for (u32 v = 0; v < h->V; ++v)
+    for (u32 q = h->part_off[h->P_real + v]; q < h->part_off[h->P_real + v + 1]; ++q) h->slot_end[q] = h->resv_end[v];
+  if (h->max_np > kScan * (u32)CNS_NPL_MAX)
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(kScan * CNS_NPL_MAX) + " schedulable nodes");
+  std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
+  std::vector<Res> type_total;
+  std::vector<uint8_t> slot_type(std::max<u32>(S, 1), 0);
+  for (u32 q = 0; q < S; ++q) {
+    const Res& r = h->slot_total[q];
+    auto key = std::make_tuple(r.cpu, r.mem, r.clo, r.chi, r.gres);
+    auto it = tmap.find(key);
+    if (it == tmap.end()) {
+      if (type_total.size() >= CNS_MAX_NODE_TYPES)
+        return fail(h, CNS_ERR_UNSUPPORTED, "more than 64 distinct res_total records (nodes + reservation shares)");
+      it = tmap.emplace(key, (u32)type_total.size()).first;
+      type_total.push_back(r);
+    }
+    slot_type[q] = (uint8_t)it->second;
+  }
+  h->T = (u32)type_total.size();
+  std::vector<i64> resv_se(2 * std::max<u32>(h->V, 1), 0);
+  for (u32 v = 0; v < h->V; ++v) { resv_se[2 * v] = h->resv_start[v]; resv_se[2 * v + 1] = h->resv_end[v]; }
+  if (int rc = upload(h, h->d_part_off, h->part_off)) return rc;
+  if (int rc = upload(h, h->d_slot_node, h->slot_node)) return rc;
+  if (int rc = upload(h, h->d_slot_total, h->slot_total)) return rc;
+  if (int rc = upload(h, h->d_slot_end, h->slot_end)) return rc;
+  if (int rc = upload(h, h->d_slot_type, slot_type)) return rc;
+  if (int rc = upload(h, h->d_type_total, type_total)) return rc;
+  if (int rc = upload(h, h->d_rv_off, h->rv_off)) return rc;
+  {
+    std::vector<i64> a = h->rv_start, b = h->rv_endt;
+    std::vector<Res> c = h->rv_res;
+    if (a.empty()) { a.push_back(0); b.push_back(0); c.push_back(Res{0, 0, 0, 0, 0}); }
+    if (int rc = upload(h, h->d_rv_start, a)) return rc;
+    if (int rc = upload(h, h->d_rv_end, b)) return rc;
+    if (int rc = upload(h, h->d_rv_res, c)) return rc;
+  }
+  if (int rc = upload(h, h->d_resv_se, resv_se)) return rc;
+  const size_t S1 = std::max<u32>(S, 1);
+  HIPCHK(h, h->d_blocks.ensure(S1 * kBlockStride));  // 48.5 KB per node: HBM is plentiful
+  HIPCHK(h, h->d_cost.ensure(S1 * sizeof(double)));
+  HIPCHK(h, h->d_fcpu.ensure(S1 * sizeof(int)));
+  HIPCHK(h, h->d_fmem.ensure(S1 * sizeof(u32)));
+  HIPCHK(h, h->d_fcnt.ensure(S1 * sizeof(u64)));
+  HIPCHK(h, h->d_first_resv.ensure(S1 * sizeof(i64)));
+  HIPCHK(h, h->d_heap.ensure((size_t)(S + h->P + 1) * sizeof(HeapEnt)));
+  HIPCHK(h, h->d_bfj.ensure(S1 * sizeof(u32)));
+  HIPCHK(h, h->d_gupd.ensure(S1 * sizeof(UpdRec)));
+  HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
+  HIPCHK(h, h->d_prof.ensure((size_t)h->P * 32 * sizeof(u64)));
+  // no running jobs until cns_set_running
+  std::vector<u32> rn_off(S + 1, 0);
+  if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
+  HIPCHK(h, h->d_rn_end.ensure(16));
+  HIPCHK(h, h->d_rn_res.ensure(sizeof(Res)));
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 }  // namespace
@@ -218,7 +305,9 @@ void cns_destroy(cns_handle* h) {
   for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_total, &h->d_ntype, &h->d_type_total,
                     &h->d_blocks, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
                     &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_gupd, &h->d_fault, &h->d_pj_off, &h->d_jobs,
-                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof})
+                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof, &h->d_slot_total,
+                    &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
+                    &h->d_first_resv, &h->d_resv_se})
     b->release();
   for (DevBuf& b : h->d_prio) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -281,47 +370,80 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   const u32 S = (u32)slot_node.size();
   if (max_np > kScan * (u32)CNS_NPL_MAX)
     return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(kScan * CNS_NPL_MAX) + " schedulable nodes");
-  // node types = distinct res_total records
-  std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
-  std::vector<Res> type_total;
-  std::vector<uint8_t> ntype(N, 0);
-  for (u32 q = 0; q < S; ++q) {
-    const Res& r = total[slot_node[q]];
-    auto key = std::make_tuple(r.cpu, r.mem, r.clo, r.chi, r.gres);
-    auto it = tmap.find(key);
-    if (it == tmap.end()) {
-      if (type_total.size() >= CNS_MAX_NODE_TYPES)
-        return fail(h, CNS_ERR_UNSUPPORTED, "more than 64 distinct node res_total records");
-      it = tmap.emplace(key, (u32)type_total.size()).first;
-      type_total.push_back(r);
-    }
-    ntype[slot_node[q]] = (uint8_t)it->second;
-  }
-  h->N = N; h->P = P; h->S = S; h->T = (u32)type_total.size(); h->max_np = max_np; h->big_nodes = big;
+  h->N = N; h->P = P; h->S = S; h->max_np = max_np; h->big_nodes = big;
+  h->P_real = P; h->S_real = S; h->V = 0;
   h->part_off = part_off; h->slot_node = slot_node; h->node_slot = node_slot; h->orig_pos_slot = orig_pos_slot;
-
-  if (int rc = upload(h, h->d_part_off, part_off)) return rc;
-  if (int rc = upload(h, h->d_slot_node, slot_node)) return rc;
-  if (int rc = upload(h, h->d_total, total)) return rc;
-  if (int rc = upload(h, h->d_ntype, ntype)) return rc;
-  if (int rc = upload(h, h->d_type_total, type_total)) return rc;
-  HIPCHK(h, h->d_blocks.ensure((size_t)std::max<u32>(S, 1) * kBlockStride));  // 48.5 KB per node: HBM is plentiful
-  HIPCHK(h, h->d_cost.ensure((size_t)std::max<u32>(S, 1) * sizeof(double)));
-  HIPCHK(h, h->d_fcpu.ensure((size_t)std::max<u32>(S, 1) * sizeof(int)));
-  HIPCHK(h, h->d_fmem.ensure((size_t)std::max<u32>(S, 1) * sizeof(u32)));
-  HIPCHK(h, h->d_fcnt.ensure((size_t)std::max<u32>(S, 1) * sizeof(u64)));
-  HIPCHK(h, h->d_heap.ensure((size_t)(S + P + 1) * sizeof(HeapEnt)));
-  HIPCHK(h, h->d_bfj.ensure((size_t)std::max<u32>(S, 1) * sizeof(u32)));
-  HIPCHK(h, h->d_gupd.ensure((size_t)std::max<u32>(S, 1) * sizeof(UpdRec)));
-  HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
-  HIPCHK(h, h->d_prof.ensure((size_t)P * 32 * sizeof(u64)));
-  // no running jobs until cns_set_running
-  std::vector<u32> rn_off(N + 1, 0);
-  if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
-  HIPCHK(h, h->d_rn_end.ensure(16));
-  HIPCHK(h, h->d_rn_res.ensure(sizeof(Res)));
-  HIPCHK(h, hipStreamSynchronize(h->stream));
+  h->node_total = total;
+  h->resv_start.clear(); h->resv_end.clear(); h->resv_node_slot.clear();
+  h->rv_off.assign(S + 1, 0); h->rv_start.clear(); h->rv_endt.clear(); h->rv_res.clear();
+  if (int rc = finalize_layout(h)) return rc;
   h->have_nodes = true;
+  return CNS_OK;
+}
+
+int cns_set_reservations(cns_handle* h, const cns_resv_soa* rv) {
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_reservations: null handle");
+  if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_set_reservations before cns_set_nodes");
+  HIPCHK(h, hipSetDevice(h->device));
+  h->have_jobs = h->have_run = false;
+  const u32 V = rv ? rv->num_resv : 0;
+  if (V && (!rv->start_sec || !rv->end_sec || !rv->alloc_offsets || !rv->alloc_node || !rv->alloc_cpu_raw ||
+            !rv->alloc_mem || !rv->alloc_core_lo))
+    return fail(h, CNS_ERR_INVALID_ARG, "cns_set_reservations: missing array");
+  // back to the layout of cns_set_nodes, then append one virtual partition per reservation
+  h->P = h->P_real; h->S = h->S_real; h->V = V;
+  h->part_off.resize(h->P_real + 1);
+  h->slot_node.resize(h->S_real);
+  h->resv_start.assign(V, 0); h->resv_end.assign(V, 0);
+  h->resv_node_slot.assign(V, {});
+  std::vector<std::vector<std::tuple<i64, i64, Res>>> per_slot(h->S_real);  // reservation entries of the real slots
+  std::vector<Res> virt_total;
+  u64 all_gres = 0;
+  for (u32 c = 0; c < h->gres.num_classes; ++c) all_gres |= h->gres.class_mask[c];
+  for (u32 v = 0; v < V; ++v) {
+    h->resv_start[v] = rv->start_sec[v];
+    h->resv_end[v] = rv->end_sec[v];
+    if (rv->alloc_offsets[v + 1] < rv->alloc_offsets[v]) return fail(h, CNS_ERR_INVALID_ARG, "reservation alloc_offsets not monotone");
+    std::vector<std::pair<u32, Res>> al;
+    for (u32 a = rv->alloc_offsets[v]; a < rv->alloc_offsets[v + 1]; ++a) {
+      const u32 n = rv->alloc_node[a];
+      if (n >= h->N) return fail(h, CNS_ERR_INVALID_ARG, "reservation node >= num_nodes");
+      Res r;
+      r.cpu = rv->alloc_cpu_raw[a]; r.mem = rv->alloc_mem[a]; r.clo = rv->alloc_core_lo[a];
+      r.chi = rv->alloc_core_hi ? rv->alloc_core_hi[a] : 0;
+      r.gres = rv->alloc_gres ? rv->alloc_gres[a] : 0;
+      if (r.gres & ~all_gres) return fail(h, CNS_ERR_INVALID_ARG, "reservation GRES slot outside every class");
+      if (r.cpu <= 0 || r.cpu >= 0x7FFFFFFEll) return fail(h, CNS_ERR_UNSUPPORTED, "reservation cpu share must be in (0, 2^31-2)");
+      al.emplace_back(n, r);
+      if (r.gres || r.chi) h->big_nodes = true;
+    }
+    std::sort(al.begin(), al.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (size_t i = 1; i < al.size(); ++i)
+      if (al[i].first == al[i - 1].first) return fail(h, CNS_ERR_INVALID_ARG, "node listed twice in one reservation");
+    for (auto& [n, r] : al) {
+      h->resv_node_slot[v][n] = (u32)h->slot_node.size();  // virtual node: its own NodeState (:6661-6664)
+      h->slot_node.push_back(n);
+      virt_total.push_back(r);
+      if (h->node_slot[n] != kNone) per_slot[h->node_slot[n]].emplace_back(rv->start_sec[v], rv->end_sec[v], r);
+    }
+    h->part_off.push_back((u32)h->slot_node.size());
+    h->max_np = std::max<u32>(h->max_np, (u32)al.size());
+  }
+  h->P = h->P_real + V;
+  h->S = (u32)h->slot_node.size();
+  h->rv_off.assign(h->S + 1, 0); h->rv_start.clear(); h->rv_endt.clear(); h->rv_res.clear();
+  for (u32 q = 0; q < h->S_real; ++q) {
+    // release + dip events of a node share the node block's upper half with the running allocations (k_init_nodes)
+    if (per_slot[q].size() > 200) return fail(h, CNS_ERR_UNSUPPORTED, "more than 200 reservations on one node");
+    for (auto& [st, en, r] : per_slot[q]) { h->rv_start.push_back(st); h->rv_endt.push_back(en); h->rv_res.push_back(r); }
+    h->rv_off[q + 1] = (u32)h->rv_start.size();
+  }
+  for (u32 q = h->S_real; q < h->S; ++q) h->rv_off[q + 1] = h->rv_off[q];
+  if (int rc = finalize_layout(h, &virt_total)) return rc;
+  // running jobs must be set again after the layout changed
+  std::vector<u32> rn_off(h->S + 1, 0);
+  if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
   return CNS_OK;
 }
 
@@ -329,8 +451,17 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
   if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_running: null handle");
   if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_set_running before cns_set_nodes");
   HIPCHK(h, hipSetDevice(h->device));
-  const u32 N = h->N;
-  std::vector<u32> rn_off(N + 1, 0);
+  const u32 N = h->N, S = h->S;
+  // allocations are grouped by SLOT: the node's own slot, or — for a job running inside a reservation
+  // (JobScheduler.cpp:6692-6707) — the reservation's virtual node
+  auto slot_of = [&](u32 job, u32 n) -> u32 {
+    const u32 v = rn->reservation ? rn->reservation[job] : CNS_RESV_NONE;
+    if (v == CNS_RESV_NONE) return h->node_slot[n];  // kNone: unschedulable node, ignored (:6685-6686)
+    if (v >= h->V) return kNone;                      // reservation not found (:6693-6700)
+    auto it = h->resv_node_slot[v].find(n);
+    return it == h->resv_node_slot[v].end() ? kNone : it->second;
+  };
+  std::vector<u32> rn_off(S + 1, 0);
   std::vector<i64> rn_end;
   std::vector<Res> rn_res;
   if (rn && rn->num_jobs) {
@@ -338,23 +469,27 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
       return fail(h, CNS_ERR_INVALID_ARG, "cns_set_running: missing array");
     const u32 A = rn->alloc_offsets[rn->num_jobs];
     if (A != rn->num_allocs) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_running: num_allocs mismatch");
-    for (u32 a = 0; a < A; ++a) {
-      u32 n = rn->alloc_node[a];
-      if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "running allocation on node >= num_nodes");
-      if (h->node_slot[n] != kNone) rn_off[n + 1]++;  // allocations on unschedulable nodes are ignored (:6685-6686)
-    }
-    for (u32 n = 0; n < N; ++n) {
-      if (rn_off[n + 1] + 2 > kTlCap) return fail(h, CNS_ERR_UNSUPPORTED, "more than 1006 running allocations on one node");
-      rn_off[n + 1] += rn_off[n];
-    }
-    rn_end.resize(rn_off[N]);
-    rn_res.resize(rn_off[N]);
-    std::vector<u32> cur(rn_off.begin(), rn_off.end() - 1);
-    for (u32 j = 0; j < rn->num_jobs; ++j)  // stable: per node, input order (cost accumulation order)
+    for (u32 j = 0; j < rn->num_jobs; ++j)
       for (u32 a = rn->alloc_offsets[j]; a < rn->alloc_offsets[j + 1]; ++a) {
-        u32 n = rn->alloc_node[a];
-        if (h->node_slot[n] == kNone) continue;
-        u32 d = cur[n]++;
+        const u32 n = rn->alloc_node[a];
+        if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "running allocation on node >= num_nodes");
+        const u32 q = slot_of(j, n);
+        if (q != kNone) rn_off[q + 1]++;
+      }
+    for (u32 q = 0; q < S; ++q) {
+      const u32 nrv = h->rv_off[q + 1] - h->rv_off[q];
+      if (nrv ? rn_off[q + 1] + 2 * nrv + 2 > kTlCap / 2 : rn_off[q + 1] + 2 > kTlCap)
+        return fail(h, CNS_ERR_UNSUPPORTED, "too many running allocations / reservations on one node (1006, or 502 events with reservations)");
+      rn_off[q + 1] += rn_off[q];
+    }
+    rn_end.resize(rn_off[S]);
+    rn_res.resize(rn_off[S]);
+    std::vector<u32> cur(rn_off.begin(), rn_off.end() - 1);
+    for (u32 j = 0; j < rn->num_jobs; ++j)  // stable: per slot, input order (cost accumulation order)
+      for (u32 a = rn->alloc_offsets[j]; a < rn->alloc_offsets[j + 1]; ++a) {
+        const u32 q = slot_of(j, rn->alloc_node[a]);
+        if (q == kNone) continue;
+        u32 d = cur[q]++;
         rn_end[d] = rn->end_sec[j];
         Res r;
         r.cpu = rn->alloc_cpu_raw[a];
@@ -390,6 +525,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761)
   std::vector<uint8_t> reason(std::max<u64>(J, 1), CNS_REASON_NONE);
   std::vector<u64> pj_cnt(h->P + 1, 0);
+  std::vector<u32> part_of(std::max<u64>(J, 1), 0);  // (virtual) partition of every job that reaches the ordered loop
   h->place_off.assign(J + 1, 0);
   u64 places = 0, algo = 0;
   const u64 s_node = h->big_nodes ? 48 : 32;
@@ -403,8 +539,18 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
     places += k;
     if (j >= batch) { reason[j] = CNS_REASON_PRIORITY; continue; }
     if (jb->skip && jb->skip[j]) { reason[j] = CNS_REASON_SKIPPED; continue; }
-    if (jb->partition[j] >= h->P) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
-    const u32 p = jb->partition[j];
+    // a job submitted to a reservation is scheduled by that reservation's scheduler, its partition is not looked
+    // at (JobScheduler.cpp:6525-6527,6746-6761); whether the reservation is ACTIVE is decided on the device (needs `now`)
+    const u32 rsv = jb->reservation ? jb->reservation[j] : CNS_RESV_NONE;
+    u32 p;
+    if (rsv != CNS_RESV_NONE) {
+      if (rsv >= h->V) { reason[j] = CNS_REASON_RESERVATION_NOT_FOUND; continue; }
+      p = h->P_real + rsv;
+    } else {
+      if (jb->partition[j] >= h->P_real) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
+      p = jb->partition[j];
+    }
+    part_of[j] = p;
     pj_cnt[p + 1]++;
     algo += (u64)(h->part_off[p + 1] - h->part_off[p]) * s_node + 64 + 16 + 24ull * k;
   }
@@ -419,7 +565,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   std::vector<u32> grouped((size_t)Jg);
   for (u64 j = 0; j < batch; ++j) {
     if (reason[j] != CNS_REASON_NONE) continue;
-    grouped[(size_t)cur[jb->partition[j]]++] = (u32)j;
+    grouped[(size_t)cur[part_of[j]]++] = (u32)j;
   }
   auto put64 = [](u32* rec, u32 f, u64 v) { rec[f] = (u32)v; rec[f + 1] = (u32)(v >> 32); };
   for (u64 i = 0; i < Jg; ++i) {

@@ -87,8 +87,16 @@ struct KParams {
   i64 now, max_window;
   const u32* part_off;     // [P+1] slot range of each partition
   const u32* slot_node;    // [S]   dense node index of slot q (ascending inside a partition)
-  const Res* total;        // [N]   res_total (input of k_init_nodes)
-  const uint8_t* ntype;    // [N]   node type id (index into type_total)
+  const Res* slot_total;   // [S]   res_total of the slot's node (virtual slots: the reserved share)
+  const i64* slot_end;     // [S]   end of the slot's time map (INF, or the reservation's end; JobScheduler.h:301-302,337)
+  const uint8_t* slot_type;// [S]   node type id (index into type_total)
+  const u32* rv_off;       // [S+1] reservation entries (start, end, res) on a real slot, ascending reservation index
+  const i64* rv_start;
+  const i64* rv_end;
+  const Res* rv_res;
+  i64* first_resv;         // [S]   earliest start of a non-expired reservation on the node (INF: none), :6635-6642
+  const i64* resv_se;      // [2V]  start, end of reservation v (virtual partition num_real_parts + v)
+  u32 num_real_parts, pad_resv;
   const Res* type_total;   // [T]   distinct res_total records
   char* blocks;            // [S]   one NodeBlock per partition slot: NodeHdr + tl_cap TlEntry
   u64 block_stride;        //       bytes per NodeBlock

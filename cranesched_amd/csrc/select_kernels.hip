@@ -180,18 +180,64 @@ __device__ __forceinline__ TlEntry* tl_of(NodeHdr* h) { return (TlEntry*)((char*
 // k_init_nodes — prologue
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ Pp) {
+  // NodeState::InitTimeAvailResMap (JobScheduler.h:301-338) + the NodeRater constructor (h:498-511) of one slot:
+  // a partition's node, or the virtual node of a reservation (res_total = the reserved share, map ends at the
+  // reservation's end).  Reservation entries of a real node (cpp:6627-6679): expired ones are ignored, an ACTIVE
+  // one is an allocation until its end, a FUTURE one is a dip [start, end) (h:305-308).
   const KParams& P = *Pp;
   u32 q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= P.num_slots) return;
   const u32 n = P.slot_node[q];
-  const Res tot = P.total[n];
+  const Res tot = P.slot_total[q];
+  const i64 end_h = P.slot_end[q];
   Res a0 = tot;
   double cost = 0.0;
   NodeHdr* hd = hdr_of(P, q);
-  TlEntry* T = tl_of(hd);
+  TlEntry* T = tl_of(hd);           // T[i].t / T[i].r: change times and what is RELEASED there
+  TlEntry* A2 = T + kTlCap / 2;     // A2[i].r: what is ALLOCATED at T[i].t (only with reservations; host bounds the count)
   u32 len = 1;  // T[0] reserved for {now, avail0}
   const double tcpu = (double)tot.cpu / 256.0;
-  for (u32 a = P.rn_off[n]; a < P.rn_off[n + 1]; ++a) {
+  const u32 rvb = P.rv_off[q], rve = P.rv_off[q + 1];
+  const bool has_rv = rve > rvb;
+  // sorted insert of a change at `time`: kind 0 = release (+r), 1 = allocation (-r); equal times accumulate,
+  // at one time releases apply before allocations (h:315-320)
+  auto put = [&](i64 time, const Res& r, int kind) {
+    u32 i = 1;
+    while (i < len && T[i].t < time) ++i;
+    if (!(i < len && T[i].t == time)) {
+      for (u32 m = len; m > i; --m) { T[m] = T[m - 1]; if (has_rv) A2[m] = A2[m - 1]; }
+      T[i].t = time;
+      T[i].r = res_zero();
+      if (has_rv) A2[i].r = res_zero();
+      ++len;
+    }
+    if (kind == 0) res_add(T[i].r, r); else res_add(A2[i].r, r);
+  };
+  i64 first = kInf;
+  for (u32 a = rvb; a < rve; ++a) {  // NodeRater: reserved_res first (h:502-506)
+    const i64 st = P.rv_start[a], en = P.rv_end[a];
+    if (P.now >= en) continue;       // expired (cpp:6631-6634)
+    first = st < first ? st : first; // craned_id_first_resv_map (cpp:6635-6642)
+    if (P.now < st) {
+      const double ratio = ((double)P.rv_res[a].cpu / 256.0) / tcpu;
+      cost += (double)(en - st) * ratio;
+    }
+  }
+  for (u32 a = rvb; a < rve; ++a) {
+    const i64 st = P.rv_start[a], en = P.rv_end[a];
+    if (P.now >= en) continue;
+    const Res r = P.rv_res[a];
+    if (P.now >= st) {               // active: allocated until its end (cpp:6644-6652), before the running jobs
+      res_sub(a0, r);
+      const double ratio = ((double)r.cpu / 256.0) / tcpu;
+      cost += (double)(en - P.now) * ratio;
+      put(en, r, 0);
+    } else {                         // future: dip (cpp:6669-6677)
+      put(st, r, 1);
+      put(en, r, 0);
+    }
+  }
+  for (u32 a = P.rn_off[q]; a < P.rn_off[q + 1]; ++a) {
     i64 end = P.rn_end[a];
     if (end < P.now + 1) end = P.now + 1;  // JobScheduler.cpp:6513-6514
     const Res r = P.rn_res[a];
@@ -199,31 +245,29 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
     // NodeRater ctor, JobScheduler.h:508-510 + MinCpuTimeRatioFirst :47-53 (ratio first, then x secs)
     double ratio = ((double)r.cpu / 256.0) / tcpu;
     cost += (double)(end - P.now) * ratio;
-    // sorted insert of the release {end, r}; equal end times accumulate (JobScheduler.h:325-335)
-    u32 i = 1;
-    while (i < len && T[i].t < end) ++i;
-    if (i < len && T[i].t == end) {
-      res_add(T[i].r, r);
-    } else {
-      for (u32 m = len; m > i; --m) T[m] = T[m - 1];
-      T[i].t = end;
-      T[i].r = r;
-      ++len;
-    }
+    put(end, r, 0);                        // release {end, r}; equal end times accumulate (JobScheduler.h:325-335)
   }
   T[0].t = P.now;
   T[0].r = a0;
-  for (u32 i = 1; i < len; ++i) {  // value at a change time = previous value + what is released there
+  for (u32 i = 1; i < len; ++i) {  // value at a change time = previous value + releases - allocations
     Res v = T[i - 1].r;
     res_add(v, T[i].r);
+    if (has_rv) res_sub(v, A2[i].r);
     T[i].r = v;
   }
-  T[len].t = kInf;  // time_avail_res_map[end].SetToZero(), JobScheduler.h:337
-  T[len].r = res_zero();
-  ++len;
+  {  // time_avail_res_map[end].SetToZero(), JobScheduler.h:337 (end = InfiniteFuture, or the reservation's end)
+    u32 i = 1;
+    while (i < len && T[i].t < end_h) ++i;
+    if (!(i < len && T[i].t == end_h)) {
+      for (u32 m = len; m > i; --m) T[m] = T[m - 1];
+      T[i].t = end_h;
+      ++len;
+    }
+    T[i].r = res_zero();
+  }
   hd->len = len;
   hd->node = n;
-  hd->type = P.ntype[n];
+  hd->type = P.slot_type[q];
   hd->pad = 0;
   hd->avail0 = a0;
   hd->total = tot;
@@ -231,6 +275,7 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
   P.f_cpu[q] = clamp_cpu(a0.cpu);
   P.f_mem[q] = mem_mib_ceil(a0.mem);
   P.f_cnt[q] = class_counts(a0.gres, P.gres);
+  P.first_resv[q] = first;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -518,7 +563,9 @@ __device__ __forceinline__ u32 tl_commit_regs(const KParams& P, NodeHdr* hd, TlE
   const i64 t = act ? e.t : kInf;
   const u32 c_start = (u32)__popcll(__ballot(act && t <= start));
   const u32 c_end = (u32)__popcll(__ballot(act && t <= end));
-  if (c_start == 0 || c_end >= len) {  // cases #1/#2 cannot occur: the INF sentinel is last
+  if (c_start == 0 || c_end > len || (c_end == len && rl64((u64)e.t, len - 1) != (u64)end)) {
+    // cases #1/#2 cannot occur: the last entry (INF, or the end of a reservation's map) is a zero entry, so no
+    // feasible window reaches past it; a job may END exactly there
     if (lane == 0) set_fault(P, 1, job, hd->node, len);
     return len;
   }
@@ -558,7 +605,7 @@ __device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, 
     c_end += __popcll(__ballot(act && t <= end));
     if (__any(act && t > end)) break;
   }
-  if (c_start == 0 || c_end >= len || len + 2 > P.tl_cap) {
+  if (c_start == 0 || c_end > len || (c_end == len && T[len - 1].t != end) || len + 2 > P.tl_cap) {
     if (lane == 0) set_fault(P, 1, job, hd->node, len);
     return len;
   }
@@ -1023,13 +1070,16 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     }
     if (found) {
       int reason = 0;
-      if (t != P.now) {  // JobScheduler.cpp:6797-6833 (no reservations in this slice)
-        bool notle = false;
+      if (t != P.now) {  // JobScheduler.cpp:6797-6833
+        bool notle = false, reserved = false;
         for (u32 i = lane; i < J.k; i += 64) {
           const HeapEnt x = H[i];
-          if (!res_le(x.res, hdr_of(P, qbeg + slot_of_code(x.p))->avail0)) notle = true;
+          const u32 qx = qbeg + slot_of_code(x.p);
+          if (!res_le(x.res, hdr_of(P, qx)->avail0)) notle = true;
+          if (P.first_resv[qx] < P.now + J.L) reserved = true;
         }
-        reason = __any(notle) ? 2 /*Resource*/ : 1 /*Priority*/;
+        const bool resv_part = blockIdx.x >= P.num_real_parts;
+        reason = (!resv_part && __any(reserved)) ? 3 /*Resource Reserved*/ : (__any(notle) ? 2 /*Resource*/ : 1 /*Priority*/);
       }
       commit_selection(P, J, H, qbeg, t, lane, s_upd, s_nupd);
       if (lane == 0) { P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
@@ -1169,7 +1219,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
   }
   if (complete) {
     __threadfence_block();
-    bool bad = false, notle = false;
+    bool bad = false, notle = false, reserved = false;
     if (lane < J.k) {  // allocation against res_total (:6353-6361)
       HeapEnt x = H[lane];
       const NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
@@ -1177,10 +1227,12 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
       Res a;
       if (!feasible(one_view, hd->total, a, P.gres)) bad = true; else x.res = a;
       notle = !res_le(x.res, hd->avail0);
+      reserved = P.first_resv[qbeg + slot_of_code(x.p)] < P.now + J.L;
       H[lane] = x;
     }
     if (__any(bad) && lane == 0) set_fault(P, 3, orig, 0, 2);
     notle = __any(notle);
+    reserved = __any(reserved) && blockIdx.x < P.num_real_parts;
     __threadfence_block();
     // EarliestStartSubsetSelector::CalcEarliestStartTime as a fixed point over the k nodes
     i64 t = P.now;
@@ -1202,7 +1254,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
     }
     if (found) {
       int reason = 0;
-      if (t != P.now) reason = notle ? 2 /*Resource*/ : 1 /*Priority*/;  // :6810-6831
+      if (t != P.now) reason = reserved ? 3 /*Resource Reserved*/ : (notle ? 2 /*Resource*/ : 1 /*Priority*/);  // :6797-6831
       for (u32 i = 0; i < J.k; ++i) commit_pick(P, J, H[i], i, qbeg, t, lane, sh.upd, orig);
       emit_placements(P, J, H, lane);
       if (lane == 0) { *sh.nupd = (int)J.k; P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
@@ -1316,7 +1368,10 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const JobCtx* J
     if (!feasible(J.min_view, h.total, alloc, P.gres)) {  // :6354-6356
       if (lane == 0) set_fault(P, 3, J.orig, h.node, 2);
     }
-    if (lane == 0) { H[i].node = h.node; H[i].ntasks = 1; H[i].res = alloc; H[i].pad = res_le(alloc, h.avail0) ? 0u : 1u; }
+    if (lane == 0) {
+      H[i].node = h.node; H[i].ntasks = 1; H[i].res = alloc;
+      H[i].pad = (res_le(alloc, h.avail0) ? 0u : 1u) | (P.first_resv[q] < P.now + J.L ? 2u : 0u);
+    }
   }
   i64 t = P.now;
   bool found = false;
@@ -1337,15 +1392,16 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const JobCtx* J
     if (Tm == t) { found = true; break; }
     t = Tm;
   }
-  bool notle = false;
-  for (u32 m = 0; m < J.k; ++m) notle = notle || H[m].pad != 0;
+  bool notle = false, reserved = false;
+  for (u32 m = 0; m < J.k; ++m) { notle = notle || (H[m].pad & 1u) != 0; reserved = reserved || (H[m].pad & 2u) != 0; }
+  if (blockIdx.x >= P.num_real_parts) reserved = false;  // jobs of a reservation: no "Resource Reserved" (:6798,6818)
   if (found && active) {
     helper_commit_regs(P, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q);
     drain_stores();
   }
   if (found && threadIdx.x == 0) *nupd = (int)J.k;
   wg_barrier();  // commits + owner updates visible (or: nothing happened)
-  *reason_out = (found && t != P.now) ? (notle ? 2 : 1) : 0;  // :6810-6831
+  *reason_out = (found && t != P.now) ? (reserved ? 3 : (notle ? 2 : 1)) : 0;  // :6797-6831
   return found ? t : kInf;
 }
 
@@ -1410,6 +1466,19 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   const u32 nn = P.part_off[part + 1] - qbeg;
   const u64 jbeg = P.pj_off[part], jend = P.pj_off[part + 1];
   if (jbeg >= jend) return;
+  // a reservation's scheduler exists only while the reservation is active (JobScheduler.cpp:6643,6754-6759)
+  const bool resv_part = part >= P.num_real_parts;
+  if (resv_part) {
+    const i64 rs = P.resv_se[2 * (part - P.num_real_parts)], re = P.resv_se[2 * (part - P.num_real_parts) + 1];
+    if (!(rs <= P.now && P.now < re)) {
+      for (u64 x = jbeg + tid; x < jend; x += kBlock) {
+        const u32 orig = P.jobrec[x * kJobRecDwords + kJrOrig];
+        P.o_start[orig] = 0;
+        P.o_reason[orig] = 6;  // "Reservation Not Found"
+      }
+      return;
+    }
+  }
 #ifdef CNS_HWID
   if (lane == 0 && part == 0) printf("wave %u hw_id %08x simd %u\n", wave, (unsigned)__builtin_amdgcn_s_getreg(63492), ((unsigned)__builtin_amdgcn_s_getreg(63492) >> 4) & 3u);
 #endif
@@ -1578,7 +1647,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               cn.fcpu = clamp_cpu(e0.cpu); cn.fmem = mem_mib_ceil(e0.mem); cn.fcnt = class_counts(e0.gres, P.gres);
               if (st != kInf && st - P.now <= P.max_window) {          // kAlgoMaxTimeWindow, JobScheduler.h:815
                 int reason = 0;
-                if (st != P.now) reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;  // :6810-6831
+                if (st != P.now) {  // :6797-6831
+                  if (!resv_part && P.first_resv[q] < P.now + F.L) reason = 3;  // "Resource Reserved" (:6799-6806)
+                  else reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;
+                }
                 commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, __longlong_as_double((long long)tc),
                                    alloc, st, reason, lane, s_upd, &s_nupd, cn);
                 code = 2;

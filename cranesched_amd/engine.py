@@ -25,7 +25,7 @@ _LIB = None
 
 # every symbol include/crane_gpu/node_select.h declares
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
-               "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
+               "cns_set_reservations", "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
                "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline",
                "cns_debug_get_prof")
 # ... and include/crane_gpu/priority.h
@@ -116,6 +116,14 @@ class GpuNodeSelector:
         c = cluster.to_c()
         self._check(self._L.cns_set_nodes(self._h, C.byref(c)))
         self._cluster = cluster
+
+    def set_reservations(self, reservations: abi.Reservations | None):
+        """Reservations of the cycle (JobScheduler.cpp:6619-6679): after set_nodes, before set_running."""
+        if reservations is None:
+            self._check(self._L.cns_set_reservations(self._h, None))
+        else:
+            r = reservations.to_c()
+            self._check(self._L.cns_set_reservations(self._h, C.byref(r)))
 
     def set_running(self, running: abi.Running | None):
         if running is None:

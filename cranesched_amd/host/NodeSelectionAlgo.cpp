@@ -13,7 +13,7 @@
 namespace crane {
 
 namespace {
-const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", ""};
+const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", "", "Reservation Not Found"};
 }
 
 struct GpuNodeSelectionAlgo::Impl {
@@ -22,6 +22,7 @@ struct GpuNodeSelectionAlgo::Impl {
   std::vector<CranedId> node_name;
   std::unordered_map<CranedId, uint32_t> node_idx;
   std::unordered_map<PartitionId, uint32_t> part_idx;
+  std::unordered_map<std::string, uint32_t> resv_idx;
   // (name, type) -> class; slot path -> bit, per class in lexicographic path order (std::set<SlotId> order)
   std::vector<std::pair<std::string, std::string>> classes;
   std::map<std::string, uint32_t> name_id;
@@ -155,6 +156,38 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   nd.gres = I.layout;
   status_ = cns_set_nodes(I.h, &nd);
   if (status_ != 0) { error_ = cns_last_error(I.h); return; }
+  // ---- reservations (JobScheduler.cpp:6619-6679) ----
+  I.resv_idx.clear();
+  const uint32_t V = (uint32_t)snap.reservations.size();
+  if (V) {
+    std::vector<int64_t> rs(V), re(V), rcpu;
+    std::vector<uint32_t> roff{0}, rnode;
+    std::vector<uint64_t> rmem, rlo, rhi, rg;
+    for (uint32_t v = 0; v < V; ++v) {
+      const ResvMeta& m = snap.reservations[v];
+      I.resv_idx[m.name] = v;
+      rs[v] = m.start_time; re[v] = m.end_time;
+      for (const auto& [cid, res] : m.res_total) {
+        auto it = I.node_idx.find(cid);
+        if (it == I.node_idx.end()) continue;
+        rnode.push_back(it->second);
+        rcpu.push_back(res.cpu_set.cpu_count.raw);
+        rmem.push_back(res.memory_bytes);
+        uint64_t l, hh;
+        Impl::core_masks(res.cpu_set.core_ids, l, hh);
+        rlo.push_back(l); rhi.push_back(hh);
+        rg.push_back(I.gres_mask(res.gres));
+      }
+      roff.push_back((uint32_t)rnode.size());
+    }
+    cns_resv_soa rv{};
+    rv.num_resv = V; rv.num_allocs = (uint32_t)rnode.size();
+    rv.start_sec = rs.data(); rv.end_sec = re.data(); rv.alloc_offsets = roff.data(); rv.alloc_node = rnode.data();
+    rv.alloc_cpu_raw = rcpu.data(); rv.alloc_mem = rmem.data(); rv.alloc_core_lo = rlo.data(); rv.alloc_core_hi = rhi.data();
+    rv.alloc_gres = rg.data();
+    status_ = cns_set_reservations(I.h, &rv);
+    if (status_ != 0) { error_ = cns_last_error(I.h); return; }
+  }
   I.have_snapshot = true;
 }
 
@@ -174,8 +207,15 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   std::vector<uint32_t> r_off{0}, r_node;
   std::vector<int64_t> r_cpu;
   std::vector<uint64_t> r_mem, r_lo, r_hi, r_g;
+  std::vector<uint32_t> r_resv;
   for (const auto& rn : running_jobs) {
-    if (!rn->reservation.empty()) continue;
+    uint32_t rv = CNS_RESV_NONE;
+    if (!rn->reservation.empty()) {  // allocated inside the reservation's own node states (cpp:6692-6707)
+      auto it = I.resv_idx.find(rn->reservation);
+      if (it == I.resv_idx.end()) continue;
+      rv = it->second;
+    }
+    r_resv.push_back(rv);
     r_end.push_back(rn->end_time);
     for (const auto& [cid, res] : rn->allocated_res) {
       auto it = I.node_idx.find(cid);
@@ -194,7 +234,7 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   rs.num_jobs = (uint32_t)r_end.size(); rs.num_allocs = (uint32_t)r_node.size();
   rs.end_sec = r_end.data(); rs.alloc_offsets = r_off.data(); rs.alloc_node = r_node.data();
   rs.alloc_cpu_raw = r_cpu.data(); rs.alloc_mem = r_mem.data(); rs.alloc_core_lo = r_lo.data();
-  rs.alloc_core_hi = r_hi.data(); rs.alloc_gres = r_g.data();
+  rs.alloc_core_hi = r_hi.data(); rs.alloc_gres = r_g.data(); rs.reservation = r_resv.data();
   int st = cns_set_running(I.h, rs.num_jobs ? &rs : nullptr);
   if (st != 0) return fail_all(st, cns_last_error(I.h));
 
@@ -211,7 +251,7 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   std::vector<int64_t> L(J), ncpu(J), tcpu(J);
   std::vector<uint64_t> nmem(J), tmem(J), ioff{0}, eoff{0};
   std::vector<uint8_t> excl(J), skip(J), gtot(J * CNS_MAX_GRES_NAMES, 0), gspec(J * CNS_MAX_GRES_CLASSES, 0);
-  std::vector<uint32_t> inodes, enodes;
+  std::vector<uint32_t> inodes, enodes, jresv(J, CNS_RESV_NONE);
   for (size_t j = 0; j < J; ++j) {
     const PdJobInScheduler& p = *ord[j];
     auto pit = I.part_idx.find(p.partition_id);
@@ -223,7 +263,11 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
     tmem[j] = p.req_task_res_view.memory_bytes;
     k[j] = p.node_num; nt[j] = p.ntasks; tmin[j] = p.ntasks_per_node_min; tmax[j] = p.ntasks_per_node_max;
     excl[j] = p.exclusive;
-    skip[j] = !p.reason.empty() || !p.reservation.empty();  // cpp:6744; reservation jobs stay with the caller
+    skip[j] = !p.reason.empty();  // cpp:6744
+    if (!p.reservation.empty()) {  // scheduled by the reservation's scheduler (cpp:6754-6760); unknown -> "Reservation Not Found"
+      auto rit = I.resv_idx.find(p.reservation);
+      jresv[j] = rit == I.resv_idx.end() ? 0xFFFFFFFEu : rit->second;
+    }
     for (const auto& [name, gc] : p.req_node_res_view.gres_map) {
       auto nit = I.name_id.find(name);
       uint64_t tot = gc.total;
@@ -248,7 +292,7 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   js.task_cpu_raw = tcpu.data(); js.task_mem = tmem.data(); js.node_num = k.data(); js.ntasks = nt.data();
   js.ntasks_per_node_min = tmin.data(); js.ntasks_per_node_max = tmax.data(); js.exclusive = excl.data();
   js.gres_total = gtot.data(); js.gres_spec = gspec.data(); js.incl_offsets = ioff.data(); js.incl_nodes = inodes.data();
-  js.excl_offsets = eoff.data(); js.excl_nodes = enodes.data(); js.skip = skip.data();
+  js.excl_offsets = eoff.data(); js.excl_nodes = enodes.data(); js.skip = skip.data(); js.reservation = jresv.data();
 
   uint64_t places = 0;
   for (size_t j = 0; j < J; ++j) places += k[j];

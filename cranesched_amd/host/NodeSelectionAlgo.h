@@ -131,9 +131,17 @@ struct CranedMeta {
   bool alive{true};
   bool drain{false};
 };
+// ResvMeta as NodeSelect reads it (JobScheduler.cpp:6627-6679): window and the reserved resources per node.
+struct ResvMeta {
+  std::string name;          // ResvId
+  TimeSec start_time{0};
+  TimeSec end_time{0};
+  ResourceV3 res_total;      // EachNodeResMap()
+};
 struct ClusterSnapshot {
   std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
   std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
+  std::vector<ResvMeta> reservations;                                     // g_meta_container->GetResvMetaMapPtr(); vector order = canonical order
 };
 
 // g_config.PriorityConfig, CtldPublicDefs.h:162-174

@@ -105,6 +105,34 @@ int main(int argc, char** argv) {
     CHECK(pd[1]->is_scheduled() && pd[1]->craned_ids[0] == "gn1");
     CHECK((pd[1]->allocated_res.at("gn1").gres.at("gpu").at("a100") == std::set<SlotId>{"/dev/nvidia0", "/dev/nvidia1"}));
 
+    // --- reservations (JobScheduler.cpp:6619-6679, 6754-6760, 6797-6806) -----------------------------------
+    {
+      snap.craned_metas = {node("cn0", 8, 16)};
+      snap.partitions = {{"CPU", {"cn0"}}};
+      ResvMeta rv0; rv0.name = "r0"; rv0.start_time = now - 10; rv0.end_time = now + 500;
+      rv0.res_total["cn0"].cpu_set.cpu_count = cpu_t(4); rv0.res_total["cn0"].cpu_set.core_ids = {4, 5, 6, 7};
+      rv0.res_total["cn0"].memory_bytes = 8ull << 30;
+      ResvMeta rv1; rv1.name = "later"; rv1.start_time = now + 1000; rv1.end_time = now + 2000;
+      rv1.res_total["cn0"].cpu_set.cpu_count = cpu_t(1); rv1.res_total["cn0"].cpu_set.core_ids = {0};
+      rv1.res_total["cn0"].memory_bytes = 1ull << 30;
+      snap.reservations = {rv0, rv1};
+      algo.SetClusterSnapshot(snap);
+      CHECK(algo.Ok());
+      pd.clear();
+      pd.push_back(job(1, 6, 100));                                   // 6 cpus: only 4 outside the reservation
+      auto in = job(2, 2, 100); in->reservation = "r0"; pd.push_back(std::move(in));
+      auto fut = job(3, 1, 10); fut->reservation = "later"; pd.push_back(std::move(fut));
+      auto unk = job(4, 1, 10); unk->reservation = "nope"; pd.push_back(std::move(unk));
+      std::vector<std::unique_ptr<RnJobInScheduler>> none;
+      algo.NodeSelect(now, none, pd);
+      CHECK(algo.Ok());
+      CHECK(pd[0]->reason == "Resource Reserved" && pd[0]->start_time == now + 500);
+      CHECK(pd[1]->is_scheduled() && pd[1]->start_time == now);
+      CHECK(pd[1]->allocated_res.at("cn0").cpu_set.core_ids == (std::set<uint32_t>{4, 5}));  // inside the reserved cores
+      CHECK(pd[2]->reason == "Reservation Not Found" && pd[3]->reason == "Reservation Not Found");
+      snap.reservations.clear();
+    }
+
     // --- MultiFactorPriority in front of the selection (JobScheduler.cpp:6735) ------------------------------
     {
       PriorityConfig pc;

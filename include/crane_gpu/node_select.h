@@ -50,11 +50,12 @@
 extern "C" {
 #endif
 
-#define CNS_ABI_VERSION 1u
+#define CNS_ABI_VERSION 2u /* 2: reservations (cns_resv_soa, `reservation` on running / pending jobs) */
 #define CNS_MAX_GRES_CLASSES 8u
 #define CNS_MAX_GRES_NAMES 4u
 #define CNS_MAX_NODE_TYPES 64u /* distinct res_total records per cycle */
 #define CNS_NODE_NONE 0xFFFFFFFFu
+#define CNS_RESV_NONE 0xFFFFFFFFu /* job / running job outside every reservation */
 #define CNS_TIME_INFINITE_FUTURE INT64_MAX /* absl::InfiniteFuture(), JobScheduler.h:302 */
 
 typedef enum cns_status {
@@ -73,9 +74,10 @@ typedef enum cns_reason {
   CNS_REASON_NONE = 0,               /* ""  : is_scheduled(), starts now            */
   CNS_REASON_PRIORITY = 1,           /* "Priority"                                   */
   CNS_REASON_RESOURCE = 2,           /* "Resource"                                   */
-  CNS_REASON_RESOURCE_RESERVED = 3,  /* "Resource Reserved" (needs reservations)     */
+  CNS_REASON_RESOURCE_RESERVED = 3,  /* "Resource Reserved" (JobScheduler.cpp:6799-6806) */
   CNS_REASON_PARTITION_NOT_FOUND = 4,/* "Partition Not Found"                        */
-  CNS_REASON_SKIPPED = 5             /* caller pre-set a reason (e.g. "License")     */
+  CNS_REASON_SKIPPED = 5,            /* caller pre-set a reason (e.g. "License")     */
+  CNS_REASON_RESERVATION_NOT_FOUND = 6 /* "Reservation Not Found" (JobScheduler.cpp:6756-6758) */
 } cns_reason;
 
 /* Scheduler constants (JobScheduler.h:266-270, CtldPublicDefs.h:82-83). */
@@ -126,7 +128,34 @@ typedef struct cns_running_soa {
   const uint64_t* alloc_core_lo;
   const uint64_t* alloc_core_hi;  /* may be NULL */
   const uint64_t* alloc_gres;     /* may be NULL */
+  const uint32_t* reservation;    /* [num_jobs] reservation index the job runs in (JobScheduler.cpp:6692-6707) or CNS_RESV_NONE; NULL = none */
 } cns_running_soa;
+
+/* Reservations of the cycle = what NodeSelect reads from g_meta_container->GetResvMetaMapPtr()
+ * (JobScheduler.cpp:6619-6679; ResvMeta: start_time, end_time, res_total per node).  Semantics kept:
+ *   now >= end_sec            : ignored ("expired but not cleaned up", :6631-6634);
+ *   start_sec <= now < end    : ACTIVE — its per-node resources count as allocated on the real node until end_sec
+ *                               (:6644-6652), and the reservation gets its own scheduler over virtual nodes whose
+ *                               res_total is the reserved share and whose time map ends at end_sec (:6657-6668,
+ *                               InitTimeAvailResMap(now, end) JobScheduler.h:301-338);
+ *   now < start_sec           : FUTURE — a dip [start,end) in the real node's time map and cost (:6669-6677,
+ *                               JobScheduler.h:305-308,502-506).
+ * Every non-expired reservation marks its nodes for the "Resource Reserved" pending reason (:6635-6642,6799-6806).
+ * Canonicalisation: the reference iterates a hash map of reservations (order unspecified, and the initial fp64
+ * node cost depends on it); here reservations are applied in ascending index. */
+typedef struct cns_resv_soa {
+  uint32_t num_resv;
+  uint32_t num_allocs;
+  const int64_t* start_sec;       /* [num_resv]                                      */
+  const int64_t* end_sec;         /* [num_resv]                                      */
+  const uint32_t* alloc_offsets;  /* [num_resv+1] CSR: res_total.EachNodeResMap()    */
+  const uint32_t* alloc_node;     /* distinct inside one reservation                 */
+  const int64_t* alloc_cpu_raw;
+  const uint64_t* alloc_mem;
+  const uint64_t* alloc_core_lo;
+  const uint64_t* alloc_core_hi;  /* may be NULL */
+  const uint64_t* alloc_gres;     /* may be NULL */
+} cns_resv_soa;
 
 /* Pending jobs in priority order (PdJobInScheduler, JobScheduler.h:92-170).
  * FIFO = ascending job id = input order (BasicPriority, JobScheduler.h:183-201). */
@@ -150,6 +179,9 @@ typedef struct cns_job_soa {
   const uint64_t* excl_offsets;     /* [J+1] CSR excluded_nodes; NULL = none         */
   const uint32_t* excl_nodes;
   const uint8_t* skip;              /* [J] non-zero: reason already set by the caller (JobScheduler.cpp:6744); NULL = 0 */
+  const uint32_t* reservation;      /* [J] reservation index the job is submitted to (then `partition` is not looked at,
+                                       JobScheduler.cpp:6525-6527,6754-6760) or CNS_RESV_NONE; NULL = none.  An index
+                                       >= num_resv, or a reservation that is not active, gives "Reservation Not Found" */
 } cns_job_soa;
 
 /* Results, caller-allocated. Job j owns records [place_offsets[j], place_offsets[j+1]),
@@ -191,6 +223,7 @@ void cns_destroy(cns_handle* h);
 
 /* Per-cycle snapshot. Copies everything; the caller keeps ownership of its buffers. */
 int cns_set_nodes(cns_handle* h, const cns_node_soa* nodes);
+int cns_set_reservations(cns_handle* h, const cns_resv_soa* resv);  /* after cns_set_nodes, before cns_set_running; NULL: none */
 int cns_set_running(cns_handle* h, const cns_running_soa* running); /* NULL or num_jobs==0: none */
 
 /* One scheduling cycle: pack+upload jobs, init node state, select, download placements.

@@ -116,9 +116,23 @@ int ora_binop(const cns_gres_layout* gl, int algebra, int op, const ora_res* a, 
 
 // ---- one scheduling cycle ---------------------------------------------------------------
 // Returns an opaque run handle through *run_out (free with ora_free) for the debug getters.
+static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
+                           const cns_resv_soa* resv, int64_t now, const cns_job_soa* jobs, cns_placement_soa* out,
+                           int algebra, void** run_out);
 int ora_select(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
                int64_t now, const cns_job_soa* jobs, cns_placement_soa* out, int algebra,
                void** run_out) {
+  return ora_select_impl(cfg, nodes, running, nullptr, now, jobs, out, algebra, run_out);
+}
+// ... with reservations (cns_resv_soa, include/crane_gpu/node_select.h)
+int ora_select_resv(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
+                    const cns_resv_soa* resv, int64_t now, const cns_job_soa* jobs, cns_placement_soa* out,
+                    int algebra, void** run_out) {
+  return ora_select_impl(cfg, nodes, running, resv, now, jobs, out, algebra, run_out);
+}
+static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
+                           const cns_resv_soa* resv, int64_t now, const cns_job_soa* jobs, cns_placement_soa* out,
+                           int algebra, void** run_out) {
   auto run = std::make_unique<OracleRun>();
   run->layout = layout_from(nodes->gres);
   u32 maxjobs = cfg && cfg->max_job_num_per_node ? cfg->max_job_num_per_node : 1000;
@@ -154,6 +168,24 @@ int ora_select(const cns_config* cfg, const cns_node_soa* nodes, const cns_runni
         m.gres = running->alloc_gres ? running->alloc_gres[a] : 0;
         rn[r].allocs.push_back({running->alloc_node[a], m});
       }
+      if (running->reservation) rn[r].reservation = running->reservation[r];
+    }
+  }
+  std::vector<Resv> rv;
+  if (resv) {
+    rv.resize(resv->num_resv);
+    for (u32 v = 0; v < resv->num_resv; ++v) {
+      rv[v].start_time = resv->start_sec[v];
+      rv[v].end_time = resv->end_sec[v];
+      for (u32 a = resv->alloc_offsets[v]; a < resv->alloc_offsets[v + 1]; ++a) {
+        MaskRes m;
+        m.cpu = resv->alloc_cpu_raw[a];
+        m.mem = resv->alloc_mem[a];
+        m.clo = resv->alloc_core_lo ? resv->alloc_core_lo[a] : 0;
+        m.chi = resv->alloc_core_hi ? resv->alloc_core_hi[a] : 0;
+        m.gres = resv->alloc_gres ? resv->alloc_gres[a] : 0;
+        rv[v].allocs.push_back({resv->alloc_node[a], m});
+      }
     }
   }
 
@@ -178,16 +210,17 @@ int ora_select(const cns_config* cfg, const cns_node_soa* nodes, const cns_runni
     if (jobs->excl_offsets)
       for (u64 i = jobs->excl_offsets[j]; i < jobs->excl_offsets[j + 1]; ++i) q.excluded_nodes.insert(jobs->excl_nodes[i]);
     q.skip = jobs->skip ? jobs->skip[j] != 0 : false;
+    if (jobs->reservation) q.reservation = jobs->reservation[j];
   }
 
   auto t0 = std::chrono::steady_clock::now();  // the reference's own bracket, JobScheduler.cpp:1439-1447
   if (algebra == 0) {
     run->mask = std::make_unique<SchedOracle<MaskAlgebra>>(MaskAlgebra(&run->layout), maxjobs, window);
-    run->mask->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch);
+    run->mask->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch, rv);
     run->jobs_ordered = run->mask->jobs_ordered();
   } else {
     run->lit = std::make_unique<SchedOracle<LitAlgebra>>(LitAlgebra(&run->layout), maxjobs, window);
-    run->lit->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch);
+    run->lit->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch, rv);
     run->jobs_ordered = run->lit->jobs_ordered();
   }
   run->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -127,15 +127,17 @@ class OracleRun:
 
 def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running | None = None,
            algebra: int = MASK, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0,
-           max_time_window_sec: int = 0) -> OracleRun:
+           max_time_window_sec: int = 0, reservations: abi.Reservations | None = None) -> OracleRun:
     cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, 0, scheduled_batch_size, max_job_num_per_node, 0,
                         max_time_window_sec)
     out = abi.Placements(jobs.num_jobs, jobs.total_places())
     cn, cj, co = cluster.to_c(), jobs.to_c(), out.to_c()
     cr = running.to_c() if running is not None else None
+    cv = reservations.to_c() if reservations is not None else None
     h = C.c_void_p()
-    rc = lib().ora_select(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
-                          C.c_int64(now), C.byref(cj), C.byref(co), algebra, C.byref(h))
+    rc = lib().ora_select_resv(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
+                               C.byref(cv) if cv is not None else None,
+                               C.c_int64(now), C.byref(cj), C.byref(co), algebra, C.byref(h))
     if rc != 0:
         raise RuntimeError(f"ora_select failed: {rc}")
     return OracleRun(h, out, cluster)

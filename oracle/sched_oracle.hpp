@@ -44,6 +44,7 @@ struct PdJob {  // PdJobInScheduler, JobScheduler.h:92-170 (fields used on this 
   bool exclusive = false;
   std::set<u32> included_nodes, excluded_nodes;
   bool skip = false;
+  u32 reservation = CNS_RESV_NONE;  // job->reservation (empty = CNS_RESV_NONE)
   // results
   i64 start_time = 0, end_time = 0;
   int reason = CNS_REASON_NONE;
@@ -53,7 +54,9 @@ struct PdJob {  // PdJobInScheduler, JobScheduler.h:92-170 (fields used on this 
 };
 
 struct RnAlloc { u32 node; MaskRes res; };
-struct RnJob { i64 end_time; std::vector<RnAlloc> allocs; };
+struct RnJob { i64 end_time; std::vector<RnAlloc> allocs; u32 reservation = CNS_RESV_NONE; };
+// ResvMeta (start_time, end_time, res_total per node) as read at JobScheduler.cpp:6627-6679
+struct Resv { i64 start_time, end_time; std::vector<RnAlloc> allocs; };
 
 template <class A>
 class SchedOracle {
@@ -63,19 +66,25 @@ class SchedOracle {
 
   struct NodeState {  // JobScheduler.h:272-460
     struct AllocatedRes { i64 end_time; Res res; };
+    struct ReservedRes { i64 start_time, end_time; Res res; };
     u32 idx;
     Res res_total;
     Res res_avail;
     std::vector<AllocatedRes> allocated_res;
+    std::vector<ReservedRes> reserved_res;  // future reservations, JobScheduler.h:288
     TimeAvailResMap time_avail_res_map;
   };
 
   SchedOracle(const A& alg, u32 max_job_num_per_node, i64 max_time_window)
       : A_(alg), kAlgoMaxJobNumPerNode(max_job_num_per_node), kAlgoMaxTimeWindow(max_time_window) {}
 
-  // -- NodeState::InitTimeAvailResMap, JobScheduler.h:301-338 (no reservations) --------
+  // -- NodeState::InitTimeAvailResMap, JobScheduler.h:301-338 ---------------------------
   void InitTimeAvailResMap(NodeState& ns, i64 now, i64 end = kInfiniteFuture) {
     std::vector<std::pair<i64, std::pair<bool, const Res*>>> resource_changes;
+    for (auto& rr : ns.reserved_res) {  // :305-308
+      resource_changes.emplace_back(rr.start_time, std::make_pair(true, &rr.res));
+      resource_changes.emplace_back(rr.end_time, std::make_pair(false, &rr.res));
+    }
     for (auto& ar : ns.allocated_res) {
       resource_changes.emplace_back(ar.end_time, std::make_pair(false, &ar.res));
       A_.sub(ns.res_avail, ar.res);
@@ -159,6 +168,8 @@ class SchedOracle {
 
   void AddNode(LocalScheduler& ls, i64 now, NodeState* ns) {  // :540-550 + NodeRater ctor :498-511
     double cost = 0.0;
+    for (const auto& rr : ns->reserved_res)  // :502-506
+      UpdateCost(cost, rr.start_time, rr.end_time, cpu_of(rr.res), cpu_of(ns->res_total));
     for (const auto& ar : ns->allocated_res)
       UpdateCost(cost, now, ar.end_time, cpu_of(ar.res), cpu_of(ns->res_total));
     ls.sel.m_node_info_map_.emplace(ns->idx, typename NodeSelector::NodeRater{ns, cost});
@@ -448,8 +459,13 @@ class SchedOracle {
   void NodeSelect(i64 now, const std::vector<MaskRes>& node_total,
                   const std::vector<uint8_t>& schedulable,
                   const std::vector<std::vector<u32>>& part_nodes, std::vector<RnJob>& running_jobs,
-                  std::vector<PdJob>& pending_jobs, u64 scheduled_batch_size) {
+                  std::vector<PdJob>& pending_jobs, u64 scheduled_batch_size,
+                  const std::vector<Resv>& resvs = {}) {
     for (auto& rn : running_jobs) rn.end_time = std::max(rn.end_time, now + 1);  // :6513-6514
+    // :6524-6530 reservations that have pending jobs (before ordering / batch limit)
+    std::vector<char> resv_has_pd(resvs.size(), 0);
+    for (const auto& job : pending_jobs)
+      if (job.reservation != CNS_RESV_NONE && job.reservation < resvs.size()) resv_has_pd[job.reservation] = 1;
 
     node_state_.clear();
     node_state_.resize(node_total.size());
@@ -461,19 +477,66 @@ class SchedOracle {
       ns->res_avail = ns->res_total;
       node_state_[n] = std::move(ns);
     }
-    for (const auto& job : running_jobs)  // :6681-6709
-      for (const auto& al : job.allocs)
-        if (al.node < node_state_.size() && node_state_[al.node])
-          node_state_[al.node]->allocated_res.push_back({job.end_time, A_.from_mask(al.res)});
+    // :6619-6679 reservations (canonical order: ascending index; the reference iterates a hash map)
+    first_resv_.assign(node_total.size(), kInfiniteFuture);
+    resv_node_state_.clear();
+    resv_node_state_.resize(resvs.size());
+    resv_end_.assign(resvs.size(), 0);
+    resv_live_.assign(resvs.size(), 0);
+    for (u32 v = 0; v < resvs.size(); ++v) {
+      const Resv& rv = resvs[v];
+      if (now >= rv.end_time) continue;  // expired
+      for (const auto& al : rv.allocs)
+        if (al.node < first_resv_.size()) first_resv_[al.node] = std::min(first_resv_[al.node], rv.start_time);
+      if (now >= rv.start_time) {
+        for (const auto& al : rv.allocs)
+          if (al.node < node_state_.size() && node_state_[al.node])
+            node_state_[al.node]->allocated_res.push_back({rv.end_time, A_.from_mask(al.res)});
+        if (!resv_has_pd[v]) continue;  // no pending jobs, skip
+        resv_live_[v] = 1;
+        resv_end_[v] = rv.end_time;
+        for (const auto& al : rv.allocs) {
+          auto ns = std::make_unique<NodeState>();
+          ns->idx = al.node;
+          ns->res_total = A_.from_mask(al.res);
+          ns->res_avail = ns->res_total;
+          resv_node_state_[v].emplace(al.node, std::move(ns));
+        }
+      } else {
+        for (const auto& al : rv.allocs)
+          if (al.node < node_state_.size() && node_state_[al.node])
+            node_state_[al.node]->reserved_res.push_back({rv.start_time, rv.end_time, A_.from_mask(al.res)});
+      }
+    }
+    for (const auto& job : running_jobs) {  // :6681-6709
+      if (job.reservation == CNS_RESV_NONE) {
+        for (const auto& al : job.allocs)
+          if (al.node < node_state_.size() && node_state_[al.node])
+            node_state_[al.node]->allocated_res.push_back({job.end_time, A_.from_mask(al.res)});
+      } else {
+        if (job.reservation >= resvs.size() || !resv_live_[job.reservation]) continue;  // "not found" (:6693-6700)
+        auto& m = resv_node_state_[job.reservation];
+        for (const auto& al : job.allocs) {
+          auto it = m.find(al.node);
+          if (it != m.end()) it->second->allocated_res.push_back({job.end_time, A_.from_mask(al.res)});
+        }
+      }
+    }
 
     for (auto& ns : node_state_)  // :6712-6714
       if (ns) InitTimeAvailResMap(*ns, now);
+    for (u32 v = 0; v < resvs.size(); ++v)  // :6715-6719
+      for (auto& [nid, ns] : resv_node_state_[v]) InitTimeAvailResMap(*ns, now, resv_end_[v]);
 
     part_scheduler_.clear();
     part_scheduler_.resize(part_nodes.size());
     for (size_t p = 0; p < part_nodes.size(); ++p)  // :6723-6728 (JobScheduler.h:603-612)
       for (u32 n : part_nodes[p])
         if (node_state_[n]) AddNode(part_scheduler_[p], now, node_state_[n].get());
+    resv_scheduler_.clear();
+    resv_scheduler_.resize(resvs.size());
+    for (u32 v = 0; v < resvs.size(); ++v)  // :6729-6732
+      for (auto& [nid, ns] : resv_node_state_[v]) AddNode(resv_scheduler_[v], now, ns.get());
 
     // BasicPriority::GetOrderedJobPtrVec, JobScheduler.h:185-200
     size_t len = pending_jobs.size();
@@ -484,11 +547,21 @@ class SchedOracle {
     for (size_t i = 0; i < len; ++i) {  // :6743-6835
       PdJob* job = &pending_jobs[i];
       if (job->skip) { job->reason = CNS_REASON_SKIPPED; continue; }  // :6744
-      if (job->partition >= part_scheduler_.size()) {  // :6748-6752
-        job->reason = CNS_REASON_PARTITION_NOT_FOUND;
-        continue;
+      LocalScheduler* sched_ptr;
+      if (job->reservation == CNS_RESV_NONE) {
+        if (job->partition >= part_scheduler_.size()) {  // :6748-6752
+          job->reason = CNS_REASON_PARTITION_NOT_FOUND;
+          continue;
+        }
+        sched_ptr = &part_scheduler_[job->partition];
+      } else {
+        if (job->reservation >= resv_scheduler_.size() || !resv_live_[job->reservation]) {  // :6754-6759
+          job->reason = CNS_REASON_RESERVATION_NOT_FOUND;
+          continue;
+        }
+        sched_ptr = &resv_scheduler_[job->reservation];
       }
-      LocalScheduler& scheduler = part_scheduler_[job->partition];
+      LocalScheduler& scheduler = *sched_ptr;
       bool ok = CalculateRunningNodesAndStartTime_(scheduler, now, job);
       if (!ok) {
         job->reason = CNS_REASON_RESOURCE;  // :6768
@@ -499,12 +572,28 @@ class SchedOracle {
       } else {
         job->end_time = job->start_time + job->time_limit;  // :6772
         AllocateResource(scheduler, job->start_time, job->end_time, job->allocated_res);  // :6795
-        if (job->start_time != now) {  // :6797-6833 (no reservations -> no "Resource Reserved")
-          for (u32 nid : job->craned_ids) {
-            const Res& res_avail = node_state_[nid]->res_avail;
-            if (!A_.le(A_.from_mask(job->allocated_res.at(nid)), res_avail)) {
-              job->reason = CNS_REASON_RESOURCE;
-              break;
+        if (job->start_time != now) {  // :6797-6833
+          if (job->reservation == CNS_RESV_NONE) {
+            for (u32 nid : job->craned_ids)
+              if (first_resv_[nid] != kInfiniteFuture && first_resv_[nid] < now + job->time_limit) {  // :6799-6806
+                job->reason = CNS_REASON_RESOURCE_RESERVED;
+                break;
+              }
+            if (job->reason != CNS_REASON_NONE) continue;
+            for (u32 nid : job->craned_ids) {
+              const Res& res_avail = node_state_[nid]->res_avail;
+              if (!A_.le(A_.from_mask(job->allocated_res.at(nid)), res_avail)) {
+                job->reason = CNS_REASON_RESOURCE;
+                break;
+              }
+            }
+          } else {
+            for (u32 nid : job->craned_ids) {
+              const Res& res_avail = resv_node_state_[job->reservation].at(nid)->res_avail;
+              if (!A_.le(A_.from_mask(job->allocated_res.at(nid)), res_avail)) {
+                job->reason = CNS_REASON_RESOURCE;
+                break;
+              }
             }
           }
           if (job->reason == CNS_REASON_NONE) job->reason = CNS_REASON_PRIORITY;
@@ -516,6 +605,9 @@ class SchedOracle {
   double CostOf(u32 part, u32 node) const { return part_scheduler_[part].sel.m_node_info_map_.at(node).cost; }
   bool HasNode(u32 node) const { return node < node_state_.size() && node_state_[node] != nullptr; }
   const TimeAvailResMap& Timeline(u32 node) const { return node_state_[node]->time_avail_res_map; }
+  bool HasResvNode(u32 v, u32 node) const { return v < resv_node_state_.size() && resv_node_state_[v].count(node) != 0; }
+  const TimeAvailResMap& ResvTimeline(u32 v, u32 node) const { return resv_node_state_[v].at(node)->time_avail_res_map; }
+  double ResvCostOf(u32 v, u32 node) const { return resv_scheduler_[v].sel.m_node_info_map_.at(node).cost; }
   const A& alg() const { return A_; }
   u64 jobs_ordered() const { return jobs_ordered_; }
 
@@ -533,6 +625,11 @@ class SchedOracle {
   const i64 kAlgoMaxTimeWindow;
   std::vector<std::unique_ptr<NodeState>> node_state_;
   std::vector<LocalScheduler> part_scheduler_;
+  // reservations: per reservation its own NodeStates (res_total = the reserved share) and scheduler
+  std::vector<std::map<u32, std::unique_ptr<NodeState>>> resv_node_state_;
+  std::vector<LocalScheduler> resv_scheduler_;
+  std::vector<i64> resv_end_, first_resv_;
+  std::vector<char> resv_live_;
   u64 jobs_ordered_ = 0;
 };
 

@@ -1,0 +1,207 @@
+"""Reservations inside NodeSelect (JobScheduler.cpp:6619-6679,6692-6707,6715-6719,6729-6732,6754-6760,
+6797-6830; InitTimeAvailResMap JobScheduler.h:301-338; NodeRater JobScheduler.h:498-511).
+
+Hand-derived scenarios (expectations written from the cited lines before running anything), checked against
+the CPU oracle here and against the HIP engine under `-m gpu`; plus random cases engine-vs-oracle."""
+import numpy as np
+import pytest
+
+from cranesched_amd import abi
+from oracle import pyoracle
+from tests import helpers, kat
+
+NOW = kat.NOW
+GIB = 1 << 30
+R = abi  # reason codes
+
+
+def _resv(specs):
+    """specs: list of (start, end, [(node, cpus, mem_gib, core_lo)])"""
+    off, node, cpu, mem, lo = [0], [], [], [], []
+    for _, _, al in specs:
+        for n, c, m, l in al:
+            node.append(n); cpu.append(c * 256); mem.append(m * GIB); lo.append(l)
+        off.append(len(node))
+    z = [0] * len(node)
+    return abi.Reservations([s[0] for s in specs], [s[1] for s in specs], off, node, cpu, mem, lo, z, z)
+
+
+def _running(specs):
+    """specs: list of (end, resv_or_None, [(node, cpus, mem_gib, core_lo)])"""
+    off, node, cpu, mem, lo = [0], [], [], [], []
+    for _, _, al in specs:
+        for n, c, m, l in al:
+            node.append(n); cpu.append(c * 256); mem.append(m * GIB); lo.append(l)
+        off.append(len(node))
+    z = [0] * len(node)
+    return abi.Running([s[0] for s in specs], off, node, cpu, mem, lo, z, z,
+                       reservation=[abi.RESV_NONE if s[1] is None else s[1] for s in specs])
+
+
+def scenario_future_dip():
+    # one node, 4 cores / 16 GiB; a FUTURE reservation takes the whole node during [NOW+100, NOW+200)
+    #   time map: {NOW: 4c, NOW+100: 0c, NOW+200: 4c, INF: 0}  (reserved_res: - at start, + at end, h:305-308,326-334)
+    #   initial cost = (200-100) * 4/4 = 100   (NodeRater ctor, reserved_res first, h:502-506)
+    # job 0: 4c, L=50  -> window [NOW, NOW+50) is free -> starts now, cost 100 + 50 = 150
+    # job 1: 4c, L=150 -> no 150 s gap before the dip; first fit after it: NOW+200; start != now and the node's
+    #                     first reservation (NOW+100) < now + L (NOW+150) -> "Resource Reserved" (:6799-6806)
+    # job 2: 2c, L=50  -> [NOW+50, NOW+100) has 4c free (job 0 ended, dip not yet) -> start NOW+50;
+    #                     first_resv NOW+100 < NOW+50?  now + L = NOW+50: 1100 < 1050 is false -> not reserved;
+    #                     alloc (2c) <= res_avail (4c at cycle start) -> "Priority"
+    c = kat.cluster([4])
+    j = kat.jobs([dict(cpu=4, L=50), dict(cpu=4, L=150), dict(cpu=2, L=50)])
+    rv = _resv([(NOW + 100, NOW + 200, [(0, 4, 16, 0xF)])])
+    exp = {0: (R.REASON_NONE, NOW, 0xF), 1: (R.REASON_RESOURCE_RESERVED, NOW + 200, 0xF),
+           2: (R.REASON_PRIORITY, NOW + 50, 0x3)}
+    return c, j, None, rv, exp
+
+
+def scenario_active_resv():
+    # node 0: 8 cores / 16 GiB.  Reservation 0 is ACTIVE [NOW-10, NOW+500): 4 cores {4..7}, 8 GiB of node 0.
+    # Reservation 1 is in the future, reservation 2 expired.
+    #   real node 0: avail now = 4 cores {0..3}, 8 GiB until NOW+500 (allocated_res gets {resv end, res}, :6644-6652)
+    #   virtual node (resv 0, node 0): total 4 cores {4..7}, 8 GiB; a job running inside the reservation holds core 4
+    #   until NOW+50; its time map ends at NOW+500 (InitTimeAvailResMap(now, end), h:337)
+    # job 0 (no resv) 6c L=100: not now (4 free); earliest NOW+500; first_resv NOW-10 < now+100 -> "Resource Reserved"
+    # job 1 (resv 0)  2c L=100: starts now on the virtual node, lowest free reserved cores {5,6}
+    # job 2 (resv 0)  4c L=600: never fits before the reservation ends -> "Resource", no start
+    # job 3 (resv 0)  2c L=100: now only 1 reserved core is free (7) until NOW+50 -> cores free at NOW+50: {4,7};
+    #                          allocation against res_total takes the lowest two reserved cores {4,5} (:6353-6361);
+    #                          {4,5} <= avail needs cpu/mem only... entry at NOW+50 has 2 cpus free but job 1 holds {5,6}
+    #                          until NOW+100: operator<= compares cpu count, mem and GRES slots, not core ids
+    #                          (PublicHeader.cpp:886-890) -> fits at NOW+50; reason: alloc cpu 2 <= res_avail cpu 3 -> "Priority"
+    # job 4 (resv 1, future) -> "Reservation Not Found"; job 5 (resv 9, unknown) -> same; job 6 (resv 2, expired) -> same
+    c = kat.cluster([8])
+    specs = [dict(cpu=6, L=100), dict(cpu=2, L=100), dict(cpu=4, L=600), dict(cpu=2, L=100),
+             dict(cpu=1, L=10), dict(cpu=1, L=10), dict(cpu=1, L=10)]
+    j = kat.jobs(specs)
+    j.reservation = np.array([abi.RESV_NONE, 0, 0, 0, 1, 9, 2], np.uint32)
+    rv = _resv([(NOW - 10, NOW + 500, [(0, 4, 8, 0xF0)]), (NOW + 1000, NOW + 2000, [(0, 1, 1, 0x1)]),
+                (NOW - 500, NOW - 100, [(0, 8, 16, 0xFF)])])
+    rn = _running([(NOW + 50, 0, [(0, 1, 1, 0x10)])])
+    exp = {0: (R.REASON_RESOURCE_RESERVED, NOW + 500, 0x3F), 1: (R.REASON_NONE, NOW, 0x60),
+           2: (R.REASON_RESOURCE, 0, None), 3: (R.REASON_PRIORITY, NOW + 50, 0x30),
+           4: (R.REASON_RESERVATION_NOT_FOUND, 0, None), 5: (R.REASON_RESERVATION_NOT_FOUND, 0, None),
+           6: (R.REASON_RESERVATION_NOT_FOUND, 0, None)}
+    return c, j, rn, rv, exp
+
+
+SCENARIOS = {"future_dip": scenario_future_dip, "active_resv": scenario_active_resv}
+
+
+def _check(got, exp):
+    for ji, (reason, start, cores) in exp.items():
+        assert int(got.reason[ji]) == reason, f"job {ji}: reason {got.reason[ji]} != {reason}"
+        assert int(got.start_sec[ji]) == start, f"job {ji}: start {got.start_sec[ji]} != {start}"
+        if cores is not None:
+            o = int(got.place_offsets[ji])
+            assert int(got.core_lo[o]) == cores, f"job {ji}: cores {int(got.core_lo[o]):#x} != {cores:#x}"
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+@pytest.mark.parametrize("algebra", [pyoracle.MASK, pyoracle.LITERAL])
+def test_oracle_reservation_kat(name, algebra):
+    c, j, rn, rv, exp = SCENARIOS[name]()
+    ref = pyoracle.select(c, j, NOW, running=rn, reservations=rv, algebra=algebra)
+    _check(ref.placements if hasattr(ref, "placements") else ref, exp)
+
+
+def random_resv_case(seed, N=48, J=400, V=6):
+    c, j, now, run = helpers.random_case(seed, N=N, J=J, P=2, running=20, general=True, lists=False, exclusive=True)
+    rng = np.random.default_rng(4242 + seed)
+    specs = []
+    for v in range(V):
+        kind = v % 3   # active / future / expired
+        if kind == 0: s, e = now - int(rng.integers(1, 500)), now + int(rng.integers(2000, 9000))
+        elif kind == 1: s = now + int(rng.integers(100, 4000)); e = s + int(rng.integers(500, 5000))
+        else: s, e = now - 5000, now - int(rng.integers(1, 100))
+        nodes = rng.choice(N, size=int(rng.integers(2, 8)), replace=False)
+        al = []
+        for n in nodes:
+            cores = int(c.cpu_total_raw[n] // 256)
+            take = int(rng.integers(1, max(2, cores // 4)))
+            first = int(rng.integers(0, min(cores, 64) - take + 1))
+            al.append((int(n), take, max(1, take), ((1 << take) - 1) << first))
+        specs.append((s, e, al))
+    rv = _resv(specs)
+    resv = np.full(j.num_jobs, abi.RESV_NONE, np.uint32)
+    pick = rng.random(j.num_jobs) < 0.25
+    resv[pick] = rng.integers(0, V + 1, int(pick.sum()))   # V = unknown reservation
+    j.reservation = resv
+    # some running jobs live inside the active reservations (on their nodes, inside the reserved cores)
+    end = list(run.end_sec); off = list(run.alloc_offsets); node = list(run.alloc_node); cpu = list(run.alloc_cpu_raw)
+    mem = list(run.alloc_mem); lo = list(run.alloc_core_lo); hi = list(run.alloc_core_hi); g = list(run.alloc_gres)
+    rres = [abi.RESV_NONE] * len(end)
+    for v, (s_, e_, al) in enumerate(specs):
+        if v % 3 != 0:
+            continue
+        for (n, take, m_gib, mask) in al[:2]:
+            low = mask & -mask                      # lowest reserved core
+            end.append(now + int(rng.integers(10, 3000))); rres.append(v)
+            node.append(n); cpu.append(256); mem.append(GIB // 2); lo.append(low); hi.append(0); g.append(0)
+            off.append(len(node))
+    run = abi.Running(end, off, node, cpu, mem, lo, hi, g, reservation=rres)
+    return c, j, now, run, rv
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_oracle_reservation_random_lit_vs_mask(seed):
+    c, j, now, run, rv = random_resv_case(seed)
+    a = pyoracle.select(c, j, now, running=run, reservations=rv, algebra=pyoracle.MASK)
+    b = pyoracle.select(c, j, now, running=run, reservations=rv, algebra=pyoracle.LITERAL)
+    pa = a.placements if hasattr(a, "placements") else a
+    pb = b.placements if hasattr(b, "placements") else b
+    assert (pa.reason[:j.num_jobs] == pb.reason[:j.num_jobs]).all()
+    assert (pa.start_sec[:j.num_jobs] == pb.start_sec[:j.num_jobs]).all()
+    r = pa.reason[:j.num_jobs]
+    assert (r == R.REASON_RESOURCE_RESERVED).sum() > 0 and (r == R.REASON_RESERVATION_NOT_FOUND).sum() > 0
+
+
+# ---- GPU parity ------------------------------------------------------------------------------------------
+
+def _gpu_run(engine_cls, c, j, now, rn, rv, **cfg):
+    eng = engine_cls(device=0, **cfg)
+    try:
+        eng.set_nodes(c)
+        eng.set_reservations(rv)
+        eng.set_running(rn)
+        got = eng.node_select(now, j)
+        ref = pyoracle.select(c, j, now, running=rn, reservations=rv, **cfg)
+        helpers.assert_same(eng, got, ref, c, tag="resv")
+        return got
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_gpu_reservation_kat(engine_cls, name):
+    c, j, rn, rv, exp = SCENARIOS[name]()
+    got = _gpu_run(engine_cls, c, j, NOW, rn, rv)
+    _check(got, exp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_gpu_reservation_random(engine_cls, seed):
+    c, j, now, run, rv = random_resv_case(seed)
+    got = _gpu_run(engine_cls, c, j, now, run, rv)
+    r = got.reason[:j.num_jobs]
+    assert (r == R.REASON_RESERVATION_NOT_FOUND).sum() > 0
+
+
+@pytest.mark.gpu
+def test_gpu_reservations_then_none(engine_cls):
+    # the same handle: a cycle with reservations, then one without (cns_set_nodes resets the layout)
+    c, j, now, run, rv = random_resv_case(11)
+    eng = engine_cls(device=0)
+    try:
+        eng.set_nodes(c); eng.set_reservations(rv); eng.set_running(run)
+        a = eng.node_select(now, j)
+        j2 = abi.Jobs(**{f: getattr(j, f) for f in j.__dataclass_fields__ if f != "reservation"})
+        eng.set_nodes(c); eng.set_running(run)
+        b = eng.node_select(now, j2)
+        ref = pyoracle.select(c, j2, now, running=run)
+        helpers.assert_same(eng, b, ref, c, tag="no-resv after resv")
+    finally:
+        eng.close()
