@@ -30,6 +30,14 @@ CASES = {
     "hetero_5": lambda: helpers.random_case(5),
 }
 
+# cases with reservations: (cluster, jobs, now, running, reservations)
+def _resv_case(seed):
+    from tests import test_reservations
+    return test_reservations.random_resv_case(seed)
+
+
+RESV_CASES = {"resv_1": lambda: _resv_case(1), "resv_4": lambda: _resv_case(4)}
+
 
 def main():
     for name, make in CASES.items():
@@ -40,6 +48,14 @@ def main():
         t = r.placements.trimmed()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), costs=r.costs().view(np.uint64), **t)
         print(name, j.num_jobs, "jobs", np.bincount(t["reason"], minlength=3))
+    for name, make in RESV_CASES.items():
+        c, j, now, run, rv = make()
+        r = pyoracle.select(c, j, now, running=run, reservations=rv)
+        r2 = pyoracle.select(c, j, now, running=run, reservations=rv, algebra=pyoracle.LITERAL)
+        assert r.placements.diff(r2.placements) is None, name
+        t = r.placements.trimmed()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), costs=r.costs().view(np.uint64), **t)
+        print(name, j.num_jobs, "jobs", np.bincount(t["reason"], minlength=7))
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
-from tests.golden.make_golden import CASES, HERE
+from tests.golden.make_golden import CASES, HERE, RESV_CASES
 
 
 def load(name):
@@ -24,4 +24,11 @@ def compare(name, placements, costs):
 def test_oracle_matches_golden(name):
     c, j, now, run = CASES[name]()
     r = pyoracle.select(c, j, now, running=run)
+    compare(name, r.placements, r.costs())
+
+
+@pytest.mark.parametrize("name", sorted(RESV_CASES))
+def test_oracle_matches_golden_reservations(name):
+    c, j, now, run, rv = RESV_CASES[name]()
+    r = pyoracle.select(c, j, now, running=run, reservations=rv)
     compare(name, r.placements, r.costs())
