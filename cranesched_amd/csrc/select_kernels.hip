@@ -1,25 +1,33 @@
 // gfx950 (MI355X / CDNA4) kernels of the node-selection engine.  Hand-written HIP; no MFMA — this is
-// integer / bitmask work bound by memory latency and LDS, not a dense contraction.
+// integer / bitmask work bound by the latency of a serial chain and by one CU's VALU, not a dense contraction.
 //
-// k_init_nodes : one thread per partition slot — NodeSelect's prologue on device:
-//                res_avail = res_total - running allocations, the per-node time map and the initial
-//                fp64 cost (src/CraneCtld/JobScheduler.cpp:6681-6732, JobScheduler.h:301-338,498-511).
-// k_select<NPL>: ONE 1024-thread workgroup per partition (independent LocalScheduler,
-//                JobScheduler.cpp:6723-6727), persistent over that partition's whole job queue, because
-//                job j+1 depends on job j's commit (SURVEY.md §7 "sequential semantics").  The
+// k_init_nodes : one thread per slot (a partition's node, or the virtual node of a reservation) — NodeSelect's
+//                prologue on device: res_avail = res_total - active reservations - running allocations, the
+//                per-node time map incl. future-reservation dips, the initial fp64 cost and the node's first
+//                reservation (src/CraneCtld/JobScheduler.cpp:6619-6732, JobScheduler.h:301-338,498-511).
+// k_prep_jobs  : one thread per pending job — everything about a job that does not depend on the evolving
+//                node state (minimum view, request side of the scanners' filters, GRES request shape, the
+//                "fits res_total" mask over the node types), written into the job record.
+// k_select<NPL>: ONE 512-thread workgroup per partition (independent LocalScheduler, JobScheduler.cpp:6723-6732),
+//                persistent over that partition's whole job queue, because job j+1 depends on job j's commit
+//                (SURVEY.md §7 "sequential semantics").  8 waves = 2 per SIMD = 256 VGPRs per lane.  The
 //                workgroup is wave-specialised:
-//                  waves 1..15 "scanners": the partition's node tile lives in their registers (each lane
-//                     owns NPL nodes: fp64 cost + a "front" summary of what is free now).  Per round they
-//                     filter their nodes against the job and deliver — wave64 shuffle argmin, then a
-//                     16-slot LDS reduce — the next node in (cost, index) order that may pass, i.e. the
-//                     reference's cost-ordered walk (JobScheduler.cpp:6188-6300) without the walk.
-//                  wave 0 "worker": exact test of that node — ONE coalesced read of its NodeBlock
+//                  waves 1..7 "scanners": the partition's node tile lives in their registers (each lane owns
+//                     NPL nodes: fp64 cost + a "front" summary of what is free now).  They filter their nodes
+//                     against a job and deliver — wave64 DPP argmin, then an LDS exchange — the next node in
+//                     (cost, index) order that may pass, i.e. the reference's cost-ordered walk
+//                     (JobScheduler.cpp:6188-6300) without the walk.  While the worker handles job j they
+//                     PRE-SCAN job j+1 over every node job j cannot change.
+//                  wave 0 "worker": exact test of the delivered node — ONE coalesced read of its NodeBlock
 //                     (header + time map, lane i <- entry i), wave-parallel window-min (Ckmin),
 //                     GetFeasibleResourceInNode on bit masks — then the commit straight from registers:
-//                     sorted-array update of the time map, fp64 cost update, LDS broadcast of the new
-//                     summary to the owning scanner lane.  Jobs that cannot start now get their nodes
-//                     by total capacity from the same scan and the earliest start by a bit-scan over
-//                     the time map's "alloc fits" ballot (backfill, JobScheduler.h:792-865).
+//                     sorted-array update of the time map, fp64 cost update, LDS broadcast of the new summary
+//                     to the owning scanner lane; then it merges the one changed node into the pre-scan of
+//                     the next job.  Jobs that cannot start now get their nodes by total capacity from the
+//                     same scan and the earliest start by a bit-scan over the time map's "alloc fits" ballot
+//                     (backfill, JobScheduler.h:792-865).
+//                  multi-node jobs: per-wave top-k lists, k-way merge by the worker, one helper wave per node
+//                     for the exact tests and the commits.
 // Compile with -ffp-contract=off (fp64 cost must match the CPU bit for bit).
 #include <hip/hip_runtime.h>
 
