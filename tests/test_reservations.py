@@ -205,3 +205,29 @@ def test_gpu_reservations_then_none(engine_cls):
         helpers.assert_same(eng, b, ref, c, tag="no-resv after resv")
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_gpu_reservation_argument_checks(engine_cls):
+    from cranesched_amd.engine import EngineError
+    c = kat.cluster([4, 4])
+    eng = engine_cls(device=0)
+    try:
+        with pytest.raises(EngineError) as ei:                       # call order
+            eng.set_reservations(_resv([(NOW, NOW + 10, [(0, 1, 1, 0x1)])]))
+        assert ei.value.status == -5
+        eng.set_nodes(c)
+        with pytest.raises(EngineError) as ei:                       # node listed twice in one reservation
+            eng.set_reservations(_resv([(NOW, NOW + 10, [(0, 1, 1, 0x1), (0, 1, 1, 0x2)])]))
+        assert ei.value.status == -1
+        with pytest.raises(EngineError) as ei:                       # node outside the cluster
+            eng.set_reservations(_resv([(NOW, NOW + 10, [(7, 1, 1, 0x1)])]))
+        assert ei.value.status == -1
+        # a valid one, then none: back to the plain layout
+        eng.set_reservations(_resv([(NOW - 5, NOW + 50, [(1, 2, 2, 0x3)])]))
+        eng.set_reservations(None)
+        j = kat.jobs([dict(cpu=4, L=10), dict(cpu=4, L=10)])
+        got = eng.node_select(NOW, j)
+        assert got.reason[:2].tolist() == [0, 0] and sorted(got.node_idx[:2].tolist()) == [0, 1]
+    finally:
+        eng.close()
