@@ -246,6 +246,35 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
     ord.reserve(pending_jobs.size());
     for (const auto& j : pending_jobs) ord.push_back(j.get());
   }
+  // ---- license pre-pass (JobScheduler.cpp:6739; LicenseManager::CheckLicenseCountSufficient, LicenseManager.cpp:167-221)
+  {
+    std::unordered_map<std::string, License> avail = licenses_;  // the cycle's working copy (:169-176)
+    for (PdJobInScheduler* job : ord) {
+      if (job->req_licenses.empty()) continue;
+      job->actual_licenses.clear();
+      if (job->is_license_or) {  // first alternative that fits (:183-194)
+        for (const auto& [key, count] : job->req_licenses) {
+          auto it = avail.find(key);
+          if (it == avail.end()) continue;
+          const License& lic = it->second;
+          if ((uint64_t)count + lic.reserved + lic.used + lic.last_deficit <= lic.total) {
+            job->actual_licenses.emplace(key, count);
+            break;
+          }
+        }
+      } else {                   // all of them (:195-210)
+        for (const auto& [key, count] : job->req_licenses) {
+          auto it = avail.find(key);
+          if (it == avail.end()) { job->actual_licenses.clear(); break; }
+          const License& lic = it->second;
+          if ((uint64_t)count + lic.reserved + lic.used + lic.last_deficit > lic.total) { job->actual_licenses.clear(); break; }
+          job->actual_licenses.emplace(key, count);
+        }
+      }
+      if (job->actual_licenses.empty()) { job->reason = "License"; continue; }  // :212-215
+      for (const auto& [key, count] : job->actual_licenses) avail[key].used += count;  // :217-219
+    }
+  }
   const size_t J = ord.size();
   std::vector<uint32_t> part(J), k(J), nt(J), tmin(J), tmax(J);
   std::vector<int64_t> L(J), ncpu(J), tcpu(J);

@@ -112,6 +112,10 @@ struct PdJobInScheduler {  // JobScheduler.h:92-170
   std::vector<CranedId> craned_ids;
   std::string reason;
   bool is_scheduled() const { return reason.empty(); }
+  // licenses (JobScheduler.h:141-146; LicenseManager::CheckLicenseCountSufficient, LicenseManager.cpp:167-221)
+  std::vector<std::pair<std::string, uint32_t>> req_licenses;   // (license id, count), request order
+  bool is_license_or{false};
+  std::unordered_map<std::string, uint32_t> actual_licenses;    // result
   // read / written by MultiFactorPriority (JobScheduler.cpp:7616, :7664-7690, :7759-7767)
   TimeSec submit_time{0};
   std::string account;
@@ -142,6 +146,11 @@ struct ClusterSnapshot {
   std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
   std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
   std::vector<ResvMeta> reservations;                                     // g_meta_container->GetResvMetaMapPtr(); vector order = canonical order
+};
+
+// License (LicenseManager: total, used, reserved, last_deficit as read at LicenseManager.cpp:188-189,203-204)
+struct License {
+  uint32_t total{0}, used{0}, reserved{0}, last_deficit{0};
 };
 
 // g_config.PriorityConfig, CtldPublicDefs.h:162-174
@@ -206,6 +215,11 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // Optional: the sorter NodeSelect consults first (SchedulerAlgo's ctor argument, JobScheduler.h:247);
   // nullptr = BasicPriority (input order, JobScheduler.h:185-200).  Not owned.
   void SetPrioritySorter(IPrioritySorter* sorter) { sorter_ = sorter; }
+  // The cycle's license table for the pre-pass NodeSelect runs between ordering and selection
+  // (g_license_manager->CheckLicenseCountSufficient, JobScheduler.cpp:6739; LicenseManager.cpp:167-221): a tiny
+  // sequential counter pass over the ordered jobs, done on the host; jobs it rejects get reason "License" and are
+  // not given to the device.  Empty table + no requests = no-op.
+  void SetLicenses(std::unordered_map<std::string, License> licenses) { licenses_ = std::move(licenses); }
 
   void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
                   const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) override;
@@ -218,6 +232,7 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   struct Impl;
   std::unique_ptr<Impl> impl_;
   IPrioritySorter* sorter_{nullptr};
+  std::unordered_map<std::string, License> licenses_;
   uint64_t batch_{0};
   int status_{0};
   std::string error_;

@@ -105,6 +105,30 @@ int main(int argc, char** argv) {
     CHECK(pd[1]->is_scheduled() && pd[1]->craned_ids[0] == "gn1");
     CHECK((pd[1]->allocated_res.at("gn1").gres.at("gpu").at("a100") == std::set<SlotId>{"/dev/nvidia0", "/dev/nvidia1"}));
 
+    // --- license pre-pass (LicenseManager.cpp:167-221) ----------------------------------------------------
+    {
+      snap.craned_metas = {node("cn0", 8, 64)};
+      snap.partitions = {{"CPU", {"cn0"}}};
+      algo.SetClusterSnapshot(snap);
+      algo.SetLicenses({{"matlab", License{3, 1, 0, 0}}, {"ansys", License{1, 0, 1, 0}}});
+      pd.clear();
+      auto a = job(1, 1, 10); a->req_licenses = {{"matlab", 2}};                      // 2 + 1 used <= 3: ok, used -> 3
+      auto b = job(2, 1, 10); b->req_licenses = {{"matlab", 1}};                      // 1 + 3 > 3: "License"
+      auto c = job(3, 1, 10); c->req_licenses = {{"ansys", 1}, {"matlab", 1}}; c->is_license_or = true;  // neither fits
+      auto d = job(4, 1, 10); d->req_licenses = {{"nope", 1}};                        // unknown license
+      auto e = job(5, 1, 10);                                                         // no license request
+      pd.push_back(std::move(a)); pd.push_back(std::move(b)); pd.push_back(std::move(c)); pd.push_back(std::move(d));
+      pd.push_back(std::move(e));
+      std::vector<std::unique_ptr<RnJobInScheduler>> none;
+      algo.NodeSelect(now, none, pd);
+      CHECK(algo.Ok());
+      CHECK(pd[0]->is_scheduled() && pd[0]->actual_licenses.at("matlab") == 2);
+      CHECK(pd[1]->reason == "License" && pd[2]->reason == "License" && pd[3]->reason == "License");
+      CHECK(pd[4]->is_scheduled());
+      CHECK(pd[4]->allocated_res.at("cn0").cpu_set.core_ids == (std::set<uint32_t>{1}));  // rejected jobs took nothing
+      algo.SetLicenses({});
+    }
+
     // --- reservations (JobScheduler.cpp:6619-6679, 6754-6760, 6797-6806) -----------------------------------
     {
       snap.craned_metas = {node("cn0", 8, 16)};
