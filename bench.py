@@ -58,8 +58,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X; the engine has no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # CNS_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, all-gather of the packed placements) on one
+    # rank too — a self-test of that path on a 1-GPU box; the reported line is then not a headline number
+    use_dist = world > 1 or os.environ.get("CNS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     cluster, jobs, now = synth.make_config(args.config, J=args.jobs, N=args.nodes)
@@ -71,7 +75,7 @@ def main():
     h2d_ms = eng.timing()["h2d_ms"]
 
     gather_in = gather_out = None
-    if world > 1:
+    if use_dist:
         ptr, nbytes = eng.device_results()
         mx = torch.tensor([nbytes], device=dev, dtype=torch.int64)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -82,14 +86,14 @@ def main():
 
     def step():
         eng.run_resident(now)                      # init kernel + persistent selection kernel (synchronous)
-        if world > 1:                              # merge per-shard node claims: one all-gather over xGMI
+        if use_dist:                               # merge per-shard node claims: one all-gather over xGMI
             gather_in[:nbytes].copy_(src)
             dist.all_gather_into_tensor(gather_out, gather_in)
 
     for _ in range(args.warmup):
         step()
     sel_ms, init_ms = [], []
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -99,13 +103,13 @@ def main():
         sel_ms.append(t["select_ms"])
         init_ms.append(t["init_ms"])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tm = eng.timing()
     ordered = torch.tensor([tm["jobs_ordered"]], device=dev, dtype=torch.int64)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ordered, op=dist.ReduceOp.SUM)
     elapsed = float(el.item())
@@ -158,7 +162,7 @@ def main():
                 "host_cpus": os.cpu_count()}
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
