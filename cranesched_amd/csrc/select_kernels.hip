@@ -1285,7 +1285,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
 // the commit.
 // ---------------------------------------------------------------------------------------------
 // Commit of candidate i from the helper's registers + owner update i + its placement record.
-__device__ __forceinline__ void helper_commit_regs(const KParams& P, const JobCtx& J, const HeapEnt* H, u32 i, u32 p,
+__device__ __forceinline__ void helper_commit_regs(const KParams& P, const GresDev& G, const JobCtx& J, const HeapEnt* H, u32 i, u32 p,
                                                    double cost0, NodeHdr* hd, const NodeHdr& h, const TlEntry& e,
                                                    const Res& res, i64 start, u32 lane, UpdRec* upd, u32 q) {
   const i64 end = start + J.L;
@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void helper_commit_regs(const KParams& P, const JobCt
     u.has_front = (start == P.now) ? 1u : 0u;
     Res f = e0;
     if (u.has_front) res_sub(f, res);
-    u.fcpu = clamp_cpu(f.cpu); u.fmem = mem_mib_ceil(f.mem); u.fcnt = class_counts(f.gres, P.gres); u.pad = 0;
+    u.fcpu = clamp_cpu(f.cpu); u.fmem = mem_mib_ceil(f.mem); u.fcnt = class_counts(f.gres, G); u.pad = 0;
     P.cost[q] = ncost;
     if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
     upd[i] = u;
@@ -1316,9 +1316,10 @@ __device__ __forceinline__ void helper_commit_regs(const KParams& P, const JobCt
 
 // Start-now ending (:6188-6333 with the first k nodes in cost order): exact test of every candidate in
 // parallel; if all pass, commit them at `now`.  Returns false (nothing written) if any candidate failed.
-__device__ __noinline__ bool multi_verify_commit(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, bool active,
-                                                 u32 qbeg, UpdRec* upd, int* nupd) {
+__device__ __noinline__ bool multi_verify_commit(const KParams& P, const GresDev* Gp, const JobCtx* Jp, HeapEnt* H, u32 i,
+                                                 bool active, u32 qbeg, UpdRec* upd, int* nupd) {
   const u32 lane = threadIdx.x & 63u;
+  const GresDev& G = *Gp;
   const JobCtx J = *Jp;
   NodeHdr* hd = nullptr;
   NodeHdr h;
@@ -1334,10 +1335,10 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const JobCtx*
     load_block(P, q, lane, hd, h, e);
     bool ok = false;
     if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                        class_counts(h.avail0.gres, P.gres), P.gres)) {                          // :6274
+                        class_counts(h.avail0.gres, G), G)) {                          // :6274
       const Res m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
                                         : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));    // :6278-6283
-      ok = feasible(J.min_view, m, f, P.gres);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
+      ok = feasible(J.min_view, m, f, G);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
     }
     if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
   }
@@ -1346,7 +1347,7 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const JobCtx*
   for (u32 m = 0; m < J.k; ++m) nok += H[m].ntasks != 0 ? 1u : 0u;
   if (nok != J.k) return false;  // (rare) the caller falls back to the sequential protocol
   if (active) {
-    helper_commit_regs(P, J, H, i, p, cost0, hd, h, e, f, P.now, lane, upd, q);
+    helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, f, P.now, lane, upd, q);
     drain_stores();  // the worker reads this block again in later jobs
   }
   if (threadIdx.x == 0) *nupd = (int)J.k;
@@ -1357,9 +1358,10 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const JobCtx*
 // Backfill ending (:6335-6376): allocations against res_total, earliest common start as the fixed point
 // t <- max_i next_fit_i(t) (each helper evaluates its own node, one barrier per iteration), commit at t.
 // Returns the start time or kInf (nothing written).  nf: 2 x kMultiK exchange slots in LDS.
-__device__ __noinline__ i64 multi_backfill_par(const KParams& P, const JobCtx* Jp, HeapEnt* H, u32 i, bool active,
-                                               u32 qbeg, UpdRec* upd, int* nupd, i64* nf, int* reason_out) {
+__device__ __noinline__ i64 multi_backfill_par(const KParams& P, const GresDev* Gp, const JobCtx* Jp, HeapEnt* H, u32 i,
+                                               bool active, u32 qbeg, UpdRec* upd, int* nupd, i64* nf, int* reason_out) {
   const u32 lane = threadIdx.x & 63u;
+  const GresDev& G = *Gp;
   const JobCtx J = *Jp;
   NodeHdr* hd = nullptr;
   NodeHdr h;
@@ -1373,7 +1375,7 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const JobCtx* J
     cost0 = H[i].cost;
     q = qbeg + slot_of_code(p);
     load_block(P, q, lane, hd, h, e);
-    if (!feasible(J.min_view, h.total, alloc, P.gres)) {  // :6354-6356
+    if (!feasible(J.min_view, h.total, alloc, G)) {  // :6354-6356
       if (lane == 0) set_fault(P, 3, J.orig, h.node, 2);
     }
     if (lane == 0) {
@@ -1404,7 +1406,7 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const JobCtx* J
   for (u32 m = 0; m < J.k; ++m) { notle = notle || (H[m].pad & 1u) != 0; reserved = reserved || (H[m].pad & 2u) != 0; }
   if (blockIdx.x >= P.num_real_parts) reserved = false;  // jobs of a reservation: no "Resource Reserved" (:6798,6818)
   if (found && active) {
-    helper_commit_regs(P, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q);
+    helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q);
     drain_stores();
   }
   if (found && threadIdx.x == 0) *nupd = (int)J.k;
@@ -1515,6 +1517,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ int s_ty_cpu[CNS_MAX_NODE_TYPES_DEV];  // per node type: what "completely free" looks like
   __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
   __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
+  __shared__ GresDev s_gres;  // LDS copy of the GRES layout for the out-of-line helpers (their parameter block is read with FLAT loads: from LDS the table lookups of the exact test are ~10x closer than from HBM)
   __shared__ u32 s_nme[kMaxNames], s_nmo[kMaxNames];  // GRES name masks in the split-nibble domain (even / odd nibbles as bytes)
 
   const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();  // lane t holds node type t
@@ -1535,6 +1538,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     s_ty_cpu[lane] = clamp_cpu(ttot.cpu);
     s_ty_m16[lane] = mem_gib16(mem_mib_ceil(ttot.mem));
     s_ty_gn[lane] = nibbles_of(tyl.cnt);
+    if (lane == 0) s_gres = P.gres;
     if (lane < (u32)kMaxNames) {
       const u32 nb = nibbles_of(P.gres.name_bytes[lane] & 0x0F0F0F0F0F0F0F0Full);  // nibble g = 0xF if class g is in the name
       s_nme[lane] = nb & 0x0F0F0F0Fu;
@@ -1717,7 +1721,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_ADD(25, d1, d2);  // start-now lists + merge
           wg_barrier();  // M2
           if (n == F.k) {  // k start-now candidates exist (:6294-6297 if their exact tests pass)
-            if (multi_verify_commit(PG, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd)) {
+            if (multi_verify_commit(PG, &s_gres, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd)) {
               if (lane == 0) { P.o_start[F.orig] = P.now; P.o_reason[F.orig] = 0; }  // :6326
               PROF_CNT(30);
             } else {
@@ -1734,7 +1738,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             wg_barrier();  // M6
             if (n == F.k) {
               int reason = 0;
-              const i64 st = multi_backfill_par(PG, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd, s_nf, &reason);
+              const i64 st = multi_backfill_par(PG, &s_gres, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd, s_nf, &reason);
               PROF_T(d6);
               PROF_ADD(29, d5, d6);  // common earliest start + commit
               PROF_CNT(31);
@@ -2150,7 +2154,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         wg_barrier();  // M1
         wg_barrier();  // M2: the worker merged the lists
         if (s_mode == 1) {
-          if (multi_verify_commit(PG, &s_job, s_heap, wave - 1, wave - 1 < kk, qbeg, s_upd, &s_nupd)) {
+          if (multi_verify_commit(PG, &s_gres, &s_job, s_heap, wave - 1, wave - 1 < kk, qbeg, s_upd, &s_nupd)) {
             verdict = 2;
           } else {
             sequential = true;  // rare: fall back to the sequential protocol from round 0
@@ -2161,7 +2165,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           wg_barrier();  // M6
           if (s_mode == 3) {
             int reason = 0;
-            const i64 st = multi_backfill_par(PG, &s_job, s_heap, wave - 1, wave - 1 < kk, qbeg, s_upd, &s_nupd, s_nf, &reason);
+            const i64 st = multi_backfill_par(PG, &s_gres, &s_job, s_heap, wave - 1, wave - 1 < kk, qbeg, s_upd, &s_nupd, s_nf, &reason);
             if (st != kInf) verdict = 2;
           }
         }
