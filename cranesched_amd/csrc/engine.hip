@@ -75,7 +75,7 @@ struct cns_engine {
   std::vector<Res> rv_res;
   DevBuf d_slot_total, d_slot_end, d_slot_type, d_rv_off, d_rv_start, d_rv_end, d_rv_res, d_first_resv, d_resv_se;
   // device buffers
-  DevBuf d_part_off, d_slot_node, d_total, d_ntype, d_type_total, d_blocks, d_cost, d_fcpu,
+  DevBuf d_part_off, d_slot_node, d_type_total, d_blocks, d_cost, d_fcpu,
       d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
   DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results, d_params, d_prof;
   // job table
@@ -302,7 +302,7 @@ int cns_create(const cns_config* cfg, cns_handle** out) {
 void cns_destroy(cns_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_total, &h->d_ntype, &h->d_type_total,
+  for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_type_total,
                     &h->d_blocks, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
                     &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_gupd, &h->d_fault, &h->d_pj_off, &h->d_jobs,
                     &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof, &h->d_slot_total,

@@ -132,7 +132,6 @@ __device__ __forceinline__ u64 wave_max_u64(u64 v) {
 }
 // order-preserving map i64 -> u64
 __device__ __forceinline__ i64 wave_min_i64(i64 v) { return (i64)(wave_min_u64((u64)v ^ 0x8000000000000000ull) ^ 0x8000000000000000ull); }
-__device__ __forceinline__ i64 wave_max_i64(i64 v) { return (i64)(wave_max_u64((u64)v ^ 0x8000000000000000ull) ^ 0x8000000000000000ull); }
 __device__ __forceinline__ u64 wave_and_u64(u64 v) {
   return ((u64)wave_and32((u32)(v >> 32)) << 32) | wave_and32((u32)v);
 }
@@ -172,9 +171,6 @@ __device__ __forceinline__ u64 class_counts(u64 gres, const GresDev& L) {
   u64 c = 0;
   for (int g = 0; g < (int)L.num_classes; ++g) c |= (u64)popc64(gres & L.class_mask[g]) << (8 * g);
   return c;
-}
-__device__ __forceinline__ u32 sum_bytes(u64 v) {
-  return __builtin_amdgcn_sad_u8((u32)v, 0u, __builtin_amdgcn_sad_u8((u32)(v >> 32), 0u, 0u));
 }
 __device__ __forceinline__ void set_fault(const KParams& P, u32 code, u32 a, u32 b, u32 c) {
   if (atomicCAS(P.fault, 0u, code) == 0u) { P.fault[1] = a; P.fault[2] = b; P.fault[3] = c; }
@@ -392,40 +388,9 @@ __device__ __forceinline__ bool in_list(const u32* lst, u64 b, u64 e, u32 n) {
   return false;
 }
 
-// requests no node can ever satisfy under the engine's 32-bit front summaries (cpu totals are
-// validated < 2^31-2 by cns_set_nodes; a class holds <= 64 slots)
-__device__ __forceinline__ bool job_impossible(const JobCtx& J) {
-  return J.min_view.cpu > 0x7FFFFFFEll || (J.node_view.gspec & 0x8080808080808080ull) != 0;
-}
 
-// ntasks_on_node_total per node type (JobScheduler.cpp:6222): lane t evaluates type t.
-// Only jobs with ntasks > node_num need the capacity itself (rare: kept out of line).
-__device__ __noinline__ int type_capacity_general(const KParams* Pp, i64 mcpu, u64 mmem, u32 gtot, u64 gspec,
-                                                  i64 tcpu, u64 tmem, u32 tmin, u32 tmax, const Res* ttot_p) {
-  Req mv; mv.cpu = mcpu; mv.mem = mmem; mv.gtot = gtot; mv.gspec = gspec;
-  return max_tasks(mv, tcpu, tmem, tmin, tmax, *ttot_p, Pp->gres);
-}
 // Per-type static data held by lane t: exact cpu / mem, number of core ids, per-class slot counts.
 struct TypeLane { i64 cpu; u64 mem; u32 ncores; u64 cnt; };
-__device__ __forceinline__ int type_capacity(const KParams& P, const KParams* Pg, const JobCtx& J, const Res& ttot,
-                                              const TypeLane& tl, u32 lane) {
-  int tt = 0;
-  if (lane < P.num_types) {
-    if (J.general)
-      tt = type_capacity_general(Pg, J.min_view.cpu, J.min_view.mem, J.min_view.gtot, J.min_view.gspec, J.tcpu, J.tmem,
-                                 J.tmin, J.tmax, &ttot);
-    else
-      tt = feasible_counts(J.min_view, tl.cpu, tl.mem, tl.ncores, tl.cnt, P.gres) ? (int)J.tmin : 0;
-  }
-  return tt;
-}
-// get_max_tasks(res_total) > 0  <=>  the minimum view fits res_total (JobScheduler.cpp:6171-6175, :6222-6223)
-__device__ __forceinline__ u64 type_ok_mask(const KParams& P, const Req& mv, const TypeLane& tl, u32 lane) {
-  return __ballot((lane < P.num_types) & feasible_counts(mv, tl.cpu, tl.mem, tl.ncores, tl.cnt, P.gres));
-}
-__device__ __forceinline__ u64 type_ok_mask(const KParams& P, const JobCtx& J, const TypeLane& tl, u32 lane) {
-  return type_ok_mask(P, J.min_view, tl, lane);
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_prep_jobs: job-parallel pre-pass (one thread per pending job of the cycle).  Everything about a job
@@ -643,27 +608,6 @@ __device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, 
   return nlen;
 }
 
-// Earliest s >= t such that `alloc` fits the node throughout [s, s + L); kInf if never.
-// (per-node half of EarliestStartSubsetSelector, JobScheduler.h:737-790,812-855) — one lane per node.
-__device__ __noinline__ i64 next_fit(const TlEntry* T, u32 len, const Res& alloc, i64 L, i64 t, u32& j) {
-  while (j + 1 < len && T[j + 1].t <= t) ++j;
-  i64 s = t;
-  u32 i = j;
-  while (true) {
-    const Res r = T[i].r;
-    if (!res_le(alloc, r)) {
-      if (i + 1 >= len) return kInf;
-      ++i;
-      s = T[i].t;
-      j = i;
-      continue;
-    }
-    if (i + 1 >= len) return s;  // satisfied through the last entry: iterator "ReachEnd"
-    i64 nt = T[i + 1].t;
-    if (nt - s >= L) return s;   // kth_time + time_limit <= next flip
-    ++i;
-  }
-}
 
 // Wave-parallel form for time maps of any length: 64 entries per step, "alloc fits" ballot per chunk, run
 // state (inside a satisfied run? its start) carried across chunks.  All lanes return the same value.
