@@ -19,10 +19,12 @@
 
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/priority.h"
+#include "../../include/crane_gpu/run_limits.h"
 #include <limits>
 #include "engine_params.h"
 #include "select_kernels.hip"  // single translation unit: kernels + their launches (no -fgpu-rdc needed)
 #include "priority_kernels.hip"
+#include "limits_kernels.hip"
 
 using namespace cns;
 
@@ -88,6 +90,14 @@ struct cns_engine {
   DevBuf d_prio[27];
   double prio_ms = 0.0;
   u64 prio_bytes = 0;
+  // run-limit admission (limits_host.inc)
+  DevBuf d_lim[29];
+  bool lim_have_tables = false, lim_have_jobs = false, lim_have_run = false;
+  bool lim_has_upl = false, lim_has_apl = false, lim_has_sel = false, lim_has_skip = false;
+  u32 lim_U = 0, lim_UA = 0, lim_A = 0, lim_Q = 0, lim_Pn = 0, lim_base[5] = {0, 0, 0, 0, 0};
+  u64 lim_NR = 0, lim_J = 0, lim_sel_J = 0;
+  std::vector<u32> lim_level;
+  cns_limit_timing lim_timing{};
 };
 
 namespace {
@@ -310,6 +320,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
   for (DevBuf& b : h->d_prio) b.release();
+  for (DevBuf& b : h->d_lim) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -784,5 +795,6 @@ int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint
 }
 
 #include "priority_host.inc"
+#include "limits_host.inc"
 
 }  // extern "C"

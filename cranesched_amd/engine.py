@@ -30,6 +30,9 @@ ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy",
                "cns_debug_get_prof")
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
+# ... and include/crane_gpu/run_limits.h
+LIMITS_ABI_SYMBOLS = ("cns_set_run_limits", "cns_apply_run_limits", "cns_upload_limit_jobs", "cns_run_limits_resident",
+                      "cns_download_limits", "cns_get_limit_timing", "cns_get_usage")
 
 
 class EngineError(RuntimeError):
@@ -99,6 +102,47 @@ class GpuNodeSelector:
         ms, nb = C.c_double(0), C.c_uint64(0)
         self._check(self._L.cns_priority_timing(self._h, C.byref(ms), C.byref(nb)))
         return {"kernels_ms": ms.value, "algorithmic_bytes": int(nb.value)}
+
+    # -- run-limit admission (include/crane_gpu/run_limits.h) --------------------------------------
+    def set_run_limits(self, tables):
+        """Limits + usage at the start of the commit loop (AccountMetaContainer state); after set_nodes."""
+        t = tables.to_c()
+        self._check(self._L.cns_set_run_limits(self._h, C.byref(t)))
+        self._lim_tables = tables
+
+    def apply_run_limits(self, jobs):
+        """CheckAndMallocMetaResource over the last node_select's results, in the order of `jobs`
+        (JobScheduler.cpp:1492-1573).  Returns (limit_reason[J] u8, num_admitted)."""
+        self.upload_limit_jobs(jobs)
+        self.run_limits_resident()
+        return self.download_limits()
+
+    def upload_limit_jobs(self, jobs):
+        cj = jobs.to_c()
+        self._check(self._L.cns_upload_limit_jobs(self._h, C.byref(cj)))
+        self._lim_jobs = jobs
+
+    def run_limits_resident(self):
+        self._check(self._L.cns_run_limits_resident(self._h))
+
+    def download_limits(self):
+        J = self._lim_jobs.num_jobs
+        out = np.zeros(max(J, 1), np.uint8)
+        adm = C.c_uint64(0)
+        self._check(self._L.cns_download_limits(self._h, out.ctypes.data_as(C.c_void_p), C.byref(adm)))
+        return out[:J], int(adm.value)
+
+    def limit_timing(self) -> dict:
+        from . import limits as lm
+        t = lm.CnsLimitTiming()
+        self._check(self._L.cns_get_limit_timing(self._h, C.byref(t)))
+        return {f: getattr(t, f) for f, _ in lm.CnsLimitTiming._fields_}
+
+    def usage(self):
+        """Usage tables after the last admission (what DoMallocResource_ left)."""
+        u = self._lim_tables.empty_usage()
+        self._check(self._L.cns_get_usage(self._h, *u.pointers()))
+        return u
 
     def close(self):
         if self._h:

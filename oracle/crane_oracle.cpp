@@ -8,6 +8,7 @@
 
 #include "sched_oracle.hpp"
 #include "prio_oracle.hpp"
+#include "limits_oracle.hpp"
 
 using namespace ora;
 
@@ -290,6 +291,45 @@ int ora_priority_order(int64_t now, uint64_t max_age, uint32_t w_age, uint32_t w
   std::vector<double> prio;
   const std::vector<uint32_t> order = ora::priority_order(now, cfg, num_accounts, pd, rn, prio);
   for (uint32_t i = 0; i < J; ++i) { order_out[i] = order[i]; prio_out[i] = prio[i]; }
+  return 0;
+}
+
+// Run-limit admission restatement (limits_oracle.hpp).  Structs as in include/crane_gpu/run_limits.h; the
+// placements are the ones a NodeSelect run produced (cns_placement_soa of the oracle or of the engine).
+// Usage tables after the pass are written to the (optional) out pointers, shapes as in cns_limit_tables.
+int ora_run_limits(const cns_gres_layout* gl, const cns_limit_tables* t, const cns_limit_job_soa* jobs,
+                   const cns_placement_soa* pl, uint8_t* reason_out, uint64_t* num_admitted, cns_usage* uq, uint8_t* uqe,
+                   cns_usage* up, uint8_t* upe, cns_usage* aq, uint8_t* aqe, cns_usage* ap, uint8_t* ape, cns_usage* qu) {
+  lim_oracle::Limits L(*t, *gl);
+  uint64_t adm = 0;
+  for (uint64_t i = 0; i < jobs->num_jobs; ++i) {  // commit loop, pending-vector order (JobScheduler.cpp:1492)
+    const uint64_t s = jobs->select_index ? jobs->select_index[i] : i;
+    if (pl->reason[s] != CNS_REASON_NONE || (jobs->skip && jobs->skip[i])) {  // :1507-1510 and the `continue`s before :1565
+      reason_out[i] = CNS_LIM_NOT_CANDIDATE;
+      continue;
+    }
+    if (jobs->user[i] >= t->num_users || jobs->user_acct[i] >= t->num_user_accts || jobs->account[i] >= t->num_accounts ||
+        jobs->qos[i] >= t->num_qos || jobs->partition[i] >= t->num_partitions)
+      return -1;
+    // job.allocated_res.View() (PublicHeader.cpp:946-952)
+    int64_t cpu = 0;
+    uint64_t mem = 0, cc[CNS_MAX_GRES_CLASSES] = {0};
+    for (uint64_t r = pl->place_offsets[s]; r < pl->place_offsets[s + 1]; ++r) {
+      if (pl->node_idx[r] == CNS_NODE_NONE) continue;
+      cpu += pl->cpu_raw[r];
+      mem += pl->mem[r];
+      for (uint32_t g = 0; g < gl->num_classes; ++g) {
+        const uint64_t w = gl->class_width[g] >= 64 ? ~0ull : ((1ull << gl->class_width[g]) - 1ull);
+        cc[g] += (uint64_t)__builtin_popcountll(pl->gres[r] & (w << gl->class_shift[g]));
+      }
+    }
+    const int r = L.check_and_malloc(jobs->user[i], jobs->user_acct[i], jobs->account[i], jobs->qos[i], jobs->partition[i],
+                                     jobs->time_limit_sec[i], L.view_of_counts(cpu, mem, cc));
+    reason_out[i] = (uint8_t)r;
+    adm += r == 0;
+  }
+  if (num_admitted) *num_admitted = adm;
+  L.export_usage(t->num_users, t->num_user_accts, uq, uqe, up, upe, aq, aqe, ap, ape, qu);
   return 0;
 }
 

@@ -35,8 +35,9 @@ class OraReq(C.Structure):
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp", "prio_oracle.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp", "prio_oracle.hpp", "limits_oracle.hpp")]
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "node_select.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "run_limits.h"))
     stale = force or not os.path.exists(path) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
     if stale:
@@ -165,3 +166,21 @@ def priority_order(now: int, cfg, num_accounts: int, pending, running=None):
     if rc != 0:
         raise ValueError("ora_priority_order: account id out of range")
     return order[:J], prio[:J]
+
+
+def run_limits(layout: abi.GresLayout, tables, jobs, placements: abi.Placements):
+    """CPU restatement of the commit loop's run-limit admission (oracle/limits_oracle.hpp).
+
+    `placements` are a NodeSelect result (of the oracle or of the engine).  Returns (reason[J] u8, admitted, Usage).
+    """
+    from cranesched_amd import limits as lm
+    L = lib()
+    reason = np.full(max(jobs.num_jobs, 1), 0, np.uint8)
+    adm = C.c_uint64(0)
+    usage = tables.empty_usage()
+    gl, ct, cj, cp = layout.to_c(), tables.to_c(), jobs.to_c(), placements.to_c()
+    rc = L.ora_run_limits(C.byref(gl), C.byref(ct), C.byref(cj), C.byref(cp), reason.ctypes.data_as(C.c_void_p),
+                          C.byref(adm), *usage.pointers())
+    if rc != 0:
+        raise ValueError("ora_run_limits: key index out of range")
+    return reason[:jobs.num_jobs], adm.value, usage
