@@ -74,6 +74,15 @@ def main():
     eng.upload_jobs(my_jobs)           # inputs resident in HBM before the timed region
     h2d_ms = eng.timing()["h2d_ms"]
 
+    # C4's "+ per-account/QoS limits": the run-limit admission of the commit loop over the resident
+    # NodeSelect results.  It runs AFTER the reference's NodeSelect bracket (JobScheduler.cpp:1439-1447 vs :1492-1573),
+    # so it is timed separately and reported in "run_limits" next to the headline; single-GPU only (its order is the
+    # global pending order, which spans the partition shards).
+    limits = None
+    if world == 1 and args.config == "C4":
+        limits = synth.make_limits(args.config, cluster, jobs)
+        eng.set_run_limits(limits[0])
+
     gather_in = gather_out = None
     if use_dist:
         ptr, nbytes = eng.device_results()
@@ -115,6 +124,23 @@ def main():
     elapsed = float(el.item())
     total_jobs = int(ordered.item())
 
+    lim_line = None
+    if limits is not None:
+        eng.upload_limit_jobs(limits[1])       # keys resident before the timed passes
+        lt, wall = [], []
+        for _ in range(max(args.steps, 1)):
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            eng.run_limits_resident()
+            wall.append(1e3 * (time.perf_counter() - w0))
+            lt.append(eng.limit_timing())
+        lim_reason, lim_adm = eng.download_limits()
+        lim_line = {"admit_ms": float(np.mean([x["admit_ms"] for x in lt])), "prep_ms": float(np.mean([x["prep_ms"] for x in lt])),
+                    "wall_ms": float(np.mean(wall)), "candidates": int(lt[-1]["candidates"]), "admitted": int(lim_adm),
+                    "bracketing_rounds": int(lt[-1]["rounds"]), "ordered_fallback": bool(lt[-1]["ordered_fallback"]),
+                    "rejected_by": {lm_name: int(n) for lm_name, n in zip(*np.unique(lim_reason[(lim_reason != 0) & (lim_reason != 255)], return_counts=True))},
+                    "tables": "1024 users, 64 accounts (8 roots x 7 children), 4 QoS, account x partition caps (synth.make_limits)"}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = total_jobs * args.steps / elapsed
@@ -149,6 +175,19 @@ def main():
                          "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); "
                                  "the node tile is register-resident, so HBM traffic is far below this"},
         }
+        if lim_line is not None:
+            from cranesched_amd import limits as lm
+            lim_line["rejected_by"] = {lm.LIMIT_REASON_STR[int(k)]: v for k, v in lim_line["rejected_by"].items()}
+            lim_line["decisions_per_s_with_run_limits"] = total_jobs / ((ms_per_step + lim_line["wall_ms"]) * 1e-3)
+            lim_line["note"] = ("run-limit admission of the commit loop over the resident NodeSelect results; outside the "
+                                "reference's NodeSelect bracket, hence reported beside `value`, not inside it")
+            if not args.no_cpu_baseline:
+                from oracle import pyoracle  # the checker, timed as the reported CPU figure of this pass
+                c0 = time.perf_counter()
+                r_ref, a_ref, _ = pyoracle.run_limits(cluster.gres, limits[0], limits[1], got)
+                lim_line["cpu_port_ms"] = 1e3 * (time.perf_counter() - c0)
+                lim_line["identical_to_cpu_port"] = bool(np.array_equal(r_ref, lim_reason) and a_ref == lim_adm)
+            line["run_limits"] = lim_line
         if world == 1 and not args.no_cpu_baseline:
             from oracle import pyoracle  # CPU oracle = the checker, timed here only as the reported baseline
             ns = min(args.cpu_sample_jobs, jobs.num_jobs)

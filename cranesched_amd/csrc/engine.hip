@@ -91,7 +91,7 @@ struct cns_engine {
   double prio_ms = 0.0;
   u64 prio_bytes = 0;
   // run-limit admission (limits_host.inc)
-  DevBuf d_lim[29];
+  DevBuf d_lim[29], d_limpar[17];
   bool lim_have_tables = false, lim_have_jobs = false, lim_have_run = false;
   bool lim_has_upl = false, lim_has_apl = false, lim_has_sel = false, lim_has_skip = false;
   u32 lim_U = 0, lim_UA = 0, lim_A = 0, lim_Q = 0, lim_Pn = 0, lim_base[5] = {0, 0, 0, 0, 0};
@@ -321,6 +321,7 @@ void cns_destroy(cns_handle* h) {
     b->release();
   for (DevBuf& b : h->d_prio) b.release();
   for (DevBuf& b : h->d_lim) b.release();
+  for (DevBuf& b : h->d_limpar) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

@@ -74,6 +74,8 @@ struct LimParams {
   i64* rec_add;          // [M * 16]
   u32* rec_c; u32* rec_l; u32* rec_en;   // [M * 16]
   u32* rec_job; u32* rec_meta;           // [M]   job index; passes | level << 8
+  u64* item_key;         // [M * 16] usage record of (candidate, slot), NR for an unused slot (sort key of the parallel pass)
+  u32 NR, pad1;
   uint8_t* out;          // [J] cns_limit_reason
   u64* admitted;
   LimLayout lay;
@@ -187,6 +189,10 @@ __global__ __launch_bounds__(256) void k_lim_build(const LimParams P) {
   }
   P.rec_job[k] = (u32)i;
   P.rec_meta[k] = ((4 + 2 * L) / 4 + 1) | L << 8;
+  if (P.item_key) {
+#pragma unroll
+    for (u32 x = 0; x < 16; ++x) P.item_key[k * 16 + x] = sc[x] == kNone ? (u64)P.NR : (u64)sc[x];
+  }
 }
 
 // ---- the ordered admission ---------------------------------------------------------------------------------
@@ -327,6 +333,289 @@ __global__ __launch_bounds__(64) void k_lim_admit(const LimParams P) {
     }
   }
   if (lane == 0) *P.admitted = adm;
+}
+
+// ==== the parallel admission ===================================================================================
+// Greedy admission in order is a chain, but its DECISIONS can be bracketed: with A = jobs known to be admitted and
+// X = jobs known to be rejected, every usage record a job sees lies between usage0 + (sum over earlier jobs in A)
+// and usage0 + (sum over earlier jobs not in X).  A job all of whose checks pass over that whole interval is
+// admitted whatever the undecided jobs turn out to be; one with a check that fails over the whole interval is
+// rejected.  The first undecided job always has a zero-width interval, so every round decides at least one job;
+// on the C4 tables ~10 rounds decide all 759 k candidates.  If kLimMaxRounds do not suffice the host falls back to
+// the ordered single-wave kernel above (same results by construction, both are checked against the oracle).
+//
+// "Sum over earlier jobs with the same usage record" = segmented exclusive prefix sums over the (candidate, slot)
+// items sorted by usage record (stable LSD radix sort, once per cycle; order inside a record = candidate order).
+// The sorted items are gathered once into streams (candidate, limit, checks, 16 components) so that a round reads
+// HBM linearly: per round k_par_tails (partial sums per chunk), k_par_carry (scan over the chunk tails),
+// k_par_eval (re-walk with the carry, evaluate the undecided jobs' slots) and k_par_update.
+// The CheckGres_ walk is not monotone in the usage (an entry the limit lacks stops the walk, :1034,1043): its
+// outcome over an interval is evaluated in three-valued logic (certain stop / maybe stop / certain fail / maybe fail).
+constexpr u32 kParChunks = 8192;     // chunks of the sorted item stream (16 lanes walk one chunk)
+constexpr u32 kParMinChunk = 64;
+constexpr u32 kParBatch = 8;         // items loaded together by a chunk walker
+constexpr u32 kLimMaxRounds = 64;
+
+struct ParParams {
+  const u64* n_items;     // items with a usage record (the sorted stream's prefix)
+  const u64* total;       // candidates
+  const u32* s_key;       // [n] usage record of the item
+  const u32* s_k;         // [n] candidate
+  const u32* s_l;         // [n] limit record or kNone
+  const u32* s_en;        // [n] checks of the slot (kind << 24 | need-exists | component mask)
+  const u32* s_slot;      // [n] slot number (for the reason order)
+  const i64* s_add;       // [n * 16]
+  uint8_t* state;         // [M] 0 undecided, 1 admitted, 2 rejected
+  u32* flags;             // [M] per round: bit 0 a slot certainly fails, bit 1 a slot does not certainly pass
+  u32* jobkey;            // [M] final pass: min (order key << 8 | reason) over the failing checks
+  i64* tails;             // [chunks][2][16]
+  uint8_t* heads;         // [chunks]
+  i64* carry;             // [chunks][2][16]
+  u64* undecided;
+  const LimRec* lim;
+  const i64* usage0; const uint8_t* exists0;
+  i64* usage; uint8_t* exists;
+  const u32* rec_meta; const u32* rec_job;
+  uint8_t* out; u64* admitted;
+};
+
+__device__ __forceinline__ u64 par_chunk_len(u64 n) {
+  const u64 c = (n + kParChunks - 1) / kParChunks;
+  return c < kParMinChunk ? kParMinChunk : c;
+}
+
+// sorted (key, item) pairs -> streams; also finds how many items carry a usage record
+__global__ __launch_bounds__(256) void k_par_gather(const u64* __restrict__ keys, const u32* __restrict__ vals, u64 n, u32 NR,
+                                                    const LimParams L, u32* s_key, u32* s_k, u32* s_l, u32* s_en, u32* s_slot,
+                                                    i64* s_add, u64* n_items) {
+  const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+  const u64 i = t >> 4;
+  const u32 comp = (u32)t & 15;
+  if (i >= n) return;
+  const u64 key = keys[i];
+  if (key >= NR) return;
+  const u32 it = vals[i], k = it >> 4;
+  if (comp == 0) {
+    s_key[i] = (u32)key; s_k[i] = k; s_l[i] = L.rec_l[it]; s_en[i] = L.rec_en[it]; s_slot[i] = it & 15;
+    if (i + 1 == n || keys[i + 1] >= NR) *n_items = i + 1;
+  }
+  s_add[i * 16 + comp] = L.rec_add[(u64)k * 16 + comp];
+}
+
+// one 16-lane group per chunk: sums of the last segment of the chunk, over A (admitted) and over not-X
+__global__ __launch_bounds__(256) void k_par_tails(const ParParams P) {
+  const u32 g = (blockIdx.x * 256 + threadIdx.x) >> 4, comp = threadIdx.x & 15;
+  const u64 n = *P.n_items, C = par_chunk_len(n);
+  const u64 beg = (u64)g * C, end = beg + C < n ? beg + C : n;
+  i64 aL = 0, aU = 0;
+  bool head = false;
+  if (beg < end) {
+    u32 prev = beg ? P.s_key[beg - 1] : kNone;
+    for (u64 i = beg; i < end; i += kParBatch) {
+      u32 key[kParBatch], k[kParBatch], st[kParBatch];
+      i64 add[kParBatch];
+#pragma unroll
+      for (u32 b = 0; b < kParBatch; ++b) {
+        const u64 x = i + b < end ? i + b : end - 1;
+        key[b] = P.s_key[x]; k[b] = P.s_k[x]; add[b] = P.s_add[x * 16 + comp];
+      }
+#pragma unroll
+      for (u32 b = 0; b < kParBatch; ++b) st[b] = P.state[k[b]];
+#pragma unroll
+      for (u32 b = 0; b < kParBatch; ++b)
+        if (i + b < end) {
+          if (key[b] != prev) { aL = 0; aU = 0; head = true; prev = key[b]; }
+          aL += st[b] == 1 ? add[b] : 0;
+          aU += st[b] != 2 ? add[b] : 0;
+        }
+    }
+  }
+  P.tails[((u64)g * 2 + 0) * 16 + comp] = aL;
+  P.tails[((u64)g * 2 + 1) * 16 + comp] = aU;
+  if (comp == 0) P.heads[g] = head;
+}
+
+// carry[c] = sum of the items since the last segment head before chunk c:  x[c] = heads[c-1] ? tails[c-1] : x[c-1] + tails[c-1]
+// one workgroup: 64 row groups of 16 lanes, each over kParChunks / 64 consecutive chunks, two sweeps
+__global__ __launch_bounds__(1024) void k_par_carry(const ParParams P) {
+  __shared__ i64 s_end[64][2][16];
+  __shared__ i64 s_in[64][2][16];
+  __shared__ uint8_t s_seen[64];
+  const u32 rg = threadIdx.x >> 4, comp = threadIdx.x & 15;
+  constexpr u32 R = kParChunks / 64;
+  const u32 c0 = rg * R;
+  for (u32 sweep = 0; sweep < 2; ++sweep) {
+    i64 xL = sweep ? s_in[rg][0][comp] : 0, xU = sweep ? s_in[rg][1][comp] : 0;
+    bool seen = false;
+    for (u32 c = c0; c < c0 + R; ++c) {
+      if (sweep) { P.carry[((u64)c * 2 + 0) * 16 + comp] = xL; P.carry[((u64)c * 2 + 1) * 16 + comp] = xU; }
+      const i64 tL = P.tails[((u64)c * 2 + 0) * 16 + comp], tU = P.tails[((u64)c * 2 + 1) * 16 + comp];
+      if (P.heads[c]) { xL = tL; xU = tU; seen = true; } else { xL += tL; xU += tU; }
+    }
+    if (sweep == 0) {
+      s_end[rg][0][comp] = xL; s_end[rg][1][comp] = xU;
+      if (comp == 0) s_seen[rg] = seen;
+      __syncthreads();
+      if (rg == 0) {   // 64 sequential steps over the row groups
+        i64 yL = 0, yU = 0;
+        for (u32 r = 0; r < 64; ++r) {
+          s_in[r][0][comp] = yL; s_in[r][1][comp] = yU;
+          if (s_seen[r]) { yL = s_end[r][0][comp]; yU = s_end[r][1][comp]; } else { yL += s_end[r][0][comp]; yU += s_end[r][1][comp]; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// first failing check of one slot in the reference's order -> (order key << 8 | reason), 0xFFFF if the slot passes
+// (exact usage; used by the final pass).  `grp16` = this group's 16 bits of a wave ballot.
+__device__ __forceinline__ u32 par_slot_reason(i64 use, i64 lim, i64 cpu_x, u32 has, u32 en, bool exists, u32 comp, u32 slot, u32 L,
+                                               u32 lane) {
+  const u32 kind = en >> 24;
+  const bool partk = kind == kLkUserPart || kind == kLkAcctPart;
+  const bool on = (en >> comp & 1) != 0;
+  const u32 rank = slot == 0 ? 0 : slot == 1 ? 1 : slot == 2 ? 4 + 2 * L : 2 + 2 * (L - ((slot - 3) >> 1)) + ((slot - 3) & 1);
+  u32 within = 7;
+  bool stop = false, gf = false;
+  if (comp == 0) {
+    if (on && use > cpu_x) within = 1;
+    else if (on && use > lim) within = 4;
+  } else if (comp == 1) {
+    if ((en & kLimNeedExists) && !exists) within = 0;
+    else if (on && use > lim) within = 2;
+  } else if (comp < 4) {
+    if (on && use > lim) within = comp == 2 ? 3 : 5;
+  } else {
+    const bool present = use > 0, h = (has >> comp & 1) != 0;
+    stop = on && present && !h;
+    gf = on && present && h && use > lim;
+  }
+  const u32 sf = (u32)(__ballot(stop || gf) >> (lane & 48u)) & 0xFFFFu;
+  if (gf && (sf & ((1u << comp) - 1u)) == 0) within = 6;
+  if (within == 7) return 0xFFFFu;
+  const u32 code = !partk ? 1 + within
+                          : within == 0 ? 8 : within == 2 ? (kind == kLkUserPart ? 9 : 11)
+                          : within == 3 ? (kind == kLkUserPart ? 10 : 12) : 9 + within;
+  return (rank * 8 + within) << 8 | code;
+}
+
+// FINAL = false: bracket the undecided jobs' slots.  FINAL = true: every job is decided, the sums are exact:
+// reasons of the rejected jobs, usage tables after the pass.
+template <bool FINAL>
+__global__ __launch_bounds__(256) void k_par_eval(const ParParams P) {
+  const u32 g = (blockIdx.x * 256 + threadIdx.x) >> 4, comp = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const u64 n = *P.n_items, C = par_chunk_len(n);
+  const u64 beg = (u64)g * C, end = beg + C < n ? beg + C : n;
+  const bool live = beg < end;
+  i64 aL = live ? P.carry[((u64)g * 2 + 0) * 16 + comp] : 0, aU = live ? P.carry[((u64)g * 2 + 1) * 16 + comp] : 0;
+  u32 prev = live && beg ? P.s_key[beg - 1] : kNone;
+  const u64 steps = (C + kParBatch - 1) / kParBatch;   // uniform trip count: the ballots below need every lane
+  for (u64 t = 0; t < steps; ++t) {
+    const u64 i = beg + t * kParBatch;
+    u32 key[kParBatch], k[kParBatch], st[kParBatch];
+    i64 add[kParBatch];
+#pragma unroll
+    for (u32 b = 0; b < kParBatch; ++b) {
+      const u64 x = live ? (i + b < end ? i + b : end - 1) : 0;
+      key[b] = live ? P.s_key[x] : kNone; k[b] = live ? P.s_k[x] : 0; add[b] = live ? P.s_add[x * 16 + comp] : 0;
+    }
+#pragma unroll
+    for (u32 b = 0; b < kParBatch; ++b) st[b] = live ? P.state[k[b]] : 2;
+#pragma unroll
+    for (u32 b = 0; b < kParBatch; ++b) {
+      const bool act = live && i + b < end;
+      if (act && key[b] != prev) {
+        if (FINAL && prev != kNone) {  // the previous usage record is complete: DoMallocResource_'s result
+          P.usage[(u64)prev * 16 + comp] = P.usage0[(u64)prev * 16 + comp] + aL;
+          if (comp == 1 && aL > 0) P.exists[prev] = 1;
+        }
+        aL = 0; aU = 0; prev = key[b];
+      }
+      const bool need = act && (FINAL ? st[b] == 2 : st[b] == 0);
+      if (__ballot(need)) {
+        const u64 x = act ? i + b : 0;
+        const u32 lidx = need ? P.s_l[x] : kNone, en = need ? P.s_en[x] : 0;
+        i64 lim = kInf, cpu_x = kInf;
+        u32 has = 0;
+        if (lidx != kNone) { const LimRec* r = P.lim + lidx; lim = r->lim[comp]; has = r->has; if (comp == 0) cpu_x = r->cpu_x; }
+        const i64 c0 = need ? P.usage0[(u64)key[b] * 16 + comp] : 0;
+        const bool ex0 = need && comp == 1 ? P.exists0[key[b]] != 0 : true;
+        const i64 useL = c0 + aL + add[b], useU = c0 + aU + add[b];
+        if (FINAL) {
+          const u32 L = need ? P.rec_meta[k[b]] >> 8 : 0;
+          const u32 v = par_slot_reason(useL, lim, cpu_x, has, en, ex0 || aL > 0, comp, need ? P.s_slot[x] : 0, L, lane);
+          if (need && v != 0xFFFFu) atomicMin(&P.jobkey[k[b]], v);
+        } else {
+          const bool on = need && (en >> comp & 1) != 0;
+          bool fC = false, fM = false, sC = false, sM = false, gC = false, gM = false;
+          if (comp == 0) {
+            fC = on && (useL > cpu_x || useL > lim);
+            fM = on && (useU > cpu_x || useU > lim);
+          } else if (comp < 4) {
+            fC = on && useL > lim;
+            fM = on && useU > lim;
+            if (comp == 1 && need && (en & kLimNeedExists)) {   // the entry exists once any earlier job was admitted
+              const bool exL = ex0 || aL > 0, exU = ex0 || aU > 0;
+              fC = fC || !exU;
+              fM = fM || !exL;
+            }
+          } else {
+            const bool h = (has >> comp & 1) != 0, pC = useL > 0, pM = useU > 0;
+            sC = on && !h && pC;
+            sM = on && !h && pM;
+            gC = on && h && useL > lim;
+            gM = on && h && useU > lim;
+          }
+          const u32 sh = lane & 48u;
+          const u32 bfC = (u32)(__ballot(fC) >> sh) & 0xFFFFu, bfM = (u32)(__ballot(fM) >> sh) & 0xFFFFu;
+          const u32 bsC = (u32)(__ballot(sC) >> sh) & 0xFFFFu, bsM = (u32)(__ballot(sM) >> sh) & 0xFFFFu;
+          const u32 bgC = (u32)(__ballot(gC) >> sh) & 0xFFFFu, bgM = (u32)(__ballot(gM) >> sh) & 0xFFFFu;
+          // CheckGres_ over the interval: certainly passes iff the first of {certain stop, any fail} is a certain stop
+          // (or none exists); certainly fails iff the first of {any stop, any fail} is a certain fail
+          const u32 m1 = bsC | bgC | bgM, m2 = m1 | bsM;
+          const bool g_pass = m1 == 0 || (bsC & (m1 & (0u - m1))) != 0;
+          const bool g_fail = m2 != 0 && (bgC & (m2 & (0u - m2))) != 0;
+          const bool cfail = bfC != 0 || g_fail;
+          const bool cpass = bfM == 0 && g_pass;   // bfM includes bfC
+          if (need && comp == 0 && (cfail || !cpass)) atomicOr(&P.flags[k[b]], (cfail ? 1u : 0u) | (cpass ? 0u : 2u));
+        }
+      }
+      if (act) {
+        aL += st[b] == 1 ? add[b] : 0;
+        aU += st[b] != 2 ? add[b] : 0;
+      }
+    }
+  }
+  if (FINAL && live && end == n && prev != kNone) {   // the very last usage record
+    P.usage[(u64)prev * 16 + comp] = P.usage0[(u64)prev * 16 + comp] + aL;
+    if (comp == 1 && aL > 0) P.exists[prev] = 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_par_update(const ParParams P) {
+  const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+  bool und = false;
+  if (k < *P.total && P.state[k] == 0) {
+    const u32 f = P.flags[k];
+    P.flags[k] = 0;
+    if (f & 1) P.state[k] = 2;
+    else if (!(f & 2)) P.state[k] = 1;
+    else und = true;
+  }
+  const u64 b = __ballot(und);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long*)P.undecided, (unsigned long long)__popcll(b));
+}
+
+__global__ __launch_bounds__(256) void k_par_finish(const ParParams P) {
+  const u64 k = (u64)blockIdx.x * 256 + threadIdx.x;
+  bool adm = false;
+  if (k < *P.total) {
+    adm = P.state[k] == 1;
+    P.out[P.rec_job[k]] = adm ? 0 : (uint8_t)(P.jobkey[k] & 0xFF);
+  }
+  const u64 b = __ballot(adm);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd((unsigned long long*)P.admitted, (unsigned long long)__popcll(b));
 }
 
 }  // namespace cns

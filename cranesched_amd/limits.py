@@ -62,7 +62,8 @@ class CnsLimitJobSoa(C.Structure):
 
 class CnsLimitTiming(C.Structure):
     _fields_ = [("h2d_ms", C.c_double), ("prep_ms", C.c_double), ("admit_ms", C.c_double), ("d2h_ms", C.c_double),
-                ("candidates", C.c_uint64), ("admitted", C.c_uint64)]
+                ("candidates", C.c_uint64), ("admitted", C.c_uint64), ("rounds", C.c_uint32),
+                ("ordered_fallback", C.c_uint32)]
 
 
 def unlimited_tres() -> np.ndarray:

@@ -101,6 +101,40 @@ def make_config(name: str, J: int | None = None, N: int | None = None, P: int | 
     return cluster, jobs, NOW
 
 
+def make_limits(name: str, cluster: Cluster, jobs: Jobs):
+    """The accounts / QoS side of a config (C4: "64 accounts x 4 QoS with max_jobs_per_user, max_tres_per_account",
+    SURVEY.md §8d), frozen like the queue: 8 root accounts with 7 children each, 1024 users (16 per account, one
+    account each), job -> (user, qos) from draw 7 of the job.  QoS 0/1 cap running jobs per user (96 / 192) and CPUs
+    per account (3000 / 6000 cores at every level of the tree), QoS 2 caps the QoS's total GPUs (4096), QoS 3 caps
+    nothing; account x partition limits (max 1500 jobs) on every 4th account.  Every memory limit is set to 2^60:
+    the reference's "unlimited" memory is kMaxJobMemoryBytes = 10 000 GB (DbClient.cpp:420-428), which as a cap on a
+    SUM of allocations would stop a 64 k-node cluster after ~1 400 jobs per QoS.
+    Returns (LimitTables, LimitJobs) in pending-vector order (= FIFO order = NodeSelect order)."""
+    from . import limits as lm
+    c = CONFIGS[name]
+    J = jobs.num_jobs
+    U, A, Q, Pn = 1024, 64, 4, max(cluster.num_partitions, 1)
+    r7 = splitmix64(SEED0 ^ c["idx"], J * NF).reshape(J, NF)[:, 7] >> np.uint64(11)
+    user = (r7 % np.uint64(U)).astype(np.uint32)
+    qos = ((r7 // np.uint64(U)) % np.uint64(Q)).astype(np.uint32)
+    account = (user % np.uint32(A)).astype(np.uint32)
+    parent = np.where(np.arange(A) < 8, lm.LIM_NONE, np.arange(A) % 8).astype(np.uint32)
+    big = 1 << 60
+    free = lm.tres(mem=big)
+    q = np.array([lm.qos_limits(max_jobs_per_user=96, max_tres_per_account=lm.tres(cpu=3000, mem=big), max_tres=free, max_tres_per_user=free),
+                  lm.qos_limits(max_jobs_per_user=192, max_tres_per_account=lm.tres(cpu=6000, mem=big), max_tres=free, max_tres_per_user=free),
+                  lm.qos_limits(max_tres=lm.tres(mem=big, names={0: 4096} if c["gres"] else None), max_tres_per_user=free, max_tres_per_account=free),
+                  lm.qos_limits(max_tres=free, max_tres_per_user=free, max_tres_per_account=free)], lm.QOS_DT)
+    pl = np.array([lm.part_limit(max_jobs=1500, max_tres=free)], lm.PART_LIMIT_DT)
+    apl = np.where((np.arange(A * Pn) // Pn) % 4 == 3, 0, lm.LIM_NONE).astype(np.uint32)
+    tables = lm.LimitTables(num_users=U, num_user_accts=U, num_partitions=Pn, qos=q, acct_parent=parent,
+                            part_limits=pl, acct_part_limit=apl)
+    part = np.minimum(jobs.partition, Pn - 1).astype(np.uint32)
+    lj = lm.LimitJobs(user=user, user_acct=user, account=account, qos=qos, partition=part,
+                      time_limit_sec=jobs.time_limit_sec)
+    return tables, lj
+
+
 def select_partitions(cluster: Cluster, jobs: Jobs, parts: list[int]):
     """Shard of a queue: the jobs (order preserved) and node lists of `parts` only, with node and
     partition indices unchanged.  Used to job-shard disjoint partitions across GPUs."""

@@ -159,6 +159,8 @@ typedef struct cns_limit_timing {
   double d2h_ms;
   uint64_t candidates; /* jobs that reached CheckAndMallocMetaResource                  */
   uint64_t admitted;
+  uint32_t rounds;            /* bracketing rounds of the parallel pass (0: not used)    */
+  uint32_t ordered_fallback;  /* 1: the ordered single-wave kernel decided (CNS_LIMITS_MODE=seq, or the rounds did not converge) */
 } cns_limit_timing;
 
 int cns_set_run_limits(cns_handle* h, const cns_limit_tables* t);

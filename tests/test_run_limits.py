@@ -285,7 +285,17 @@ def test_limits_abi_symbols(built):
 
 
 # ---------------------------------------------------------------- GPU ----------------------------------------------------
-def _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, tag=""):
+@pytest.fixture(params=["parallel", "ordered"])
+def mode(request, monkeypatch):
+    """Both device paths: the bracketing rounds over sorted items (default) and the ordered single-wave kernel."""
+    if request.param == "ordered":
+        monkeypatch.setenv("CNS_LIMITS_MODE", "seq")
+    else:
+        monkeypatch.delenv("CNS_LIMITS_MODE", raising=False)
+    return request.param
+
+
+def _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, tag="", expect_fallback=None):
     eng = engine_cls(device=0)
     try:
         eng.set_nodes(cluster)
@@ -303,6 +313,8 @@ def _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, tag=""):
             assert np.array_equal(getattr(usage, f), getattr(u_ref, f)), f"{tag}: usage table {f} differs"
         tm = eng.limit_timing()
         assert tm["admitted"] == adm and tm["candidates"] == int((r_ref != 255).sum())
+        if expect_fallback is not None:
+            assert bool(tm["ordered_fallback"]) == expect_fallback, tm
         # re-running from the same tables gives the same answer (the working copy is reset)
         eng.run_limits_resident()
         reason2, adm2 = eng.download_limits()
@@ -314,21 +326,54 @@ def _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, tag=""):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
-def test_gpu_kat(engine_cls, name):
+def test_gpu_kat(engine_cls, name, mode):
     specs, keys, ua, t, exp, extra = SCENARIOS[name]()
     cluster, lay = _cluster()
     jobs = kat.jobs(specs)
     lj = _limjobs(keys, ua, jobs.time_limit_sec)
-    reason, usage = _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, name)
+    reason, usage = _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, name, expect_fallback=mode == "ordered")
     assert list(reason) == exp
     _check_extra(usage, extra)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,tight", [(1, True), (2, True), (3, True), (4, False), (5, True), (6, False)])
-def test_gpu_random(engine_cls, seed, tight):
+def test_gpu_random(engine_cls, seed, tight, mode):
     cluster, jobs, now, lay, t, lj = random_limit_case(seed, J=900, N=128, tight=tight)
-    _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, f"seed {seed}")
+    _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, f"seed {seed}", expect_fallback=mode == "ordered")
+
+
+def dependency_chain_case(n=200):
+    """job i is admitted iff job i-1 was rejected: jobs 2m-1, 2m share an (account, qos) usage record capped at 1 core,
+    jobs 2m, 2m+1 share an (account, partition) record capped at 1 job.  The bracketing rounds decide one job per
+    round here, so the engine must notice and hand over to the ordered kernel (same answer: 1,0,1,0,...)."""
+    cluster, lay = _cluster()
+    jobs = kat.jobs([dict(cpu=1)] * n)
+    Q = Pn = n // 2 + 1
+    ua = [(0, 0)]
+    qos = [lm.qos_limits(max_tres_per_account=lm.tres(cpu=1, mem=1 << 60)) for _ in range(Q)]
+    pl = np.array([lm.part_limit(max_jobs=1, max_tres=lm.tres(mem=1 << 60))], lm.PART_LIMIT_DT)
+    t = _tables(qos, [NONE], 1, ua, Pn=Pn, part_limits=pl, acct_part_limit=[0] * Pn)
+    keys = [(0, (i + 1) // 2, i // 2) for i in range(n)]      # i = 0: (q0, p0); 1: (q1, p0); 2: (q1, p1); 3: (q2, p1) ...
+    return cluster, jobs, lay, t, _limjobs(keys, ua, jobs.time_limit_sec)
+
+
+def test_oracle_dependency_chain():
+    cluster, jobs, lay, t, lj = dependency_chain_case(40)
+    sel = pyoracle.select(cluster, jobs, NOW)
+    reason, adm, _ = pyoracle.run_limits(lay, t, lj, sel.placements)
+    # 0: ok | 1: a0 x p0 has a job -> AccPartitionJobsLimit | 2: (a0,q1) empty (1 was rejected), p1 empty -> ok | 3: (a0,q2) ok, p1 full ...
+    assert list(reason[:6]) == [0, 11, 0, 11, 0, 11] and adm == 20
+
+
+@pytest.mark.gpu
+def test_gpu_dependency_chain_falls_back_to_ordered_kernel(engine_cls, monkeypatch):
+    monkeypatch.delenv("CNS_LIMITS_MODE", raising=False)
+    cluster, jobs, lay, t, lj = dependency_chain_case(200)
+    reason, _ = _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, "chain", expect_fallback=True)
+    assert list(reason[:4]) == [0, 11, 0, 11]
+    cluster, jobs, lay, t, lj = dependency_chain_case(40)        # short chain: the rounds finish it
+    _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, "short chain", expect_fallback=False)
 
 
 @pytest.mark.gpu
