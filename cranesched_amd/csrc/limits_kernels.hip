@@ -513,75 +513,102 @@ __global__ __launch_bounds__(256) void k_par_eval(const ParParams P) {
   const u64 steps = (C + kParBatch - 1) / kParBatch;   // uniform trip count: the ballots below need every lane
   for (u64 t = 0; t < steps; ++t) {
     const u64 i = beg + t * kParBatch;
-    u32 key[kParBatch], k[kParBatch], st[kParBatch];
+    // two load stages per batch, each issued for all kParBatch items before anything is consumed: the item streams
+    // (usage record, candidate, components, limit, checks), then what they point to (the candidate's state, the limit
+    // record, usage0).  Every load is unconditional on a clamped index and masked afterwards: a load under a
+    // data-dependent branch makes the compiler wait for it on the spot (one round trip per item instead of per batch).
+    u32 key[kParBatch], k[kParBatch], st[kParBatch], lidx[kParBatch], en[kParBatch], slot[kParBatch];
     i64 add[kParBatch];
+    bool act[kParBatch], need[kParBatch];
 #pragma unroll
     for (u32 b = 0; b < kParBatch; ++b) {
-      const u64 x = live ? (i + b < end ? i + b : end - 1) : 0;
-      key[b] = live ? P.s_key[x] : kNone; k[b] = live ? P.s_k[x] : 0; add[b] = live ? P.s_add[x * 16 + comp] : 0;
+      act[b] = live && i + b < end;
+      const u64 x = act[b] ? i + b : 0;   // item 0 always exists (every candidate has at least three slots)
+      key[b] = P.s_key[x]; k[b] = P.s_k[x]; add[b] = P.s_add[x * 16 + comp];
+      lidx[b] = P.s_l[x]; en[b] = P.s_en[x];
+      slot[b] = FINAL ? P.s_slot[x] : 0;
+    }
+    i64 lim[kParBatch], cpu_x[kParBatch], c0[kParBatch];
+    u32 has[kParBatch], lvl[kParBatch];
+    bool ex0[kParBatch];
+    bool any = false;
+#pragma unroll
+    for (u32 b = 0; b < kParBatch; ++b) {
+      st[b] = P.state[k[b]];
+      const LimRec* r = P.lim + (lidx[b] == kNone ? 0u : lidx[b]);
+      lim[b] = r->lim[comp]; has[b] = r->has; cpu_x[b] = r->cpu_x;
+      c0[b] = P.usage0[(u64)key[b] * 16 + comp];
+      ex0[b] = P.exists0[key[b]] != 0;
+      lvl[b] = FINAL ? P.rec_meta[k[b]] >> 8 : 0;
     }
 #pragma unroll
-    for (u32 b = 0; b < kParBatch; ++b) st[b] = live ? P.state[k[b]] : 2;
+    for (u32 b = 0; b < kParBatch; ++b) {
+      if (lidx[b] == kNone) { lim[b] = kInf; cpu_x[b] = kInf; has[b] = 0; }
+      if (comp != 0) cpu_x[b] = kInf;
+      if (comp != 1) ex0[b] = true;
+      if (!act[b]) { st[b] = 2; key[b] = kNone; add[b] = 0; }
+    }
 #pragma unroll
     for (u32 b = 0; b < kParBatch; ++b) {
-      const bool act = live && i + b < end;
-      if (act && key[b] != prev) {
+      need[b] = act[b] && (FINAL ? st[b] == 2 : st[b] == 0);
+      any = any || need[b];
+    }
+    const bool wave_any = __ballot(any) != 0;
+#pragma unroll
+    for (u32 b = 0; b < kParBatch; ++b) {
+      if (act[b] && key[b] != prev) {
         if (FINAL && prev != kNone) {  // the previous usage record is complete: DoMallocResource_'s result
           P.usage[(u64)prev * 16 + comp] = P.usage0[(u64)prev * 16 + comp] + aL;
           if (comp == 1 && aL > 0) P.exists[prev] = 1;
         }
         aL = 0; aU = 0; prev = key[b];
       }
-      const bool need = act && (FINAL ? st[b] == 2 : st[b] == 0);
-      if (__ballot(need)) {
-        const u64 x = act ? i + b : 0;
-        const u32 lidx = need ? P.s_l[x] : kNone, en = need ? P.s_en[x] : 0;
-        i64 lim = kInf, cpu_x = kInf;
-        u32 has = 0;
-        if (lidx != kNone) { const LimRec* r = P.lim + lidx; lim = r->lim[comp]; has = r->has; if (comp == 0) cpu_x = r->cpu_x; }
-        const i64 c0 = need ? P.usage0[(u64)key[b] * 16 + comp] : 0;
-        const bool ex0 = need && comp == 1 ? P.exists0[key[b]] != 0 : true;
-        const i64 useL = c0 + aL + add[b], useU = c0 + aU + add[b];
+      if (wave_any && __ballot(need[b])) {
+        const bool nd = need[b];
+        const i64 useL = c0[b] + aL + add[b], useU = c0[b] + aU + add[b];
         if (FINAL) {
-          const u32 L = need ? P.rec_meta[k[b]] >> 8 : 0;
-          const u32 v = par_slot_reason(useL, lim, cpu_x, has, en, ex0 || aL > 0, comp, need ? P.s_slot[x] : 0, L, lane);
-          if (need && v != 0xFFFFu) atomicMin(&P.jobkey[k[b]], v);
+          const u32 v = par_slot_reason(useL, lim[b], cpu_x[b], has[b], en[b], ex0[b] || aL > 0, comp, slot[b], lvl[b], lane);
+          if (nd && v != 0xFFFFu) atomicMin(&P.jobkey[k[b]], v);
         } else {
-          const bool on = need && (en >> comp & 1) != 0;
+          const bool on = nd && (en[b] >> comp & 1) != 0;
           bool fC = false, fM = false, sC = false, sM = false, gC = false, gM = false;
           if (comp == 0) {
-            fC = on && (useL > cpu_x || useL > lim);
-            fM = on && (useU > cpu_x || useU > lim);
+            fC = on && (useL > cpu_x[b] || useL > lim[b]);
+            fM = on && (useU > cpu_x[b] || useU > lim[b]);
           } else if (comp < 4) {
-            fC = on && useL > lim;
-            fM = on && useU > lim;
-            if (comp == 1 && need && (en & kLimNeedExists)) {   // the entry exists once any earlier job was admitted
-              const bool exL = ex0 || aL > 0, exU = ex0 || aU > 0;
+            fC = on && useL > lim[b];
+            fM = on && useU > lim[b];
+            if (comp == 1 && nd && (en[b] & kLimNeedExists)) {   // the entry exists once any earlier job was admitted
+              const bool exL = ex0[b] || aL > 0, exU = ex0[b] || aU > 0;
               fC = fC || !exU;
               fM = fM || !exL;
             }
           } else {
-            const bool h = (has >> comp & 1) != 0, pC = useL > 0, pM = useU > 0;
+            const bool h = (has[b] >> comp & 1) != 0, pC = useL > 0, pM = useU > 0;
             sC = on && !h && pC;
             sM = on && !h && pM;
-            gC = on && h && useL > lim;
-            gM = on && h && useU > lim;
+            gC = on && h && useL > lim[b];
+            gM = on && h && useU > lim[b];
           }
           const u32 sh = lane & 48u;
           const u32 bfC = (u32)(__ballot(fC) >> sh) & 0xFFFFu, bfM = (u32)(__ballot(fM) >> sh) & 0xFFFFu;
-          const u32 bsC = (u32)(__ballot(sC) >> sh) & 0xFFFFu, bsM = (u32)(__ballot(sM) >> sh) & 0xFFFFu;
-          const u32 bgC = (u32)(__ballot(gC) >> sh) & 0xFFFFu, bgM = (u32)(__ballot(gM) >> sh) & 0xFFFFu;
-          // CheckGres_ over the interval: certainly passes iff the first of {certain stop, any fail} is a certain stop
-          // (or none exists); certainly fails iff the first of {any stop, any fail} is a certain fail
-          const u32 m1 = bsC | bgC | bgM, m2 = m1 | bsM;
-          const bool g_pass = m1 == 0 || (bsC & (m1 & (0u - m1))) != 0;
-          const bool g_fail = m2 != 0 && (bgC & (m2 & (0u - m2))) != 0;
+          const u64 any_gres = __ballot(sM || gM);
+          bool g_pass = true, g_fail = false;
+          if (any_gres) {
+            const u32 bsC = (u32)(__ballot(sC) >> sh) & 0xFFFFu, bsM = (u32)(__ballot(sM) >> sh) & 0xFFFFu;
+            const u32 bgC = (u32)(__ballot(gC) >> sh) & 0xFFFFu, bgM = (u32)(__ballot(gM) >> sh) & 0xFFFFu;
+            // CheckGres_ over the interval: certainly passes iff the first of {certain stop, any fail} is a certain
+            // stop (or none exists); certainly fails iff the first of {any stop, any fail} is a certain fail
+            const u32 m1 = bsC | bgC | bgM, m2 = m1 | bsM;
+            g_pass = m1 == 0 || (bsC & (m1 & (0u - m1))) != 0;
+            g_fail = m2 != 0 && (bgC & (m2 & (0u - m2))) != 0;
+          }
           const bool cfail = bfC != 0 || g_fail;
           const bool cpass = bfM == 0 && g_pass;   // bfM includes bfC
-          if (need && comp == 0 && (cfail || !cpass)) atomicOr(&P.flags[k[b]], (cfail ? 1u : 0u) | (cpass ? 0u : 2u));
+          if (nd && comp == 0 && (cfail || !cpass)) atomicOr(&P.flags[k[b]], (cfail ? 1u : 0u) | (cpass ? 0u : 2u));
         }
       }
-      if (act) {
+      if (act[b]) {
         aL += st[b] == 1 ? add[b] : 0;
         aU += st[b] != 2 ? add[b] : 0;
       }
