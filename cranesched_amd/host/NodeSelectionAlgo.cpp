@@ -9,6 +9,7 @@
 
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/priority.h"
+#include "../../include/crane_gpu/run_limits.h"
 
 namespace crane {
 
@@ -30,6 +31,7 @@ struct GpuNodeSelectionAlgo::Impl {
   std::vector<std::vector<SlotId>> class_bit_slot;          // per class: bit offset -> slot path
   cns_gres_layout layout{};
   bool have_snapshot = false;
+  std::unordered_map<const PdJobInScheduler*, uint64_t> last_index;  // job -> its index in the last cns_select
 
   int class_of(const std::string& name, const std::string& type) const {
     for (size_t c = 0; c < classes.size(); ++c)
@@ -334,8 +336,10 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   out.start_sec = o_start.data(); out.reason = o_reason.data(); out.place_offsets = o_off.data();
   out.node_idx = o_node.data(); out.ntasks = o_nt.data(); out.cpu_raw = o_cpu.data(); out.mem = o_mem.data();
   out.core_lo = o_lo.data(); out.core_hi = o_hi.data(); out.gres = o_g.data();
+  I.last_index.clear();
   st = cns_select(I.h, now, &js, &out);
   if (st != 0) return fail_all(st, cns_last_error(I.h));
+  for (size_t j = 0; j < J; ++j) I.last_index[ord[j]] = j;
   status_ = 0;
   error_.clear();
 
@@ -359,6 +363,251 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
       p.allocated_res[cid] = std::move(res);
     }
   }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Run-limit admission (JobScheduler.cpp:1557-1573 -> AccountMetaContainer.cpp:180-224).  Host work: names -> dense
+// indices and maps -> tables (what the reference does with string-keyed hash maps per job); every comparison and
+// usage update runs on the device (cns_apply_run_limits).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+ResourceView UnlimitedTres() {  // DbClient.cpp:420-428
+  ResourceView v;
+  v.cpu_count = cpu_t::from_raw(CNS_LIM_UNLIMITED_CPU_RAW);
+  v.memory_bytes = v.memory_sw_bytes = CNS_LIM_MAX_JOB_MEMORY;
+  return v;
+}
+const char* kLimitReasonStr[] = {"", "QosEntryNotFound", "QosCpuResourceLimit", "QosJobsResourceLimit", "QosWallTimeLimit",
+                                 "CpuResourceLimit", "MemResourceLimit", "GresResourceLimit", "PartitionEntryNotFound",
+                                 "UserPartitionJobsLimit", "UserPartitionWallTimeLimit", "AccPartitionJobsLimit",
+                                 "AccPartitionWallTimeLimit", "PartitionCpuResourceLimit", "PartitionMemResourceLimit",
+                                 "PartitionGresResourceLimit"};
+}  // namespace
+
+Qos::Qos() : max_tres(UnlimitedTres()), max_tres_per_user(UnlimitedTres()), max_tres_per_account(UnlimitedTres()) {}
+PartitionResourceLimit::PartitionResourceLimit() : max_tres(UnlimitedTres()) {}
+
+void GpuNodeSelectionAlgo::CheckAndMallocMetaResource(AccountMetaSnapshot& meta,
+                                                      const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                                      std::vector<std::string>& results) {
+  Impl& I = *impl_;
+  results.assign(pending_jobs.size(), std::string());
+  auto fail_all = [&](int st, const std::string& msg) {
+    status_ = st; error_ = msg;
+    for (size_t i = 0; i < pending_jobs.size(); ++i) results[i] = pending_jobs[i]->reason.empty() ? "GpuEngineError" : pending_jobs[i]->reason;
+  };
+  if (!I.h) return fail_all(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
+  if (!I.have_snapshot) return fail_all(CNS_ERR_STATE, "CheckAndMallocMetaResource before SetClusterSnapshot / NodeSelect");
+
+  // ---- dense indices (sorted names: deterministic) ----
+  auto index_of = [](const auto& m) {
+    std::map<std::string, uint32_t> ix;
+    for (const auto& kv : m) ix.emplace(kv.first, 0);
+    uint32_t n = 0;
+    for (auto& kv : ix) kv.second = n++;
+    return ix;
+  };
+  const std::map<std::string, uint32_t> qos_ix = index_of(meta.qos), acct_ix = index_of(meta.account_parent), user_ix = index_of(meta.user_accounts);
+  std::map<std::pair<std::string, std::string>, uint32_t> ua_ix;  // (user, account) pairs of User::account_to_attrs_map
+  for (const auto& [u, accts] : meta.user_accounts)
+    for (const auto& [a, lims] : accts) ua_ix.emplace(std::make_pair(u, a), 0);
+  { uint32_t n = 0; for (auto& kv : ua_ix) kv.second = n++; }
+  const uint32_t Q = (uint32_t)qos_ix.size(), A = (uint32_t)acct_ix.size(), U = (uint32_t)user_ix.size(), UA = (uint32_t)ua_ix.size();
+  const uint32_t Pn = (uint32_t)I.part_idx.size();
+  std::vector<std::string> part_name(Pn);
+  for (const auto& [name, ix] : I.part_idx) part_name[ix] = name;
+  if (!Q) return fail_all(CNS_ERR_INVALID_ARG, "AccountMetaSnapshot without QoS");
+
+  auto to_tres = [&](const ResourceView& v) {
+    cns_tres t{};
+    t.cpu_raw = v.cpu_count.raw;
+    t.mem = v.memory_bytes;
+    for (const auto& [name, gc] : v.gres_map) {
+      auto nit = I.name_id.find(name);
+      if (nit == I.name_id.end()) continue;
+      t.name_mask |= 1u << nit->second;
+      t.name_total[nit->second] = gc.total;
+      for (const auto& [type, cnt] : gc.specified) {
+        const int c = I.class_of(name, type);
+        if (c < 0) continue;
+        t.class_mask |= 1u << c;
+        t.class_count[c] = cnt;
+      }
+    }
+    return t;
+  };
+  auto to_usage = [&](const MetaResource& m) {
+    cns_usage u{};
+    u.cpu_raw = m.resource.cpu_count.raw;
+    u.mem = m.resource.memory_bytes;
+    u.wall_sec = m.wall_time;
+    u.jobs_count = m.jobs_count;
+    for (const auto& [name, gc] : m.resource.gres_map) {
+      auto nit = I.name_id.find(name);
+      if (nit == I.name_id.end()) continue;
+      u.name_total[nit->second] = gc.total;
+      for (const auto& [type, cnt] : gc.specified) {
+        const int c = I.class_of(name, type);
+        if (c >= 0) u.class_count[c] = cnt;
+      }
+    }
+    return u;
+  };
+  auto from_usage = [&](const cns_usage& u) {
+    MetaResource m;
+    m.resource.cpu_count = cpu_t::from_raw(u.cpu_raw);
+    m.resource.memory_bytes = u.mem;
+    m.wall_time = u.wall_sec;
+    m.jobs_count = u.jobs_count;
+    for (const auto& [name, id] : I.name_id)
+      if (u.name_total[id]) m.resource.gres_map[name].total = u.name_total[id];
+    for (size_t c = 0; c < I.classes.size(); ++c)
+      if (u.class_count[c]) m.resource.gres_map[I.classes[c].first].specified[I.classes[c].second] = u.class_count[c];
+    return m;
+  };
+
+  // ---- limits ----
+  std::vector<cns_qos_limits> qos(Q);
+  for (const auto& [name, ix] : qos_ix) {
+    const Qos& s = meta.qos.at(name);
+    cns_qos_limits& d = qos[ix];
+    d.max_jobs_per_user = s.max_jobs_per_user; d.max_jobs_per_account = s.max_jobs_per_account; d.max_jobs = s.max_jobs;
+    d.max_cpus_per_user_raw = s.max_cpus_per_user.raw; d.max_wall_sec = s.max_wall;
+    d.max_tres = to_tres(s.max_tres); d.max_tres_per_user = to_tres(s.max_tres_per_user); d.max_tres_per_account = to_tres(s.max_tres_per_account);
+  }
+  std::vector<uint32_t> parent(A, CNS_LIM_NONE);
+  for (const auto& [name, ix] : acct_ix) {
+    const std::string& p = meta.account_parent.at(name);
+    if (!p.empty()) { auto it = acct_ix.find(p); if (it != acct_ix.end()) parent[ix] = it->second; }
+  }
+  std::vector<cns_part_limit> plims;
+  auto add_plim = [&](const PartitionResourceLimit& s) {
+    cns_part_limit d{};
+    d.max_jobs = s.max_jobs; d.max_wall_sec = s.max_wall; d.max_tres = to_tres(s.max_tres);
+    plims.push_back(d);
+    return (uint32_t)plims.size() - 1;
+  };
+  std::vector<uint32_t> upl((size_t)UA * Pn, CNS_LIM_NONE), apl((size_t)A * Pn, CNS_LIM_NONE);
+  for (const auto& [key, x] : ua_ix)
+    for (const auto& [pname, lim] : meta.user_accounts.at(key.first).at(key.second)) {
+      auto pit = I.part_idx.find(pname);
+      if (pit != I.part_idx.end()) upl[(size_t)x * Pn + pit->second] = add_plim(lim);
+    }
+  for (const auto& [aname, lims] : meta.account_partition_limits) {
+    auto ait = acct_ix.find(aname);
+    if (ait == acct_ix.end()) continue;
+    for (const auto& [pname, lim] : lims) {
+      auto pit = I.part_idx.find(pname);
+      if (pit != I.part_idx.end()) apl[(size_t)ait->second * Pn + pit->second] = add_plim(lim);
+    }
+  }
+  // ---- usage maps -> tables (an absent map entry = exists 0) ----
+  std::vector<cns_usage> uq((size_t)U * Q), up((size_t)UA * Pn), aq((size_t)A * Q), ap((size_t)A * Pn), qu(Q);
+  std::vector<uint8_t> uqe(uq.size(), 0), upe(up.size(), 0), aqe(aq.size(), 0), ape(ap.size(), 0);
+  for (const auto& [uname, stat] : meta.user_meta) {
+    auto uit = user_ix.find(uname);
+    if (uit == user_ix.end()) continue;
+    for (const auto& [qname, m] : stat.qos_to_resource_map) {
+      auto qit = qos_ix.find(qname);
+      if (qit != qos_ix.end()) { uq[(size_t)uit->second * Q + qit->second] = to_usage(m); uqe[(size_t)uit->second * Q + qit->second] = 1; }
+    }
+    for (const auto& [aname, pm] : stat.account_to_partition_to_resource_map) {
+      auto x = ua_ix.find({uname, aname});
+      if (x == ua_ix.end()) continue;
+      for (const auto& [pname, m] : pm) {
+        auto pit = I.part_idx.find(pname);
+        if (pit != I.part_idx.end()) { up[(size_t)x->second * Pn + pit->second] = to_usage(m); upe[(size_t)x->second * Pn + pit->second] = 1; }
+      }
+    }
+  }
+  for (const auto& [aname, stat] : meta.account_meta) {
+    auto ait = acct_ix.find(aname);
+    if (ait == acct_ix.end()) continue;
+    for (const auto& [qname, m] : stat.qos_to_resource_map) {
+      auto qit = qos_ix.find(qname);
+      if (qit != qos_ix.end()) { aq[(size_t)ait->second * Q + qit->second] = to_usage(m); aqe[(size_t)ait->second * Q + qit->second] = 1; }
+    }
+    for (const auto& [pname, m] : stat.partition_to_resource_map) {
+      auto pit = I.part_idx.find(pname);
+      if (pit != I.part_idx.end()) { ap[(size_t)ait->second * Pn + pit->second] = to_usage(m); ape[(size_t)ait->second * Pn + pit->second] = 1; }
+    }
+  }
+  for (const auto& [qname, m] : meta.qos_meta) {
+    auto qit = qos_ix.find(qname);
+    if (qit != qos_ix.end()) qu[qit->second] = to_usage(m);
+  }
+  cns_limit_tables t{};
+  t.num_users = U; t.num_user_accts = UA; t.num_accounts = A; t.num_qos = Q; t.num_partitions = Pn; t.num_part_limits = (uint32_t)plims.size();
+  t.qos = qos.data(); t.acct_parent = parent.data(); t.part_limits = plims.data();
+  t.user_part_limit = upl.data(); t.acct_part_limit = apl.data();
+  t.user_qos = uq.data(); t.user_qos_exists = uqe.data(); t.user_part = up.data(); t.user_part_exists = upe.data();
+  t.acct_qos = aq.data(); t.acct_qos_exists = aqe.data(); t.acct_part = ap.data(); t.acct_part_exists = ape.data();
+  t.qos_usage = qu.data();
+  int st = cns_set_run_limits(I.h, &t);
+  if (st != 0) return fail_all(st, cns_last_error(I.h));
+
+  // ---- the pending vector: keys, and the lookups the reference fails on before CheckRunLimits_ ----
+  const size_t J = pending_jobs.size();
+  std::vector<uint64_t> sel(J, 0);
+  std::vector<uint32_t> user(J, 0), ua(J, 0), acct(J, 0), qosv(J, 0), part(J, 0);
+  std::vector<int64_t> tl(J, 0);
+  std::vector<uint8_t> skip(J, 0);
+  for (size_t i = 0; i < J; ++i) {
+    const PdJobInScheduler& p = *pending_jobs[i];
+    auto li = I.last_index.find(&p);
+    if (!p.reason.empty() || li == I.last_index.end()) { skip[i] = 1; results[i] = p.reason; continue; }   // :1507-1510
+    sel[i] = li->second;
+    tl[i] = p.time_limit;
+    const char* err = nullptr;
+    auto uit = user_ix.find(p.username);
+    auto qit = qos_ix.find(p.qos);
+    auto ait = acct_ix.find(p.account);
+    auto xit = ua_ix.find({p.username, p.account});
+    auto pit = I.part_idx.find(p.partition_id);
+    if (uit == user_ix.end()) err = "InvalidUser";                                    // :186-191
+    else if (ait == acct_ix.end()) err = "InvalidAccount";                            // :193-199,958-963
+    else if (qit == qos_ix.end()) err = "InvalidQOS";                                 // :201-202
+    else if (!meta.user_meta.count(p.username)) err = "UserMetaNotFound";            // :895-899
+    else if (!meta.qos_meta.count(p.qos)) err = "QosMetaNotFound";                    // :909-913
+    else if (xit == ua_ix.end()) err = "UserAccountMismatch";                         // :920-928
+    else if (pit == I.part_idx.end()) err = "Partition Not Found";
+    if (!err)
+      for (std::string a = p.account; !a.empty(); a = meta.account_parent.count(a) ? meta.account_parent.at(a) : std::string())
+        if (!meta.account_meta.count(a)) { err = "AccountMetaNotFound"; break; }     // :901-907
+    if (err) { skip[i] = 1; results[i] = err; continue; }
+    user[i] = uit->second; ua[i] = xit->second; acct[i] = ait->second; qosv[i] = qit->second; part[i] = pit->second;
+  }
+  cns_limit_job_soa lj{};
+  lj.num_jobs = J; lj.select_index = sel.data(); lj.user = user.data(); lj.user_acct = ua.data(); lj.account = acct.data();
+  lj.qos = qosv.data(); lj.partition = part.data(); lj.time_limit_sec = tl.data(); lj.skip = skip.data();
+  std::vector<uint8_t> reason(J + 1, 0);
+  uint64_t admitted = 0;
+  st = cns_apply_run_limits(I.h, &lj, reason.data(), &admitted);
+  if (st != 0) return fail_all(st, cns_last_error(I.h));
+  for (size_t i = 0; i < J; ++i)
+    if (!skip[i]) results[i] = reason[i] < 16 ? kLimitReasonStr[reason[i]] : "GpuEngineError";
+
+  // ---- DoMallocResource_'s result back into the caller's maps ----
+  st = cns_get_usage(I.h, uq.data(), uqe.data(), up.data(), upe.data(), aq.data(), aqe.data(), ap.data(), ape.data(), qu.data());
+  if (st != 0) { status_ = st; error_ = cns_last_error(I.h); return; }
+  for (const auto& [uname, uix] : user_ix) {
+    for (const auto& [qname, qix] : qos_ix)
+      if (uqe[(size_t)uix * Q + qix]) meta.user_meta[uname].qos_to_resource_map[qname] = from_usage(uq[(size_t)uix * Q + qix]);
+  }
+  for (const auto& [key, x] : ua_ix)
+    for (uint32_t pp = 0; pp < Pn; ++pp)
+      if (upe[(size_t)x * Pn + pp]) meta.user_meta[key.first].account_to_partition_to_resource_map[key.second][part_name[pp]] = from_usage(up[(size_t)x * Pn + pp]);
+  for (const auto& [aname, aix] : acct_ix) {
+    for (const auto& [qname, qix] : qos_ix)
+      if (aqe[(size_t)aix * Q + qix]) meta.account_meta[aname].qos_to_resource_map[qname] = from_usage(aq[(size_t)aix * Q + qix]);
+    for (uint32_t pp = 0; pp < Pn; ++pp)
+      if (ape[(size_t)aix * Pn + pp]) meta.account_meta[aname].partition_to_resource_map[part_name[pp]] = from_usage(ap[(size_t)aix * Pn + pp]);
+  }
+  for (const auto& [qname, qix] : qos_ix)
+    if (meta.qos_meta.count(qname)) meta.qos_meta[qname] = from_usage(qu[qix]);
+  status_ = 0;
+  error_.clear();
 }
 
 

@@ -123,6 +123,10 @@ struct PdJobInScheduler {  // JobScheduler.h:92-170
   uint32_t partition_priority{0};
   double priority{0.0};               // cached across cycles: 0.0 = compute (cpp:7616)
   ResourceView req_total_res_view;    // req_node * node_num + req_task * ntasks (cpp:7156)
+  // read by the commit loop's run-limit check (AccountMetaContainer::CheckAndMallocMetaResource); the account chain
+  // (job.account_chain, JobScheduler.h:108) is derived from AccountMetaSnapshot::account_parent
+  std::string username;
+  std::string qos;
 };
 
 // What NodeSelect's prologue reads from g_meta_container (JobScheduler.cpp:6563-6617): per craned its
@@ -146,6 +150,46 @@ struct ClusterSnapshot {
   std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
   std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
   std::vector<ResvMeta> reservations;                                     // g_meta_container->GetResvMetaMapPtr(); vector order = canonical order
+};
+
+// ---- what the commit loop's run-limit admission reads (JobScheduler.cpp:1557-1573) -----------------------------
+// Qos (src/CraneCtld/Account/AccountDefs.h:27-49), the fields CheckRunLimits_ reads
+struct Qos {
+  uint32_t max_jobs_per_user{UINT32_MAX};
+  uint32_t max_jobs_per_account{UINT32_MAX};
+  uint32_t max_jobs{UINT32_MAX};
+  cpu_t max_cpus_per_user{cpu_t::from_raw(int64_t{1} << 53)};   // kUnlimitedCpu
+  int64_t max_wall{0};                                          // absl::Duration seconds, 0 = unlimited
+  ResourceView max_tres, max_tres_per_user, max_tres_per_account;
+  Qos();
+};
+struct PartitionResourceLimit {  // AccountDefs.h:163-175
+  ResourceView max_tres;
+  uint32_t max_jobs{UINT32_MAX};
+  int64_t max_wall{0};
+  PartitionResourceLimit();
+};
+struct MetaResource {  // AccountMetaContainer.h:30-35
+  ResourceView resource;
+  uint32_t jobs_count{0};
+  int64_t wall_time{0};
+};
+struct MetaResourceStat {  // AccountMetaContainer.h:62-80
+  std::unordered_map<std::string /*qos*/, MetaResource> qos_to_resource_map;
+  std::unordered_map<std::string /*account*/, std::unordered_map<PartitionId, MetaResource>> account_to_partition_to_resource_map;  // users
+  std::unordered_map<PartitionId, MetaResource> partition_to_resource_map;                                                          // accounts
+};
+// The state of AccountManager + AccountMetaContainer the check reads, copied by the caller under the locks the
+// reference takes (AccountMetaContainer.cpp:204-207).
+struct AccountMetaSnapshot {
+  std::unordered_map<std::string, Qos> qos;                                              // GetExistedQosInfo
+  std::unordered_map<std::string, std::string> account_parent;                           // Account::parent_account, "" = root
+  std::unordered_map<std::string, std::unordered_map<PartitionId, PartitionResourceLimit>> account_partition_limits;  // Account::partition_to_limit_map
+  // User::account_to_attrs_map: the accounts of a user, each with its partition_to_limit_map
+  std::unordered_map<std::string, std::unordered_map<std::string, std::unordered_map<PartitionId, PartitionResourceLimit>>> user_accounts;
+  std::unordered_map<std::string, MetaResourceStat> user_meta;     // m_user_meta_map_
+  std::unordered_map<std::string, MetaResourceStat> account_meta;  // m_account_meta_map_
+  std::unordered_map<std::string, MetaResource> qos_meta;          // m_qos_meta_map_
 };
 
 // License (LicenseManager: total, used, reserved, last_deficit as read at LicenseManager.cpp:188-189,203-204)
@@ -223,6 +267,15 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
 
   void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
                   const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) override;
+
+  // The run-limit admission of the commit loop, batched: AccountMetaContainer::CheckAndMallocMetaResource
+  // (AccountMetaContainer.cpp:180-224) for every job of `pending_jobs` — in THAT order, JobScheduler.cpp:1492 — that the
+  // last NodeSelect started (`reason` empty).  results[i] = "" (admitted: `meta`'s usage maps now include the job, as
+  // after DoMallocResource_) or the pending reason the reference would set ("QosJobsResourceLimit", ...); jobs with a
+  // reason keep it.  The NodeSelect results are read where they are, on the device (include/crane_gpu/run_limits.h).
+  // GRES names / types no node of the snapshot has are dropped from limits and usage (no job can allocate them).
+  void CheckAndMallocMetaResource(AccountMetaSnapshot& meta, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                  std::vector<std::string>& results);
 
   bool Ok() const { return status_ == 0; }
   int LastStatus() const { return status_; }

@@ -201,6 +201,48 @@ int main(int argc, char** argv) {
       algo.SetPrioritySorter(nullptr);
     }
 
+    // --- the commit loop's run-limit admission after NodeSelect (JobScheduler.cpp:1557-1573) --------------------
+    {
+      snap.craned_metas = {node("cn0", 4, 16), node("cn1", 4, 16)};
+      snap.partitions = {{"CPU", {"cn0", "cn1"}}};
+      algo.SetClusterSnapshot(snap);
+      AccountMetaSnapshot meta;
+      Qos normal;
+      normal.max_jobs_per_user = 1;                       // -> "QosJobsResourceLimit" for a user's second job (:526-527)
+      normal.max_tres_per_account.cpu_count = cpu_t(2);   // every account of the chain may hold 2 cores (:538)
+      meta.qos["normal"] = normal;
+      meta.account_parent = {{"root", ""}, {"lab", "root"}};
+      for (const char* u : {"alice", "bob", "dave"}) {
+        meta.user_accounts[u]["lab"];                      // User::account_to_attrs_map, no partition limits
+        meta.user_meta[u].qos_to_resource_map["normal"];   // entries created at submit time
+      }
+      for (const char* a : {"root", "lab"}) meta.account_meta[a].qos_to_resource_map["normal"];
+      meta.qos_meta["normal"];
+      pd.clear();
+      auto uj = [&](job_id_t id, const char* user) {
+        auto j = job(id, 1, 100);
+        j->username = user; j->account = "lab"; j->qos = "normal";
+        return j;
+      };
+      pd.push_back(uj(1, "alice")); pd.push_back(uj(2, "alice")); pd.push_back(uj(3, "bob")); pd.push_back(uj(4, "carol"));
+      pd.push_back(uj(5, "dave"));
+      std::vector<std::unique_ptr<RnJobInScheduler>> none;
+      algo.NodeSelect(now, none, pd);
+      for (const auto& j : pd) CHECK(j->is_scheduled() && j->start_time == now);
+      std::vector<std::string> res;
+      algo.CheckAndMallocMetaResource(meta, pd, res);
+      CHECK(algo.Ok());
+      CHECK(res.size() == 5 && res[0].empty() && res[1] == "QosJobsResourceLimit" && res[2].empty());
+      CHECK(res[3] == "InvalidUser");                      // not in AccountManager (:186-191)
+      CHECK(res[4] == "CpuResourceLimit");                 // lab already holds 2 cores (alice, bob)
+      CHECK(meta.user_meta["alice"].qos_to_resource_map["normal"].jobs_count == 1);
+      CHECK(meta.user_meta["alice"].account_to_partition_to_resource_map["lab"]["CPU"].jobs_count == 1);  // created by DoMallocResource_
+      CHECK(meta.account_meta["root"].qos_to_resource_map["normal"].jobs_count == 2);
+      CHECK(meta.account_meta["lab"].qos_to_resource_map["normal"].resource.cpu_count == cpu_t(2));
+      CHECK(meta.account_meta["lab"].partition_to_resource_map["CPU"].wall_time == 200);
+      CHECK(meta.qos_meta["normal"].jobs_count == 2 && meta.user_meta["dave"].qos_to_resource_map["normal"].jobs_count == 0);
+    }
+
     // --- a running job shapes the snapshot (cost and availability) ------------------------------------------
     snap.craned_metas = {node("cn0", 2, 8), node("cn1", 2, 8)};
     snap.partitions = {{"CPU", {"cn0", "cn1"}}};

@@ -29,7 +29,12 @@ def test_header_symbols_exported(built):
     assert set(pnames) == set(engine.PRIORITY_ABI_SYMBOLS)
     for n in pnames:
         assert hasattr(lib, n), f"{n} declared in priority.h but not exported"
-    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "priority.h"]
+    # ... and run_limits.h (run-limit admission of the commit loop)
+    lnames = header_functions("run_limits.h")
+    assert set(lnames) == set(engine.LIMITS_ABI_SYMBOLS)
+    for n in lnames:
+        assert hasattr(lib, n), f"{n} declared in run_limits.h but not exported"
+    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "priority.h", "run_limits.h"]
 
 
 def test_no_gpu_means_loud_failure(built):
