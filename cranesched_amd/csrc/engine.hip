@@ -80,6 +80,7 @@ struct cns_engine {
   DevBuf d_part_off, d_slot_node, d_type_total, d_blocks, d_cost, d_fcpu,
       d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
   DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results, d_params, d_prof;
+  DevBuf d_raw[16];  // the caller's job arrays as uploaded (k_pack_jobs reads them; d_raw[14] = place offsets)
   // job table
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
   std::vector<u64> place_off;
@@ -321,6 +322,7 @@ void cns_destroy(cns_handle* h) {
     b->release();
   for (DevBuf& b : h->d_prio) b.release();
   for (DevBuf& b : h->d_lim) b.release();
+  for (DevBuf& b : h->d_raw) b.release();
   for (DevBuf& b : h->d_limpar) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -570,62 +572,66 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   std::vector<u64> pj_off(h->P + 1, 0);
   for (u32 p = 0; p < h->P; ++p) pj_off[p + 1] = pj_off[p] + pj_cnt[p + 1];
   const u64 Jg = pj_off[h->P];
-  // job records (host half: dwords 0..29 of 64), grouped by partition in queue order (lane-striped fetch on the device)
-  std::vector<u32> stage((size_t)std::max<u64>(Jg, 1) * kJobRecDwords, 0);
+  // grouped by partition in queue order: one u32 per job on the host; the 64-dword records are packed on the
+  // device from the caller's arrays (k_pack_jobs)
   std::vector<u64> cur(pj_off.begin(), pj_off.end() - 1);
-  std::vector<u32> incl, excl;
-  std::vector<u32> grouped((size_t)Jg);
+  std::vector<u32> grouped((size_t)std::max<u64>(Jg, 1));
   for (u64 j = 0; j < batch; ++j) {
     if (reason[j] != CNS_REASON_NONE) continue;
     grouped[(size_t)cur[part_of[j]]++] = (u32)j;
   }
-  auto put64 = [](u32* rec, u32 f, u64 v) { rec[f] = (u32)v; rec[f + 1] = (u32)(v >> 32); };
-  for (u64 i = 0; i < Jg; ++i) {
-    const u64 j = grouped[(size_t)i];
-    u32* rec = stage.data() + (size_t)i * kJobRecDwords;
-    u32 flags = 0;
-    put64(rec, 0, (u64)jb->time_limit_sec[j]);
-    put64(rec, 2, (u64)(jb->node_cpu_raw ? jb->node_cpu_raw[j] : 0));
-    put64(rec, 4, jb->node_mem[j]);
-    put64(rec, 6, (u64)jb->task_cpu_raw[j]);
-    put64(rec, 8, jb->task_mem[j]);
-    u32 gtot = 0;
-    u64 gspec = 0;
-    if (jb->gres_total) memcpy(&gtot, jb->gres_total + j * CNS_MAX_GRES_NAMES, 4);
-    if (jb->gres_spec) memcpy(&gspec, jb->gres_spec + j * CNS_MAX_GRES_CLASSES, 8);
-    for (u32 c = h->gres.num_classes; c < CNS_MAX_GRES_CLASSES; ++c)
-      if ((gspec >> (8 * c)) & 0xFF) return fail(h, CNS_ERR_INVALID_ARG, "job requests an undefined GRES class");
-    if (gtot | gspec) flags |= kJfGres;
-    put64(rec, 10, gspec);
-    rec[12] = jb->node_num[j];
-    rec[13] = jb->ntasks[j];
-    rec[14] = jb->ntasks_per_node_min[j];
-    rec[15] = jb->ntasks_per_node_max[j];
-    rec[17] = gtot;
-    rec[18] = (u32)j;
-    put64(rec, 20, h->place_off[j]);
-    if (jb->exclusive && jb->exclusive[j]) flags |= kJfExclusive;
-    put64(rec, 22, incl.size());
-    if (jb->incl_offsets && jb->incl_offsets[j + 1] > jb->incl_offsets[j]) {
-      flags |= kJfIncl;
-      incl.insert(incl.end(), jb->incl_nodes + jb->incl_offsets[j], jb->incl_nodes + jb->incl_offsets[j + 1]);
+  if (jb->gres_spec)
+    for (u64 i = 0; i < Jg; ++i) {
+      const uint8_t* g = jb->gres_spec + (u64)grouped[(size_t)i] * CNS_MAX_GRES_CLASSES;
+      for (u32 c = h->gres.num_classes; c < CNS_MAX_GRES_CLASSES; ++c)
+        if (g[c]) return fail(h, CNS_ERR_INVALID_ARG, "job requests an undefined GRES class");
     }
-    put64(rec, 24, incl.size());
-    put64(rec, 26, excl.size());
-    if (jb->excl_offsets && jb->excl_offsets[j + 1] > jb->excl_offsets[j]) {
-      flags |= kJfExcl;
-      excl.insert(excl.end(), jb->excl_nodes + jb->excl_offsets[j], jb->excl_nodes + jb->excl_offsets[j + 1]);
-    }
-    put64(rec, 28, excl.size());
-    rec[16] = flags;
+  if ((jb->incl_offsets && !jb->incl_nodes && jb->incl_offsets[J]) || (jb->excl_offsets && !jb->excl_nodes && jb->excl_offsets[J]))
+    return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: include / exclude offsets without node lists");
+  auto raw = [&](DevBuf& d, const void* src, size_t bytes) -> int {
+    HIPCHK(h, d.ensure(bytes));
+    if (src && bytes) HIPCHK(h, hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream));
+    return 0;
+  };
+  DevBuf* rb_ = h->d_raw;  // 0 L, 1 ncpu, 2 nmem, 3 tcpu, 4 tmem, 5 k, 6 ntasks, 7 tmin, 8 tmax, 9 excl, 10 gtot, 11 gspec, 12 incl_off,
+                           // 13 excl_off, 14 place_off, 15 grouped
+  if (int rc = raw(rb_[0], jb->time_limit_sec, J * 8)) return rc;
+  if (jb->node_cpu_raw) { if (int rc = raw(rb_[1], jb->node_cpu_raw, J * 8)) return rc; }
+  if (int rc = raw(rb_[2], jb->node_mem, J * 8)) return rc;
+  if (int rc = raw(rb_[3], jb->task_cpu_raw, J * 8)) return rc;
+  if (int rc = raw(rb_[4], jb->task_mem, J * 8)) return rc;
+  if (int rc = raw(rb_[5], jb->node_num, J * 4)) return rc;
+  if (int rc = raw(rb_[6], jb->ntasks, J * 4)) return rc;
+  if (int rc = raw(rb_[7], jb->ntasks_per_node_min, J * 4)) return rc;
+  if (int rc = raw(rb_[8], jb->ntasks_per_node_max, J * 4)) return rc;
+  if (jb->exclusive) { if (int rc = raw(rb_[9], jb->exclusive, J)) return rc; }
+  if (jb->gres_total) { if (int rc = raw(rb_[10], jb->gres_total, J * CNS_MAX_GRES_NAMES)) return rc; }
+  if (jb->gres_spec) { if (int rc = raw(rb_[11], jb->gres_spec, J * CNS_MAX_GRES_CLASSES)) return rc; }
+  if (jb->incl_offsets) { if (int rc = raw(rb_[12], jb->incl_offsets, (J + 1) * 8)) return rc; }
+  if (jb->excl_offsets) { if (int rc = raw(rb_[13], jb->excl_offsets, (J + 1) * 8)) return rc; }
+  if (int rc = raw(rb_[14], h->place_off.data(), (J + 1) * 8)) return rc;
+  if (int rc = upload(h, rb_[15], grouped)) return rc;
+  const u64 n_incl = jb->incl_offsets ? jb->incl_offsets[J] : 0, n_excl = jb->excl_offsets ? jb->excl_offsets[J] : 0;
+  HIPCHK(h, h->d_incl.ensure(std::max<u64>(n_incl, 1) * 4));
+  HIPCHK(h, h->d_excl.ensure(std::max<u64>(n_excl, 1) * 4));
+  if (int rc = raw(h->d_incl, jb->incl_nodes, n_incl * 4)) return rc;
+  if (int rc = raw(h->d_excl, jb->excl_nodes, n_excl * 4)) return rc;
+  HIPCHK(h, h->d_jobs.ensure((size_t)std::max<u64>(Jg, 1) * kJobRecDwords * 4));
+  if (Jg) {
+    PackParams K{};
+    K.Jg = Jg; K.grouped = rb_[15].as<u32>();
+    K.L = rb_[0].as<i64>(); K.ncpu = jb->node_cpu_raw ? rb_[1].as<i64>() : nullptr; K.nmem = rb_[2].as<u64>();
+    K.tcpu = rb_[3].as<i64>(); K.tmem = rb_[4].as<u64>(); K.k = rb_[5].as<u32>(); K.ntasks = rb_[6].as<u32>();
+    K.tmin = rb_[7].as<u32>(); K.tmax = rb_[8].as<u32>();
+    K.excl = jb->exclusive ? rb_[9].as<uint8_t>() : nullptr;
+    K.gtot = jb->gres_total ? rb_[10].as<uint8_t>() : nullptr; K.gspec = jb->gres_spec ? rb_[11].as<uint8_t>() : nullptr;
+    K.incl_off = jb->incl_offsets ? rb_[12].as<u64>() : nullptr; K.excl_off = jb->excl_offsets ? rb_[13].as<u64>() : nullptr;
+    K.place_off = rb_[14].as<u64>(); K.jobrec = h->d_jobs.as<u32>();
+    hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)((Jg + 255) / 256)), dim3(256), 0, h->stream, K);
+    HIPCHK(h, hipGetLastError());
   }
-  if (incl.empty()) incl.push_back(0);
-  if (excl.empty()) excl.push_back(0);
 
   if (int rc = upload(h, h->d_pj_off, pj_off)) return rc;
-  if (int rc = upload(h, h->d_jobs, stage)) return rc;
-  if (int rc = upload(h, h->d_incl, incl)) return rc;
-  if (int rc = upload(h, h->d_excl, excl)) return rc;
   if (int rc = upload(h, h->d_reason_init, reason)) return rc;
   // results: one contiguous HBM buffer (also what an RCCL allgather ships)
   cns_engine::ResOff& r = h->ro;

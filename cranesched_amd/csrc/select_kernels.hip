@@ -319,6 +319,48 @@ enum JobRecField : u32 {
   kJdGneed = 42,  // its count | the total << 8, both saturated at 15
   kJdTyok = 44    // u64: bit t = the minimum view fits res_total of node type t (:6171-6175, :6222-6223)
 };
+// ---------------------------------------------------------------------------------------------
+// k_pack_jobs: the caller's job SoA (uploaded as it is) -> dwords 0..29 of the 64-dword job records, grouped by
+// partition in queue order (`grouped[i]` = caller index of the i-th grouped job; the grouping itself is a counting
+// pass over one u32 per job on the host).  One thread per job; replaces a 256-byte-per-job staging loop on the host.
+// ---------------------------------------------------------------------------------------------
+struct PackParams {
+  u64 Jg;
+  const u32* grouped;
+  const i64* L; const i64* ncpu; const u64* nmem; const i64* tcpu; const u64* tmem;
+  const u32* k; const u32* ntasks; const u32* tmin; const u32* tmax;
+  const uint8_t* excl; const uint8_t* gtot; const uint8_t* gspec;
+  const u64* incl_off; const u64* excl_off; const u64* place_off;
+  u32* jobrec;
+};
+__global__ __launch_bounds__(256) void k_pack_jobs(const PackParams P) {
+  const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
+  if (i >= P.Jg) return;
+  const u64 j = P.grouped[i];
+  u32* rec = P.jobrec + i * kJobRecDwords;
+  auto put64 = [&](u32 f, u64 v) { rec[f] = (u32)v; rec[f + 1] = (u32)(v >> 32); };
+  u32 flags = 0, gt = 0;
+  u64 gs = 0;
+  if (P.gtot) { const uint8_t* g = P.gtot + j * 4; gt = g[0] | (u32)g[1] << 8 | (u32)g[2] << 16 | (u32)g[3] << 24; }
+  if (P.gspec) { const uint8_t* g = P.gspec + j * 8; for (u32 c = 0; c < 8; ++c) gs |= (u64)g[c] << (8 * c); }
+  if (gt | gs) flags |= kJfGres;
+  if (P.excl && P.excl[j]) flags |= kJfExclusive;
+  u64 ib = 0, ie = 0, eb = 0, ee = 0;
+  if (P.incl_off) { ib = P.incl_off[j]; ie = P.incl_off[j + 1]; if (ie > ib) flags |= kJfIncl; else ie = ib; }
+  if (P.excl_off) { eb = P.excl_off[j]; ee = P.excl_off[j + 1]; if (ee > eb) flags |= kJfExcl; else ee = eb; }
+  put64(kJrL, (u64)P.L[j]);
+  put64(kJrNcpu, (u64)(P.ncpu ? P.ncpu[j] : 0));
+  put64(kJrNmem, P.nmem[j]);
+  put64(kJrTcpu, (u64)P.tcpu[j]);
+  put64(kJrTmem, P.tmem[j]);
+  put64(kJrGspec, gs);
+  rec[kJrK] = P.k[j]; rec[kJrNtasks] = P.ntasks[j]; rec[kJrTmin] = P.tmin[j]; rec[kJrTmax] = P.tmax[j];
+  rec[kJrFlags] = flags; rec[kJrGtot] = gt; rec[kJrOrig] = (u32)j; rec[19] = 0;
+  put64(kJrPoff, P.place_off[j]);
+  put64(kJrInclB, ib); put64(kJrInclE, ie); put64(kJrExclB, eb); put64(kJrExclE, ee);
+  rec[30] = 0; rec[31] = 0;
+}
+
 __device__ __forceinline__ u32 fetch_job(const KParams& P, u64 ji) {
   return P.jobrec[ji * kJobRecDwords + (threadIdx.x & (kJobRecDwords - 1))];
 }
