@@ -39,6 +39,25 @@ def _resv_case(seed):
 RESV_CASES = {"resv_1": lambda: _resv_case(1), "resv_4": lambda: _resv_case(4)}
 
 
+# run-limit admission (tests/test_run_limits.py::random_limit_case): reasons + usage tables of the oracle's pass
+def _limit_case(seed, tight):
+    from tests import test_run_limits
+    return test_run_limits.random_limit_case(seed, J=700, N=96, tight=tight)
+
+
+LIMIT_CASES = {"limits_2": lambda: _limit_case(2, True), "limits_6": lambda: _limit_case(6, False)}
+
+
+def limit_outputs(case):
+    cluster, jobs, now, lay, t, lj = case
+    sel = pyoracle.select(cluster, jobs, now)
+    reason, adm, usage = pyoracle.run_limits(lay, t, lj, sel.placements)
+    out = {"reason": reason, "admitted": np.array([adm], np.uint64)}
+    for f in usage.__dataclass_fields__:
+        out[f] = getattr(usage, f).view(np.uint8)
+    return out
+
+
 def main():
     for name, make in CASES.items():
         c, j, now, run = make()
@@ -56,6 +75,10 @@ def main():
         t = r.placements.trimmed()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), costs=r.costs().view(np.uint64), **t)
         print(name, j.num_jobs, "jobs", np.bincount(t["reason"], minlength=7))
+    for name, make in LIMIT_CASES.items():
+        out = limit_outputs(make())
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, len(out["reason"]), "jobs", int(out["admitted"][0]), "admitted")
 
 
 if __name__ == "__main__":

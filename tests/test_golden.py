@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
-from tests.golden.make_golden import CASES, HERE, RESV_CASES
+from tests.golden.make_golden import CASES, HERE, LIMIT_CASES, RESV_CASES, limit_outputs
 
 
 def load(name):
@@ -32,3 +32,11 @@ def test_oracle_matches_golden_reservations(name):
     c, j, now, run, rv = RESV_CASES[name]()
     r = pyoracle.select(c, j, now, running=run, reservations=rv)
     compare(name, r.placements, r.costs())
+
+
+@pytest.mark.parametrize("name", sorted(LIMIT_CASES))
+def test_oracle_matches_golden_run_limits(name):
+    out = limit_outputs(LIMIT_CASES[name]())
+    g = load(name)
+    for k, v in out.items():
+        assert np.array_equal(g[k], v), f"{name}: {k} differs from the golden fixture"
