@@ -703,25 +703,28 @@ __device__ __noinline__ i64 next_fit_wave(const TlEntry* T, u32 len, const Res* 
 // Same question for ONE node whose map sits in registers (lane i = entry i, len <= 64), answered with
 // a ballot of "alloc fits entry i" and bit scans over its runs.
 __device__ __forceinline__ i64 next_fit_regs(const TlEntry& e, u32 len, const Res& alloc, i64 L, i64 t0, u32 lane) {
+  // EarliestStartSubsetSelector on one node (JobScheduler.h:792-865) without its walk: every lane decides for ITS
+  // entry whether a run of satisfied entries starts there (the entry covering t0 counts with start t0) and whether
+  // that run lasts L — the end of the run is the first unsatisfied entry above it, fetched across lanes in one
+  // ds_bpermute — and the lowest such lane wins.  (The walk over the runs cost ~150 cycles per run on the worker's
+  // serial chain: 4.9 k cycles per backfilled job on C4's deep time maps.)
   const bool act = lane < len;
   const u64 valid = len >= 64 ? ~0ull : ((1ull << len) - 1ull);
   const u64 sat = __ballot(act && res_le(alloc, e.r));
-  u32 idx = (u32)__popcll(__ballot(act && e.t <= t0)) - 1u;  // entry covering t0 (T[0].t = now <= t0)
-  i64 s = t0;
-  while (true) {
-    if (!((sat >> idx) & 1ull)) {  // not satisfied here: jump to the start of the next satisfied run
-      const u64 above = idx >= 63 ? 0ull : (sat & ~((2ull << idx) - 1ull));
-      if (above == 0) return kInf;
-      idx = (u32)__builtin_ctzll(above);
-      s = (i64)rl64((u64)e.t, idx);
-    }
-    const u64 unsat = idx >= 63 ? 0ull : (~sat & valid & ~((2ull << idx) - 1ull));
-    if (unsat == 0) return s;  // satisfied through the last entry
-    const u32 ue = (u32)__builtin_ctzll(unsat);
-    const i64 endt = (i64)rl64((u64)e.t, ue);
-    if (endt - s >= L) return s;
-    idx = ue;
-  }
+  const u32 idx0 = (u32)__popcll(__ballot(act && e.t <= t0)) - 1u;  // entry covering t0 (T[0].t = now <= t0)
+  const u64 unsat = ~sat & valid;
+  const bool here = ((sat >> lane) & 1ull) != 0;
+  const bool below = lane > 0 && ((sat >> (lane - 1u)) & 1ull) != 0;
+  const bool starts = here && (lane == idx0 || (lane > idx0 && !below));
+  const i64 s = lane == idx0 ? t0 : e.t;
+  const u64 above = lane >= 63 ? 0ull : (unsat & ~((2ull << lane) - 1ull));
+  const u32 ue = above ? (u32)__builtin_ctzll(above) : lane;
+  const u32 elo = (u32)__shfl((int)(u32)(u64)e.t, (int)ue), ehi = (u32)__shfl((int)(u32)((u64)e.t >> 32), (int)ue);
+  const i64 endt = (i64)(((u64)ehi << 32) | elo);
+  const u64 ok = __ballot(starts && (above == 0 || endt - s >= L));
+  if (!ok) return kInf;
+  const u32 w = (u32)__builtin_ctzll(ok);
+  return w == idx0 ? t0 : (i64)rl64((u64)e.t, w);
 }
 
 // Shared by the "start now" and "backfill" endings of the general path: H[0..k) holds the selected
@@ -1593,7 +1596,11 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           // :6274 only needs the truth value of GetFeasibleResourceInNode(res_avail): counts suffice
           if (feasible_counts(F.mv, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
                               class_counts(h.avail0.gres, P.gres), P.gres)) {
+            PROF_T(a1w);
             m = uni_res(window_min_regs(e, lane < h.len, h.avail0, F.E));   // :6278-6283
+            PROF_T(a1x);
+            PROF_ADD(22, a1, a1w);   // phase A: count pre-check
+            PROF_ADD(23, a1w, a1x);  // phase A: window-min
             ok = feasible(F.mv, m, f, P.gres);                             // get_max_tasks(min_res) > 0, :6285
           }
           PROF_T(a2);
@@ -1627,10 +1634,14 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           on.code = kNone;
           have_on = false;
           NodeHdr* hd = nullptr; NodeHdr h; TlEntry e;
+          i64 first_resv = kInf;
           if (tcode != kNone) {
+            if (!resv_part) first_resv = P.first_resv[qbeg + slot_of_code(tcode)];  // in flight with the block
             load_block(P, qbeg + slot_of_code(tcode), lane, hd, h, e);
             if (h.len > 64) divert = true;
           }
+          PROF_T(b0l);
+          PROF_ADD(8, b0, b0l);  // phase B: node block load
           if (!divert) {
             if (tcode != kNone) {
               const u32 q = qbeg + slot_of_code(tcode);
@@ -1638,7 +1649,11 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               if (!feasible(F.mv, h.total, alloc, P.gres)) {  // :6354-6356
                 if (lane == 0) set_fault(P, 3, F.orig, h.node, 0);
               }
+              PROF_T(b0f);
+              PROF_ADD(16, b0l, b0f);  // phase B: allocation against res_total
               const i64 st = next_fit_regs(e, h.len, alloc, F.L, P.now, lane);
+              PROF_T(b0n);
+              PROF_ADD(9, b0l, b0n);  // phase B: allocation against res_total + next fit
               // the node as the scanners see it if nothing is committed
               const Res e0 = rl_res(e.r, 0);
               cn.code = tcode; cn.cost = tc; cn.len = h.len; cn.type = h.type;
@@ -1646,11 +1661,14 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               if (st != kInf && st - P.now <= P.max_window) {          // kAlgoMaxTimeWindow, JobScheduler.h:815
                 int reason = 0;
                 if (st != P.now) {  // :6797-6831
-                  if (!resv_part && P.first_resv[q] < P.now + F.L) reason = 3;  // "Resource Reserved" (:6799-6806)
+                  if (!resv_part && first_resv < P.now + F.L) reason = 3;  // "Resource Reserved" (:6799-6806)
                   else reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;
                 }
+                PROF_T(b0c);
                 commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, __longlong_as_double((long long)tc),
                                    alloc, st, reason, lane, s_upd, &s_nupd, cn);
+                PROF_T(b0d);
+                PROF_ADD(10, b0c, b0d);  // phase B: commit
                 code = 2;
               }
             }
