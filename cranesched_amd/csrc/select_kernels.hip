@@ -894,6 +894,10 @@ __device__ __noinline__ bool distribute_and_alloc(const KParams& P, const JobCtx
 //   A == none  -> phase B: cur = T;  while cur != none and < k nodes: S: next T argmin  B1 (+B2 if ntasks>k)
 //                 W: allocations vs res_total, earliest start, commit -> verdict       B3
 // ---------------------------------------------------------------------------------------------
+struct AllocCacheEnt {  // (request shape, node type) -> allocation against res_total
+  i64 cpu; u64 gspec; u32 gtot; u32 type; u64 clo, chi, gres;
+};
+constexpr int kAllocCache = 256;
 struct WorkerShared {
   u64 (*wc)[kRed];
   u32 (*wp)[kRed];
@@ -1324,7 +1328,7 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const GresDev
     load_block(P, q, lane, hd, h, e);
     bool ok = false;
     if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                        class_counts(h.avail0.gres, G), G)) {                          // :6274
+                        (J.flags & kJfGres) ? class_counts(h.avail0.gres, G) : 0ull, G)) {  // :6274
       const Res m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
                                         : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));    // :6278-6283
       ok = feasible(J.min_view, m, f, G);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
@@ -1507,6 +1511,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
   __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
   __shared__ GresDev s_gres;  // LDS copy of the GRES layout for the out-of-line helpers (their parameter block is read with FLAT loads: from LDS the table lookups of the exact test are ~10x closer than from HBM)
+  // Worker-private cache of GetFeasibleResourceInNode(request, res_total) (:6354-6356): the allocation of a backfilled
+  // job depends only on (cpu, GRES request, node type); computing it cost 4.1 k cycles of the serial chain per job.
+  __shared__ AllocCacheEnt s_ac[kAllocCache];
   __shared__ u32 s_nme[kMaxNames], s_nmo[kMaxNames];  // GRES name masks in the split-nibble domain (even / odd nibbles as bytes)
 
   const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();  // lane t holds node type t
@@ -1528,6 +1535,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     s_ty_m16[lane] = mem_gib16(mem_mib_ceil(ttot.mem));
     s_ty_gn[lane] = nibbles_of(tyl.cnt);
     if (lane == 0) s_gres = P.gres;
+    for (u32 x = lane; x < (u32)kAllocCache; x += 64) s_ac[x].type = kNone;
     if (lane < (u32)kMaxNames) {
       const u32 nb = nibbles_of(P.gres.name_bytes[lane] & 0x0F0F0F0F0F0F0F0Full);  // nibble g = 0xF if class g is in the name
       s_nme[lane] = nb & 0x0F0F0F0Fu;
@@ -1595,7 +1603,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           bool ok = false;
           // :6274 only needs the truth value of GetFeasibleResourceInNode(res_avail): counts suffice
           if (feasible_counts(F.mv, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                              class_counts(h.avail0.gres, P.gres), P.gres)) {
+                              (F.flags & kJfGres) ? class_counts(h.avail0.gres, P.gres) : 0ull, P.gres)) {  // counts only read for GRES requests
             PROF_T(a1w);
             m = uni_res(window_min_regs(e, lane < h.len, h.avail0, F.E));   // :6278-6283
             PROF_T(a1x);
@@ -1646,8 +1654,24 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             if (tcode != kNone) {
               const u32 q = qbeg + slot_of_code(tcode);
               Res alloc = res_zero();
-              if (!feasible(F.mv, h.total, alloc, P.gres)) {  // :6354-6356
-                if (lane == 0) set_fault(P, 3, F.orig, h.node, 0);
+              {
+                u32 hs = (u32)F.mv.cpu * 0x9E3779B1u ^ (u32)(F.mv.gspec * 0x85EBCA6B5BD1E995ull >> 29) ^ F.mv.gtot * 0xC2B2AE35u ^ h.type * 0x27D4EB2Fu;
+                hs = (hs ^ (hs >> 15)) & (kAllocCache - 1);
+                const AllocCacheEnt c = s_ac[hs];
+                const bool hit = uni32((c.type == h.type && c.cpu == F.mv.cpu && c.gspec == F.mv.gspec && c.gtot == F.mv.gtot) ? 1u : 0u) != 0;
+                if (hit) {
+                  alloc.cpu = F.mv.cpu; alloc.mem = F.mv.mem;
+                  alloc.clo = uni64(c.clo); alloc.chi = uni64(c.chi); alloc.gres = uni64(c.gres);
+                } else {
+                  if (!feasible(F.mv, h.total, alloc, P.gres)) {  // :6354-6356; cannot fail: the T argmin only ranks nodes whose res_total fits
+                    if (lane == 0) set_fault(P, 3, F.orig, h.node, 0);
+                  } else if (lane == 0) {
+                    AllocCacheEnt w;
+                    w.cpu = F.mv.cpu; w.gspec = F.mv.gspec; w.gtot = F.mv.gtot; w.type = h.type;
+                    w.clo = alloc.clo; w.chi = alloc.chi; w.gres = alloc.gres;
+                    s_ac[hs] = w;
+                  }
+                }
               }
               PROF_T(b0f);
               PROF_ADD(16, b0l, b0f);  // phase B: allocation against res_total
