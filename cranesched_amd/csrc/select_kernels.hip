@@ -1326,12 +1326,14 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const GresDev
     cost0 = H[i].cost;
     q = qbeg + slot_of_code(p);
     load_block(P, q, lane, hd, h, e);
-    bool ok = false;
-    if (feasible_counts(J.min_view, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                        (J.flags & kJfGres) ? class_counts(h.avail0.gres, G) : 0ull, G)) {  // :6274
-      const Res m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
-                                        : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));    // :6278-6283
-      ok = feasible(J.min_view, m, f, G);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
+    // :6285 first; it implies :6274 except for the core-id count of res_avail (see the single-node fast path)
+    const Res m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
+                                      : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));    // :6278-6283
+    bool ok = feasible(J.min_view, m, f, G);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
+    if (ok) {
+      const i64 req_int = J.min_view.cpu / 256;
+      const u32 nc0 = (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi));
+      if (req_int * 256 == J.min_view.cpu && nc0 != 0 && nc0 < (u32)req_int) ok = false;   // :528-534 on res_avail
     }
     if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
   }
@@ -1601,15 +1603,20 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_ADD(1, a0, a1);  // node block load
           Res f, m;
           bool ok = false;
-          // :6274 only needs the truth value of GetFeasibleResourceInNode(res_avail): counts suffice
-          if (feasible_counts(F.mv, h.avail0.cpu, h.avail0.mem, (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi)),
-                              (F.flags & kJfGres) ? class_counts(h.avail0.gres, P.gres) : 0ull, P.gres)) {  // counts only read for GRES requests
-            PROF_T(a1w);
-            m = uni_res(window_min_regs(e, lane < h.len, h.avail0, F.E));   // :6278-6283
-            PROF_T(a1x);
-            PROF_ADD(22, a1, a1w);   // phase A: count pre-check
-            PROF_ADD(23, a1w, a1x);  // phase A: window-min
-            ok = feasible(F.mv, m, f, P.gres);                             // get_max_tasks(min_res) > 0, :6285
+          // :6274 wants GetFeasibleResourceInNode(res_avail) to succeed, :6285 the same on the window minimum m.
+          // m is res_avail folded with Ckmin (:6278-6283): cpu and mem are minima, GRES slots and (when non-empty)
+          // core ids are subsets.  So success on m implies the cpu, mem and GRES tests of :6274; the one test of
+          // :6274 that m does not imply is the core-id count of res_avail (:534) when m's core set came out empty.
+          PROF_T(a1w);
+          m = uni_res(window_min_regs(e, lane < h.len, h.avail0, F.E));   // :6278-6283
+          PROF_T(a1x);
+          PROF_ADD(22, a1, a1w);   // phase A: (nothing left before the window-min)
+          PROF_ADD(23, a1w, a1x);  // phase A: window-min
+          ok = feasible(F.mv, m, f, P.gres);                             // get_max_tasks(min_res) > 0, :6285
+          if (ok) {
+            const i64 req_int = F.mv.cpu / 256;
+            const u32 nc0 = (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi));
+            if (req_int * 256 == F.mv.cpu && nc0 != 0 && nc0 < (u32)req_int) ok = false;   // :528-534 on res_avail
           }
           PROF_T(a2);
           PROF_ADD(2, a1, a2);  // window-min + feasibility

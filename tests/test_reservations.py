@@ -231,3 +231,36 @@ def test_gpu_reservation_argument_checks(engine_cls):
         assert got.reason[:2].tolist() == [0, 0] and sorted(got.node_idx[:2].tolist()) == [0, 1]
     finally:
         eng.close()
+
+
+def core_id_shortfall_case():
+    """res_avail with FEWER core ids than cpus (cpu_total 4, core ids {0,1}: the node table does not force them to
+    agree) and two future dips whose core sets are disjoint, so the window minimum of a long job has an EMPTY core set:
+    GetFeasibleResourceInNode succeeds on the window minimum through its count-only branch (PublicHeader.cpp:540) while
+    the test on res_avail (JobScheduler.cpp:6274) fails on the core-id count (:534).  The engine evaluates :6285 first
+    and derives :6274 from it, except for exactly this test."""
+    c = abi.Cluster(np.array([4 * 256], np.int64), np.array([16 * GIB], np.uint64), np.array([0b111], np.uint64),
+                    np.array([0], np.uint64), np.array([0], np.uint64), np.array([0, 1], np.uint32), np.array([0], np.uint32))
+    j = kat.jobs([dict(cpu=3, L=100), dict(cpu=2, L=100), dict(cpu=3, L=5), dict(cpu=0.5, L=100)])
+    # a running job holds core id 2 but only half a cpu; the two reservations take one core id each and a quarter cpu
+    rn = _running([(NOW + 5000, None, [(0, 0.5, 1, 0b100)])])
+    rv = _resv([(NOW + 10, NOW + 20, [(0, 0.25, 1, 0b01)]), (NOW + 30, NOW + 40, [(0, 0.25, 1, 0b10)])])
+    return c, j, rn, rv
+
+
+def test_oracle_core_id_shortfall():
+    c, j, rn, rv = core_id_shortfall_case()
+    ref = pyoracle.select(c, j, NOW, running=rn, reservations=rv)
+    lit = pyoracle.select(c, j, NOW, running=rn, reservations=rv, algebra=pyoracle.LITERAL)
+    assert ref.placements.diff(lit.placements) is None
+    # job 0 (3 cpus, window over both dips): window minimum = 3.25 cpus, no core ids -> count-only success; res_avail has
+    # 2 core ids < 3 -> :6274 rejects the node for "start now" -> the job is placed by the backfill branch instead: its
+    # allocation is the one against res_total (core ids {0,1,2}; `<=` ignores core ids, PublicHeader.cpp:886-890) and it
+    # still starts at `now`.  Had :6285 alone decided, the allocation would carry no core ids at all.
+    assert ref.placements.reason[0] == 0 and ref.placements.start_sec[0] == NOW and ref.placements.core_lo[0] == 0b111
+
+
+@pytest.mark.gpu
+def test_gpu_core_id_shortfall(engine_cls):
+    c, j, rn, rv = core_id_shortfall_case()
+    _gpu_run(engine_cls, c, j, NOW, rn, rv)
