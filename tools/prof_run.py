@@ -20,7 +20,7 @@ jobs = j.num_jobs / c.num_partitions
 print(f"{name} J={j.num_jobs} N={c.num_nodes} P={c.num_partitions}: k_select {t['select_ms']:.1f} ms = "
       f"{1e3*t['select_ms']/jobs:.2f} us/job/partition")
 names = {0: "W wait scanners (B1, no pre-scan)", 7: "W next-job decode + merge",  1: "W node block load", 2: "W window-min+feasible", 3: "W commit(now)",
-         4: "W backfill+commit", 8: "W   B: node block load", 9: "W   B: alloc vs total + next fit", 16: "W     B: alloc vs total", 22: "W   A: count pre-check", 23: "W   A: window-min", 10: "W   B: commit", 5: "W slow-path job", 6: "W multi-node job", 11: "#fast start-now",
+         4: "W backfill+commit", 8: "W   B: node block load", 9: "W   B: alloc vs total + next fit", 16: "W     B: alloc vs total", 22: "W   A: before the window-min (counter latency only)", 23: "W   A: window-min", 10: "W   B: commit", 5: "W slow-path job", 6: "W multi-node job", 11: "#fast start-now",
          12: "#fast backfill", 13: "#slow jobs", 14: "#rejected candidates", 15: "#multi-node jobs", 24: "W multi: job record -> LDS", 25: "W multi: start-now lists + merge", 26: "W multi: helpers verify + commit", 28: "W multi: res_total lists + merge", 29: "W multi: common start + commit", 30: "#multi start-now", 31: "#multi backfill", 17: "S scan/mask completion (+B1)", 18: "S next-job prep+pre-scan",
          19: "S wait verdict", 20: "S owner update", 21: "S wait worker merge (B1')"}
 m = pr.mean(axis=0)
