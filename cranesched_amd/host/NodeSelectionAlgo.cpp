@@ -5,7 +5,9 @@
 #include "NodeSelectionAlgo.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstring>
+#include <iterator>
 
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/priority.h"
@@ -32,6 +34,97 @@ struct GpuNodeSelectionAlgo::Impl {
   cns_gres_layout layout{};
   bool have_snapshot = false;
   std::unordered_map<const PdJobInScheduler*, uint64_t> last_index;  // job -> its index in the last cns_select
+  // Incremental packing of the running jobs: an allocation never changes while its job runs, so its
+  // dense form (node indices, core / GRES masks) is kept per job id across cycles; a cycle costs one lookup per
+  // running job instead of one string lookup + set -> mask conversion per allocated node.  Entries of jobs that did
+  // not show up in a cycle are dropped; a new snapshot (new dense indices) drops everything.
+  struct AllocRec { uint32_t node; int64_t cpu; uint64_t mem, lo, hi, g; };
+  struct PackedAlloc {
+    uint32_t resv;
+    uint64_t gen;
+    std::vector<AllocRec> recs;
+  };
+  // the packed node table / reservations of the current snapshot, kept so that a state flip of one craned
+  // (CranedUp / CranedDown / drain) re-sends them without touching a string
+  std::vector<int64_t> n_cpu, v_start, v_end, v_cpu;
+  std::vector<uint64_t> n_mem, n_lo, n_hi, n_gres, v_mem, v_lo, v_hi, v_g;
+  std::vector<uint8_t> n_sched;
+  std::vector<uint32_t> n_poff, n_pnodes, v_off, v_node;
+  int push_tables(std::string& err) {   // cns_set_nodes + cns_set_reservations from the packed arrays
+    cns_node_soa nd{};
+    nd.num_nodes = (uint32_t)n_cpu.size();
+    nd.num_partitions = (uint32_t)n_poff.size() - 1;
+    nd.cpu_total_raw = n_cpu.data(); nd.mem_total = n_mem.data(); nd.core_lo = n_lo.data(); nd.core_hi = n_hi.data();
+    nd.gres_slots = n_gres.data(); nd.schedulable = n_sched.data();
+    nd.part_offsets = n_poff.data(); nd.part_nodes = n_pnodes.data();
+    nd.gres = layout;
+    int st = cns_set_nodes(h, &nd);
+    if (st != 0) { err = cns_last_error(h); return st; }
+    if (!v_start.empty()) {
+      cns_resv_soa rv{};
+      rv.num_resv = (uint32_t)v_start.size(); rv.num_allocs = (uint32_t)v_node.size();
+      rv.start_sec = v_start.data(); rv.end_sec = v_end.data(); rv.alloc_offsets = v_off.data(); rv.alloc_node = v_node.data();
+      rv.alloc_cpu_raw = v_cpu.data(); rv.alloc_mem = v_mem.data(); rv.alloc_core_lo = v_lo.data(); rv.alloc_core_hi = v_hi.data();
+      rv.alloc_gres = v_g.data();
+      st = cns_set_reservations(h, &rv);
+      if (st != 0) { err = cns_last_error(h); return st; }
+    }
+    return 0;
+  }
+  std::unordered_map<job_id_t, PackedAlloc> alloc_cache;
+  uint64_t alloc_gen = 0;
+  bool use_alloc_cache = true;
+  std::vector<int64_t> r_end, r_cpu;
+  std::vector<uint32_t> r_off, r_node, r_resv;
+  std::vector<uint64_t> r_mem, r_lo, r_hi, r_g;
+
+  // running jobs -> cns_running_soa arrays (JobScheduler.cpp:6681-6709); order = the caller's vector
+  void pack_running(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
+    r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
+    r_off.assign(1, 0);
+    ++alloc_gen;
+    PackedAlloc scratch;
+    for (const auto& rn : running_jobs) {
+      uint32_t rv = CNS_RESV_NONE;
+      if (!rn->reservation.empty()) {  // allocated inside the reservation's own node states (cpp:6692-6707)
+        auto it = resv_idx.find(rn->reservation);
+        if (it == resv_idx.end()) continue;
+        rv = it->second;
+      }
+      PackedAlloc* pa = nullptr;
+      if (use_alloc_cache) {
+        auto it = alloc_cache.find(rn->job_id);
+        if (it != alloc_cache.end() && it->second.resv == rv) pa = &it->second;
+      }
+      if (!pa) {
+        PackedAlloc& d = use_alloc_cache ? alloc_cache[rn->job_id] : scratch;
+        d.resv = rv;
+        d.recs.clear();
+        for (const auto& [cid, res] : rn->allocated_res) {
+          auto it = node_idx.find(cid);
+          if (it == node_idx.end()) continue;
+          AllocRec a;
+          a.node = it->second;
+          a.cpu = res.cpu_set.cpu_count.raw;
+          a.mem = res.memory_bytes;
+          core_masks(res.cpu_set.core_ids, a.lo, a.hi);
+          a.g = gres_mask(res.gres);
+          d.recs.push_back(a);
+        }
+        pa = &d;
+      }
+      pa->gen = alloc_gen;
+      r_resv.push_back(rv);
+      r_end.push_back(rn->end_time);
+      for (const AllocRec& a : pa->recs) {
+        r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
+        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g);
+      }
+      r_off.push_back((uint32_t)r_node.size());
+    }
+    if (use_alloc_cache && alloc_cache.size() > r_end.size())  // jobs that ended since the last cycle
+      for (auto it = alloc_cache.begin(); it != alloc_cache.end();) it = it->second.gen != alloc_gen ? alloc_cache.erase(it) : std::next(it);
+  }
 
   int class_of(const std::string& name, const std::string& type) const {
     for (size_t c = 0; c < classes.size(); ++c)
@@ -85,6 +178,36 @@ GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(int device, uint64_t scheduled_batch_
   if (status_ != 0) error_ = cns_last_error(nullptr);
 }
 
+void GpuNodeSelectionAlgo::SetCranedState(const CranedId& craned_id, bool alive, bool drain) {
+  Impl& I = *impl_;
+  auto it = I.node_idx.find(craned_id);
+  if (!I.have_snapshot || it == I.node_idx.end()) { status_ = CNS_ERR_INVALID_ARG; error_ = "SetCranedState: unknown craned or no snapshot"; return; }
+  const uint8_t s = alive && !drain;   // JobScheduler.cpp:6595
+  if (I.n_sched[it->second] == s) return;
+  I.n_sched[it->second] = s;
+  status_ = I.push_tables(error_);     // the packed tables again, no string is looked at; dense indices stay valid
+  if (status_ == 0) error_.clear();
+}
+
+size_t GpuNodeSelectionAlgo::PackRunningForBench(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
+                                                 bool use_cache, uint64_t* checksum, double* pack_ms) {
+  Impl& I = *impl_;
+  I.use_alloc_cache = use_cache;
+  const auto t0 = std::chrono::steady_clock::now();
+  I.pack_running(running_jobs);
+  if (pack_ms) *pack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  I.use_alloc_cache = true;
+  if (checksum) {  // FNV-1a over everything cns_set_running would receive
+    uint64_t hsh = 1469598103934665603ull;
+    auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ull; } };
+    mix(I.r_end.data(), I.r_end.size() * 8); mix(I.r_off.data(), I.r_off.size() * 4); mix(I.r_node.data(), I.r_node.size() * 4);
+    mix(I.r_cpu.data(), I.r_cpu.size() * 8); mix(I.r_mem.data(), I.r_mem.size() * 8); mix(I.r_lo.data(), I.r_lo.size() * 8);
+    mix(I.r_hi.data(), I.r_hi.size() * 8); mix(I.r_g.data(), I.r_g.size() * 8); mix(I.r_resv.data(), I.r_resv.size() * 4);
+    *checksum = hsh;
+  }
+  return I.r_node.size();
+}
+
 GpuNodeSelectionAlgo::~GpuNodeSelectionAlgo() {
   if (impl_ && impl_->h) cns_destroy(impl_->h);
 }
@@ -92,7 +215,7 @@ GpuNodeSelectionAlgo::~GpuNodeSelectionAlgo() {
 void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   Impl& I = *impl_;
   I.have_snapshot = false;
-  if (!I.h) return;
+  I.alloc_cache.clear();   // dense node indices and GRES bit positions are per snapshot
   const uint32_t N = (uint32_t)snap.craned_metas.size();
   I.node_name.clear(); I.node_idx.clear(); I.part_idx.clear();
   I.classes.clear(); I.name_id.clear(); I.class_slot_bit.clear(); I.class_bit_slot.clear();
@@ -127,9 +250,9 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   }
   I.layout.num_classes = (uint32_t)I.classes.size();
 
-  std::vector<int64_t> cpu(N);
-  std::vector<uint64_t> mem(N), lo(N), hi(N), gres(N);
-  std::vector<uint8_t> sched(N);
+  auto &cpu = I.n_cpu; auto &mem = I.n_mem, &lo = I.n_lo, &hi = I.n_hi, &gres = I.n_gres;
+  auto &sched = I.n_sched;
+  cpu.assign(N, 0); mem.assign(N, 0); lo.assign(N, 0); hi.assign(N, 0); gres.assign(N, 0); sched.assign(N, 0);
   for (uint32_t n = 0; n < N; ++n) {
     const CranedMeta& m = snap.craned_metas[n];
     I.node_name.push_back(m.craned_id);
@@ -140,7 +263,8 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     gres[n] = I.gres_mask(m.res_total.gres);
     sched[n] = m.alive && !m.drain;  // JobScheduler.cpp:6595
   }
-  std::vector<uint32_t> poff{0}, pnodes;
+  auto &poff = I.n_poff, &pnodes = I.n_pnodes;
+  poff.assign(1, 0); pnodes.clear();
   for (const auto& [pid, ids] : snap.partitions) {
     I.part_idx[pid] = (uint32_t)poff.size() - 1;
     for (const auto& id : ids) {
@@ -149,47 +273,31 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     }
     poff.push_back((uint32_t)pnodes.size());
   }
-  cns_node_soa nd{};
-  nd.num_nodes = N;
-  nd.num_partitions = (uint32_t)snap.partitions.size();
-  nd.cpu_total_raw = cpu.data(); nd.mem_total = mem.data(); nd.core_lo = lo.data(); nd.core_hi = hi.data();
-  nd.gres_slots = gres.data(); nd.schedulable = sched.data();
-  nd.part_offsets = poff.data(); nd.part_nodes = pnodes.data();
-  nd.gres = I.layout;
-  status_ = cns_set_nodes(I.h, &nd);
-  if (status_ != 0) { error_ = cns_last_error(I.h); return; }
   // ---- reservations (JobScheduler.cpp:6619-6679) ----
   I.resv_idx.clear();
   const uint32_t V = (uint32_t)snap.reservations.size();
-  if (V) {
-    std::vector<int64_t> rs(V), re(V), rcpu;
-    std::vector<uint32_t> roff{0}, rnode;
-    std::vector<uint64_t> rmem, rlo, rhi, rg;
-    for (uint32_t v = 0; v < V; ++v) {
-      const ResvMeta& m = snap.reservations[v];
-      I.resv_idx[m.name] = v;
-      rs[v] = m.start_time; re[v] = m.end_time;
-      for (const auto& [cid, res] : m.res_total) {
-        auto it = I.node_idx.find(cid);
-        if (it == I.node_idx.end()) continue;
-        rnode.push_back(it->second);
-        rcpu.push_back(res.cpu_set.cpu_count.raw);
-        rmem.push_back(res.memory_bytes);
-        uint64_t l, hh;
-        Impl::core_masks(res.cpu_set.core_ids, l, hh);
-        rlo.push_back(l); rhi.push_back(hh);
-        rg.push_back(I.gres_mask(res.gres));
-      }
-      roff.push_back((uint32_t)rnode.size());
+  I.v_start.assign(V, 0); I.v_end.assign(V, 0);
+  I.v_off.assign(1, 0); I.v_node.clear(); I.v_cpu.clear(); I.v_mem.clear(); I.v_lo.clear(); I.v_hi.clear(); I.v_g.clear();
+  for (uint32_t v = 0; v < V; ++v) {
+    const ResvMeta& m = snap.reservations[v];
+    I.resv_idx[m.name] = v;
+    I.v_start[v] = m.start_time; I.v_end[v] = m.end_time;
+    for (const auto& [cid, res] : m.res_total) {
+      auto it = I.node_idx.find(cid);
+      if (it == I.node_idx.end()) continue;
+      I.v_node.push_back(it->second);
+      I.v_cpu.push_back(res.cpu_set.cpu_count.raw);
+      I.v_mem.push_back(res.memory_bytes);
+      uint64_t l, hh;
+      Impl::core_masks(res.cpu_set.core_ids, l, hh);
+      I.v_lo.push_back(l); I.v_hi.push_back(hh);
+      I.v_g.push_back(I.gres_mask(res.gres));
     }
-    cns_resv_soa rv{};
-    rv.num_resv = V; rv.num_allocs = (uint32_t)rnode.size();
-    rv.start_sec = rs.data(); rv.end_sec = re.data(); rv.alloc_offsets = roff.data(); rv.alloc_node = rnode.data();
-    rv.alloc_cpu_raw = rcpu.data(); rv.alloc_mem = rmem.data(); rv.alloc_core_lo = rlo.data(); rv.alloc_core_hi = rhi.data();
-    rv.alloc_gres = rg.data();
-    status_ = cns_set_reservations(I.h, &rv);
-    if (status_ != 0) { error_ = cns_last_error(I.h); return; }
+    I.v_off.push_back((uint32_t)I.v_node.size());
   }
+  if (!I.h) return;   // no device: the dictionaries above still serve PackRunningForBench
+  status_ = I.push_tables(error_);
+  if (status_ != 0) return;
   I.have_snapshot = true;
 }
 
@@ -204,34 +312,11 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   if (!I.h) return fail_all(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
   if (!I.have_snapshot) return fail_all(CNS_ERR_STATE, "NodeSelect before SetClusterSnapshot");
 
-  // ---- running jobs (JobScheduler.cpp:6681-6709); reservations are outside this slice ------------------
-  std::vector<int64_t> r_end;
-  std::vector<uint32_t> r_off{0}, r_node;
-  std::vector<int64_t> r_cpu;
-  std::vector<uint64_t> r_mem, r_lo, r_hi, r_g;
-  std::vector<uint32_t> r_resv;
-  for (const auto& rn : running_jobs) {
-    uint32_t rv = CNS_RESV_NONE;
-    if (!rn->reservation.empty()) {  // allocated inside the reservation's own node states (cpp:6692-6707)
-      auto it = I.resv_idx.find(rn->reservation);
-      if (it == I.resv_idx.end()) continue;
-      rv = it->second;
-    }
-    r_resv.push_back(rv);
-    r_end.push_back(rn->end_time);
-    for (const auto& [cid, res] : rn->allocated_res) {
-      auto it = I.node_idx.find(cid);
-      if (it == I.node_idx.end()) continue;
-      r_node.push_back(it->second);
-      r_cpu.push_back(res.cpu_set.cpu_count.raw);
-      r_mem.push_back(res.memory_bytes);
-      uint64_t lo, hi;
-      Impl::core_masks(res.cpu_set.core_ids, lo, hi);
-      r_lo.push_back(lo); r_hi.push_back(hi);
-      r_g.push_back(I.gres_mask(res.gres));
-    }
-    r_off.push_back((uint32_t)r_node.size());
-  }
+  // ---- running jobs (JobScheduler.cpp:6681-6709), packed incrementally -----------------------------------------
+  I.pack_running(running_jobs);
+  const auto &r_end = I.r_end, &r_cpu = I.r_cpu;
+  const auto &r_off = I.r_off, &r_node = I.r_node, &r_resv = I.r_resv;
+  const auto &r_mem = I.r_mem, &r_lo = I.r_lo, &r_hi = I.r_hi, &r_g = I.r_g;
   cns_running_soa rs{};
   rs.num_jobs = (uint32_t)r_end.size(); rs.num_allocs = (uint32_t)r_node.size();
   rs.end_sec = r_end.data(); rs.alloc_offsets = r_off.data(); rs.alloc_node = r_node.data();

@@ -256,6 +256,12 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // Per-cycle snapshot (the reference re-reads the meta container inside NodeSelect; here the caller
   // hands the snapshot over before the call).
   void SetClusterSnapshot(const ClusterSnapshot& snap);
+  // Incremental form for what changes between cycles without changing the node set (CranedMetaContainer::CranedUp /
+  // CranedDown, CranedMetaContainer.cpp:26-122, and the drain flag): flips the node's "schedulable" bit
+  // (alive && !drain, JobScheduler.cpp:6595) and re-sends the packed tables; the snapshot's dense indices, the
+  // reservation tables and the cached running allocations stay valid.  SetClusterSnapshot is only needed again when
+  // nodes, partitions, res_total or reservations change.
+  void SetCranedState(const CranedId& craned_id, bool alive, bool drain);
   // Optional: the sorter NodeSelect consults first (SchedulerAlgo's ctor argument, JobScheduler.h:247);
   // nullptr = BasicPriority (input order, JobScheduler.h:185-200).  Not owned.
   void SetPrioritySorter(IPrioritySorter* sorter) { sorter_ = sorter; }
@@ -276,6 +282,12 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // GRES names / types no node of the snapshot has are dropped from limits and usage (no job can allocate them).
   void CheckAndMallocMetaResource(AccountMetaSnapshot& meta, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
                                   std::vector<std::string>& results);
+
+  // Measurement / test hook: only the host-side packing of the running jobs (what NodeSelect does before
+  // cns_set_running), with or without the per-job cache; needs no device.  Returns the number of allocation records,
+  // *checksum covers every array cns_set_running would receive, *pack_ms is the packing alone.
+  size_t PackRunningForBench(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs, bool use_cache,
+                             uint64_t* checksum, double* pack_ms = nullptr);
 
   bool Ok() const { return status_ == 0; }
   int LastStatus() const { return status_; }

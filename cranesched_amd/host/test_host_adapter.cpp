@@ -4,7 +4,9 @@
 // known answers of tests/kat.py (scenarios A, B and F).
 //   test_host_adapter            -> needs an MI355X, exit 0 on success
 //   test_host_adapter --no-gpu   -> checks the loud "no device" behaviour instead
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -31,7 +33,65 @@ static std::unique_ptr<PdJobInScheduler> job(job_id_t id, double cpus, int64_t L
   return j;
 }
 
+// Host-side packing of the running jobs with and without the per-job cache; needs no device.
+static int pack_bench(int n_nodes, int n_jobs) {
+  GpuNodeSelectionAlgo algo(0);   // without a GPU the engine handle is missing; the packing does not need it
+  ClusterSnapshot snap;
+  std::vector<CranedId> ids;
+  for (int i = 0; i < n_nodes; ++i) {
+    char name[16];
+    snprintf(name, sizeof name, "cn%05d", i);
+    snap.craned_metas.push_back(node(name, 64, 256));
+    ids.push_back(name);
+  }
+  snap.partitions = {{"CPU", ids}};
+  algo.SetClusterSnapshot(snap);
+  std::vector<std::unique_ptr<RnJobInScheduler>> rj;
+  uint64_t x = 88172645463325252ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  auto mk = [&](job_id_t id) {
+    auto r = std::make_unique<RnJobInScheduler>();
+    r->job_id = id; r->partition_id = "CPU"; r->start_time = 900; r->end_time = 2000 + (int64_t)(rnd() % 5000);
+    const int k = 1 + (int)(rnd() % 4);
+    for (int a = 0; a < k; ++a) {
+      ResourceInNodeV3& res = r->allocated_res[ids[rnd() % ids.size()]];
+      res.cpu_set.cpu_count = cpu_t(8);
+      const uint32_t c0 = (uint32_t)(rnd() % 56);
+      for (uint32_t c = c0; c < c0 + 8; ++c) res.cpu_set.core_ids.insert(c);
+      res.memory_bytes = 16ull << 30;
+    }
+    return r;
+  };
+  for (int j = 0; j < n_jobs; ++j) rj.push_back(mk((job_id_t)(j + 1)));
+  auto timed = [&](bool cache, uint64_t* sum, size_t* recs) {
+    double ms = 0;
+    *recs = algo.PackRunningForBench(rj, cache, sum, &ms);
+    return ms;
+  };
+  uint64_t s0, s1, s2, s3, s4;
+  size_t n0, n1, n2, n3, n4;
+  const double t_full = timed(false, &s0, &n0);     // every cycle from the strings, as the first version did
+  const double t_fill = timed(true, &s1, &n1);      // first cycle with the cache: same work + inserts
+  const double t_warm = timed(true, &s2, &n2);      // steady state
+  // churn: 5 % of the jobs end, as many start
+  const int churn = n_jobs / 20;
+  rj.erase(rj.begin(), rj.begin() + churn);
+  for (int j = 0; j < churn; ++j) rj.push_back(mk((job_id_t)(n_jobs + j + 1)));
+  const double t_churn = timed(true, &s3, &n3);
+  timed(false, &s4, &n4);
+  CHECK(s0 == s1 && s1 == s2 && n0 == n2);
+  CHECK(s3 == s4 && n3 == n4);                      // incremental == from scratch after churn
+  printf("pack-bench: %d nodes, %d running jobs, %zu allocation records\n", n_nodes, n_jobs, n0);
+  printf("  from the strings every cycle : %8.2f ms\n", t_full);
+  printf("  first cycle with the cache   : %8.2f ms\n", t_fill);
+  printf("  steady state (all cached)    : %8.2f ms  (%.1fx)\n", t_warm, t_full / t_warm);
+  printf("  5 %% of the jobs replaced     : %8.2f ms  (%.1fx)\n", t_churn, t_full / t_churn);
+  printf("%s\n", g_fail ? "FAIL" : "ok");
+  return g_fail != 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
   const bool no_gpu = argc > 1 && !strcmp(argv[1], "--no-gpu");
   const TimeSec now = 1000;
   std::vector<std::unique_ptr<RnJobInScheduler>> running;
@@ -69,6 +129,30 @@ int main(int argc, char** argv) {
     }
     CHECK(pd[3]->allocated_res.at("cn0").cpu_set.core_ids == std::set<uint32_t>{1});  // lowest free core id
     CHECK(pd[4]->reason == "Partition Not Found");
+
+    // --- the same queue after cn0 went down (CranedDown) and came back: SetCranedState re-sends the packed tables,
+    // no new snapshot; a node that is not alive is skipped (JobScheduler.cpp:6595) -------------------------------
+    {
+      auto again = [&]() {
+        pd.clear();
+        pd.push_back(job(1, 1, 100)); pd.push_back(job(2, 1, 100)); pd.push_back(job(3, 1, 100));
+        algo.NodeSelect(now, running, pd);
+      };
+      algo.SetCranedState("cn0", /*alive=*/false, /*drain=*/false);
+      CHECK(algo.Ok());
+      again();
+      CHECK(pd[0]->craned_ids[0] == "cn1" && pd[1]->craned_ids[0] == "cn2" && pd[2]->craned_ids[0] == "cn1");
+      algo.SetCranedState("cn0", true, true);   // alive but draining: still skipped
+      again();
+      CHECK(pd[0]->craned_ids[0] == "cn1");
+      algo.SetCranedState("cn0", true, false);
+      again();
+      CHECK(pd[0]->craned_ids[0] == "cn0" && pd[1]->craned_ids[0] == "cn1" && pd[2]->craned_ids[0] == "cn2");
+      algo.SetCranedState("cn9", true, false);  // unknown craned: reported, nothing changes
+      CHECK(!algo.Ok());
+      again();
+      CHECK(algo.Ok() && pd[0]->craned_ids[0] == "cn0");
+    }
 
     // --- scenario B: backfill, reasons ---------------------------------------------------------------------
     snap.craned_metas = {node("cn0", 2, 8)};

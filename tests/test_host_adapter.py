@@ -20,3 +20,10 @@ def test_adapter_without_gpu_is_loud(built):
 def test_adapter_known_answers_on_gpu(built):
     r = subprocess.run([EXE], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_incremental_running_pack_equals_full_pack(built):
+    """the per-job cache of packed running allocations gives byte-identical cns_running_soa arrays, also
+    after jobs ended / started (host-only, no device needed); the printed timings are the measurement."""
+    r = subprocess.run([EXE, "--pack-bench", "2048", "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
