@@ -20,11 +20,13 @@
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/priority.h"
 #include "../../include/crane_gpu/run_limits.h"
+#include "../../include/crane_gpu/steps.h"
 #include <limits>
 #include "engine_params.h"
 #include "select_kernels.hip"  // single translation unit: kernels + their launches (no -fgpu-rdc needed)
 #include "priority_kernels.hip"
 #include "limits_kernels.hip"
+#include "steps_kernels.hip"
 
 using namespace cns;
 
@@ -93,6 +95,7 @@ struct cns_engine {
   u64 prio_bytes = 0;
   // run-limit admission (limits_host.inc)
   DevBuf d_lim[29], d_limpar[17];
+  DevBuf d_step[13];  // step scheduler (steps_host.inc)
   bool lim_have_tables = false, lim_have_jobs = false, lim_have_run = false;
   bool lim_has_upl = false, lim_has_apl = false, lim_has_sel = false, lim_has_skip = false;
   u32 lim_U = 0, lim_UA = 0, lim_A = 0, lim_Q = 0, lim_Pn = 0, lim_base[5] = {0, 0, 0, 0, 0};
@@ -324,6 +327,7 @@ void cns_destroy(cns_handle* h) {
   for (DevBuf& b : h->d_lim) b.release();
   for (DevBuf& b : h->d_raw) b.release();
   for (DevBuf& b : h->d_limpar) b.release();
+  for (DevBuf& b : h->d_step) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -803,5 +807,6 @@ int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint
 
 #include "priority_host.inc"
 #include "limits_host.inc"
+#include "steps_host.inc"
 
 }  // extern "C"

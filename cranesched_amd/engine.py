@@ -31,6 +31,8 @@ ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy",
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
 # ... and include/crane_gpu/run_limits.h
+# ... and include/crane_gpu/steps.h
+STEPS_ABI_SYMBOLS = ("cns_schedule_steps",)
 LIMITS_ABI_SYMBOLS = ("cns_set_run_limits", "cns_apply_run_limits", "cns_upload_limit_jobs", "cns_run_limits_resident",
                       "cns_download_limits", "cns_get_limit_timing", "cns_get_usage")
 
@@ -143,6 +145,17 @@ class GpuNodeSelector:
         u = self._lim_tables.empty_usage()
         self._check(self._L.cns_get_usage(self._h, *u.pointers()))
         return u
+
+    # -- step scheduler (include/crane_gpu/steps.h) ------------------------------------------------
+    def schedule_steps(self, step_jobs, steps):
+        """JobInCtld::SchedulePendingSteps for every job with pending steps (CtldPublicDefs.cpp:2038-2159); after
+        set_nodes (GRES layout).  Returns (StepResults, kernel_ms)."""
+        from . import steps as st
+        out = st.StepResults(step_jobs, steps)
+        cj, cs, co = step_jobs.to_c(), steps.to_c(), out.to_c()
+        ms = C.c_double(0)
+        self._check(self._L.cns_schedule_steps(self._h, C.byref(cj), C.byref(cs), C.byref(co), C.byref(ms)))
+        return out, ms.value
 
     def close(self):
         if self._h:

@@ -9,6 +9,8 @@
 #include "sched_oracle.hpp"
 #include "prio_oracle.hpp"
 #include "limits_oracle.hpp"
+#include "steps_oracle.hpp"
+#include "../include/crane_gpu/steps.h"
 
 using namespace ora;
 
@@ -334,3 +336,74 @@ int ora_run_limits(const cns_gres_layout* gl, const cns_limit_tables* t, const c
 }
 
 }  // extern "C"
+
+// SchedulePendingSteps restatement (steps_oracle.hpp) behind the structs of include/crane_gpu/steps.h.
+template <class Alg>
+static int run_steps(const Alg& alg, const cns_step_job_soa* jb, const cns_step_soa* st, cns_step_result_soa* out) {
+  u64 po = 0, to = 0;
+  for (u32 s = 0; s < st->num_steps; ++s) {
+    out->place_offsets[s] = po; out->task_offsets[s] = to;
+    po += st->node_num[s]; to += st->ntasks[s];
+  }
+  out->place_offsets[st->num_steps] = po; out->task_offsets[st->num_steps] = to;
+  for (u64 i = 0; i < po; ++i) { out->node_idx[i] = CNS_NODE_NONE; out->node_ntasks[i] = 0; out->node_cpu_raw[i] = 0; out->node_mem[i] = 0; out->node_core_lo[i] = 0; out->node_core_hi[i] = 0; out->node_gres[i] = 0; }
+  for (u64 i = 0; i < to; ++i) { out->task_node[i] = CNS_NODE_NONE; out->task_cpu_raw[i] = 0; out->task_mem[i] = 0; out->task_core_lo[i] = 0; out->task_core_hi[i] = 0; out->task_gres[i] = 0; }
+  for (u32 j = 0; j < jb->num_jobs; ++j) {
+    std::vector<u32> nodes;
+    std::vector<typename Alg::Res> avail;
+    for (u32 n = jb->node_offsets[j]; n < jb->node_offsets[j + 1]; ++n) {
+      nodes.push_back(jb->node_idx[n]);
+      MaskRes m;
+      m.cpu = jb->avail_cpu_raw[n]; m.mem = jb->avail_mem[n]; m.clo = jb->avail_core_lo[n];
+      m.chi = jb->avail_core_hi ? jb->avail_core_hi[n] : 0; m.gres = jb->avail_gres ? jb->avail_gres[n] : 0;
+      avail.push_back(alg.from_mask(m));
+    }
+    std::vector<ora::StepReq> steps;
+    for (u32 s = jb->step_offsets[j]; s < jb->step_offsets[j + 1]; ++s) {
+      ora::StepReq r;
+      r.node_view.cpu = st->node_cpu_raw ? st->node_cpu_raw[s] : 0; r.node_view.mem = st->node_mem ? st->node_mem[s] : 0;
+      r.task_view.cpu = st->task_cpu_raw[s]; r.task_view.mem = st->task_mem[s];
+      for (u32 a = 0; a < CNS_MAX_GRES_NAMES; ++a) {
+        r.node_view.gtot[a] = st->node_gres_total ? st->node_gres_total[s * CNS_MAX_GRES_NAMES + a] : 0;
+        r.task_view.gtot[a] = st->task_gres_total ? st->task_gres_total[s * CNS_MAX_GRES_NAMES + a] : 0;
+      }
+      for (u32 g = 0; g < CNS_MAX_GRES_CLASSES; ++g) {
+        r.node_view.gspec[g] = st->node_gres_spec ? st->node_gres_spec[s * CNS_MAX_GRES_CLASSES + g] : 0;
+        r.task_view.gspec[g] = st->task_gres_spec ? st->task_gres_spec[s * CNS_MAX_GRES_CLASSES + g] : 0;
+      }
+      r.node_num = st->node_num[s]; r.ntasks = st->ntasks[s]; r.tmin = st->ntasks_per_node_min[s]; r.tmax = st->ntasks_per_node_max[s];
+      if (st->incl_offsets) r.included.assign(st->incl_nodes + st->incl_offsets[s], st->incl_nodes + st->incl_offsets[s + 1]);
+      if (st->excl_offsets) r.excluded.assign(st->excl_nodes + st->excl_offsets[s], st->excl_nodes + st->excl_offsets[s + 1]);
+      steps.push_back(std::move(r));
+    }
+    const std::vector<ora::StepOut> res = ora::SchedulePendingSteps(alg, nodes, avail, steps);
+    for (size_t k = 0; k < res.size(); ++k) {
+      const u32 s = jb->step_offsets[j] + (u32)k;
+      out->scheduled[s] = res[k].scheduled ? 1 : 0;
+      u64 p = out->place_offsets[s], t = out->task_offsets[s];
+      for (size_t i = 0; i < res[k].node.size(); ++i, ++p) {
+        const MaskRes& m = res[k].node_alloc[i];
+        out->node_idx[p] = res[k].node[i]; out->node_ntasks[p] = res[k].node_ntasks[i];
+        out->node_cpu_raw[p] = m.cpu; out->node_mem[p] = m.mem; out->node_core_lo[p] = m.clo; out->node_core_hi[p] = m.chi; out->node_gres[p] = m.gres;
+      }
+      for (size_t i = 0; i < res[k].task_node.size(); ++i, ++t) {
+        const MaskRes& m = res[k].task_alloc[i];
+        out->task_node[t] = res[k].task_node[i];
+        out->task_cpu_raw[t] = m.cpu; out->task_mem[t] = m.mem; out->task_core_lo[t] = m.clo; out->task_core_hi[t] = m.chi; out->task_gres[t] = m.gres;
+      }
+    }
+    for (u32 n = jb->node_offsets[j], i = 0; n < jb->node_offsets[j + 1]; ++n, ++i) {
+      const MaskRes m = alg.to_mask(avail[i]);
+      out->avail_cpu_raw[n] = m.cpu; out->avail_mem[n] = m.mem; out->avail_core_lo[n] = m.clo; out->avail_core_hi[n] = m.chi; out->avail_gres[n] = m.gres;
+    }
+  }
+  return 0;
+}
+
+extern "C" int ora_schedule_steps(const cns_gres_layout* gl, const cns_step_job_soa* jobs, const cns_step_soa* steps,
+                                  cns_step_result_soa* out, int algebra) {
+  const GresLayout L = layout_from(*gl);
+  if (algebra == 1) { LitAlgebra alg(&L); return run_steps(alg, jobs, steps, out); }
+  MaskAlgebra alg(&L);
+  return run_steps(alg, jobs, steps, out);
+}

@@ -35,9 +35,10 @@ class OraReq(C.Structure):
 
 def build(force: bool = False) -> str:
     path = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp", "prio_oracle.hpp", "limits_oracle.hpp")]
+    srcs = [os.path.join(_HERE, f) for f in ("crane_oracle.cpp", "sched_oracle.hpp", "res_algebra.hpp", "prio_oracle.hpp", "limits_oracle.hpp", "steps_oracle.hpp")]
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "node_select.h"))
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "run_limits.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "steps.h"))
     stale = force or not os.path.exists(path) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
     if stale:
@@ -184,3 +185,14 @@ def run_limits(layout: abi.GresLayout, tables, jobs, placements: abi.Placements)
     if rc != 0:
         raise ValueError("ora_run_limits: key index out of range")
     return reason[:jobs.num_jobs], adm.value, usage
+
+
+def schedule_steps(layout: abi.GresLayout, step_jobs, steps, algebra: int = MASK):
+    """CPU restatement of JobInCtld::SchedulePendingSteps for every job (oracle/steps_oracle.hpp).  Returns StepResults."""
+    from cranesched_amd import steps as st
+    out = st.StepResults(step_jobs, steps)
+    gl, cj, cs, co = layout.to_c(), step_jobs.to_c(), steps.to_c(), out.to_c()
+    rc = lib().ora_schedule_steps(C.byref(gl), C.byref(cj), C.byref(cs), C.byref(co), C.c_int(algebra))
+    if rc != 0:
+        raise RuntimeError(f"ora_schedule_steps failed: {rc}")
+    return out

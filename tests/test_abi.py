@@ -34,7 +34,12 @@ def test_header_symbols_exported(built):
     assert set(lnames) == set(engine.LIMITS_ABI_SYMBOLS)
     for n in lnames:
         assert hasattr(lib, n), f"{n} declared in run_limits.h but not exported"
-    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "priority.h", "run_limits.h"]
+    # ... and steps.h (step scheduler)
+    snames = header_functions("steps.h")
+    assert set(snames) == set(engine.STEPS_ABI_SYMBOLS)
+    for n in snames:
+        assert hasattr(lib, n), f"{n} declared in steps.h but not exported"
+    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "priority.h", "run_limits.h", "steps.h"]
 
 
 def test_no_gpu_means_loud_failure(built):
