@@ -12,6 +12,7 @@
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/priority.h"
 #include "../../include/crane_gpu/run_limits.h"
+#include "../../include/crane_gpu/steps.h"
 
 namespace crane {
 
@@ -693,6 +694,126 @@ void GpuNodeSelectionAlgo::CheckAndMallocMetaResource(AccountMetaSnapshot& meta,
     if (meta.qos_meta.count(qname)) meta.qos_meta[qname] = from_usage(qu[qix]);
   status_ = 0;
   error_.clear();
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Step scheduling (JobScheduler.cpp:1992-2001 -> CtldPublicDefs.cpp:2038-2159), all jobs in one device call.
+// ---------------------------------------------------------------------------------------------------------
+void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs) {
+  Impl& I = *impl_;
+  if (!I.h) { status_ = status_ ? status_ : CNS_ERR_NO_DEVICE; return; }
+  if (!I.have_snapshot) { status_ = CNS_ERR_STATE; error_ = "SchedulePendingSteps before SetClusterSnapshot"; return; }
+  std::vector<uint32_t> noff{0}, nidx, soff{0};
+  std::vector<int64_t> acpu;
+  std::vector<uint64_t> amem, alo, ahi, ag;
+  std::vector<StepInScheduler*> flat;
+  for (const JobStepQueue& jq : jobs) {
+    std::vector<std::pair<uint32_t, const ResourceInNodeV3*>> nodes;   // canonical walk order: ascending dense index
+    if (jq.step_res_avail)
+      for (const auto& [cid, res] : *jq.step_res_avail) {
+        auto it = I.node_idx.find(cid);
+        if (it != I.node_idx.end()) nodes.emplace_back(it->second, &res);
+      }
+    std::sort(nodes.begin(), nodes.end(), [](const auto& a, const auto& b) { return a.first < b.first; });
+    for (const auto& [n, res] : nodes) {
+      nidx.push_back(n);
+      acpu.push_back(res->cpu_set.cpu_count.raw);
+      amem.push_back(res->memory_bytes);
+      uint64_t lo, hi;
+      Impl::core_masks(res->cpu_set.core_ids, lo, hi);
+      alo.push_back(lo); ahi.push_back(hi);
+      ag.push_back(I.gres_mask(res->gres));
+    }
+    noff.push_back((uint32_t)nidx.size());
+    for (StepInScheduler* s : jq.pending_steps) flat.push_back(s);
+    soff.push_back((uint32_t)flat.size());
+  }
+  const size_t S = flat.size();
+  std::vector<int64_t> ncpu(S), tcpu(S);
+  std::vector<uint64_t> nmem(S), tmem(S);
+  std::vector<uint8_t> ngt(S * CNS_MAX_GRES_NAMES, 0), ngs(S * CNS_MAX_GRES_CLASSES, 0), tgt(S * CNS_MAX_GRES_NAMES, 0), tgs(S * CNS_MAX_GRES_CLASSES, 0);
+  std::vector<uint32_t> k(S), nt(S), tmin(S), tmax(S), ioff{0}, inn, eoff{0}, enn;
+  auto pack_gres = [&](const ResourceView& v, uint8_t* gt, uint8_t* gs) {
+    for (const auto& [name, gc] : v.gres_map) {
+      auto nit = I.name_id.find(name);
+      if (nit == I.name_id.end()) { if (gc.total || !gc.specified.empty()) gt[0] = 255; continue; }   // name absent everywhere: never fits
+      gt[nit->second] = (uint8_t)std::min<uint64_t>(gc.total, 255);
+      for (const auto& [type, cnt] : gc.specified) {
+        const int c = I.class_of(name, type);
+        if (c < 0) { if (cnt) gt[nit->second] = 255; continue; }
+        gs[c] = (uint8_t)std::min<uint64_t>(cnt, 127);
+      }
+    }
+  };
+  for (size_t s = 0; s < S; ++s) {
+    const StepInScheduler& st = *flat[s];
+    ncpu[s] = st.req_node_res_view.cpu_count.raw; nmem[s] = st.req_node_res_view.memory_bytes;
+    tcpu[s] = st.req_task_res_view.cpu_count.raw; tmem[s] = st.req_task_res_view.memory_bytes;
+    pack_gres(st.req_node_res_view, &ngt[s * CNS_MAX_GRES_NAMES], &ngs[s * CNS_MAX_GRES_CLASSES]);
+    pack_gres(st.req_task_res_view, &tgt[s * CNS_MAX_GRES_NAMES], &tgs[s * CNS_MAX_GRES_CLASSES]);
+    k[s] = st.node_num; nt[s] = st.ntasks; tmin[s] = st.ntasks_per_node_min; tmax[s] = st.ntasks_per_node_max;
+    for (const auto& n : st.included_nodes) { auto it = I.node_idx.find(n); inn.push_back(it == I.node_idx.end() ? 0xFFFFFFFEu : it->second); }
+    ioff.push_back((uint32_t)inn.size());
+    for (const auto& n : st.excluded_nodes) { auto it = I.node_idx.find(n); if (it != I.node_idx.end()) enn.push_back(it->second); }
+    eoff.push_back((uint32_t)enn.size());
+  }
+  uint64_t places = 0, tasks = 0;
+  for (size_t s = 0; s < S; ++s) { places += k[s]; tasks += nt[s]; }
+  const size_t Nn = nidx.size();
+  std::vector<uint8_t> sch(S + 1);
+  std::vector<uint64_t> poff(S + 1), toff(S + 1), o_mem(places + 1), o_lo(places + 1), o_hi(places + 1), o_g(places + 1),
+      t_mem(tasks + 1), t_lo(tasks + 1), t_hi(tasks + 1), t_g(tasks + 1), r_mem(Nn + 1), r_lo(Nn + 1), r_hi(Nn + 1), r_g(Nn + 1);
+  std::vector<uint32_t> o_node(places + 1), o_nt(places + 1), t_node(tasks + 1);
+  std::vector<int64_t> o_cpu(places + 1), t_cpu(tasks + 1), r_cpu(Nn + 1);
+  cns_step_job_soa cj{};
+  cj.num_jobs = (uint32_t)jobs.size(); cj.num_nodes = (uint32_t)Nn; cj.node_offsets = noff.data(); cj.node_idx = nidx.data();
+  cj.avail_cpu_raw = acpu.data(); cj.avail_mem = amem.data(); cj.avail_core_lo = alo.data(); cj.avail_core_hi = ahi.data();
+  cj.avail_gres = ag.data(); cj.step_offsets = soff.data();
+  cns_step_soa cs{};
+  cs.num_steps = (uint32_t)S; cs.node_cpu_raw = ncpu.data(); cs.node_mem = nmem.data(); cs.node_gres_total = ngt.data(); cs.node_gres_spec = ngs.data();
+  cs.task_cpu_raw = tcpu.data(); cs.task_mem = tmem.data(); cs.task_gres_total = tgt.data(); cs.task_gres_spec = tgs.data();
+  cs.node_num = k.data(); cs.ntasks = nt.data(); cs.ntasks_per_node_min = tmin.data(); cs.ntasks_per_node_max = tmax.data();
+  if (inn.empty()) inn.push_back(0);
+  if (enn.empty()) enn.push_back(0);
+  cs.incl_offsets = ioff.data(); cs.incl_nodes = inn.data(); cs.excl_offsets = eoff.data(); cs.excl_nodes = enn.data();
+  cns_step_result_soa co{};
+  co.scheduled = sch.data(); co.place_offsets = poff.data(); co.node_idx = o_node.data(); co.node_ntasks = o_nt.data();
+  co.node_cpu_raw = o_cpu.data(); co.node_mem = o_mem.data(); co.node_core_lo = o_lo.data(); co.node_core_hi = o_hi.data(); co.node_gres = o_g.data();
+  co.task_offsets = toff.data(); co.task_node = t_node.data(); co.task_cpu_raw = t_cpu.data(); co.task_mem = t_mem.data();
+  co.task_core_lo = t_lo.data(); co.task_core_hi = t_hi.data(); co.task_gres = t_g.data();
+  co.avail_cpu_raw = r_cpu.data(); co.avail_mem = r_mem.data(); co.avail_core_lo = r_lo.data(); co.avail_core_hi = r_hi.data(); co.avail_gres = r_g.data();
+  const int st = cns_schedule_steps(I.h, &cj, &cs, &co, nullptr);
+  if (st != 0) { status_ = st; error_ = cns_last_error(I.h); return; }
+  status_ = 0;
+  error_.clear();
+  // ---- write back (:2109-2135) ----
+  for (size_t s = 0; s < S; ++s) {
+    StepInScheduler& x = *flat[s];
+    x.scheduled = sch[s] != 0;
+    x.craned_ids.clear(); x.allocated_res.clear(); x.craned_task_map.clear(); x.task_res_map.clear();
+    if (!x.scheduled) continue;
+    for (uint64_t p = poff[s]; p < poff[s + 1]; ++p) {
+      const CranedId& cid = I.node_name[o_node[p]];
+      x.craned_ids.push_back(cid);
+      x.allocated_res[cid] = I.to_res(o_cpu[p], o_mem[p], o_lo[p], o_hi[p], o_g[p]);
+    }
+    for (uint64_t t = toff[s]; t < toff[s + 1]; ++t) {
+      if (t_node[t] == CNS_NODE_NONE) continue;   // ntasks > what was handed out cannot happen for a scheduled step
+      const uint32_t tid = (uint32_t)(t - toff[s]);
+      x.craned_task_map[I.node_name[t_node[t]]].insert(tid);
+      x.task_res_map[tid] = I.to_res(t_cpu[t], t_mem[t], t_lo[t], t_hi[t], t_g[t]);
+    }
+  }
+  for (size_t j = 0; j < jobs.size(); ++j) {
+    if (!jobs[j].step_res_avail) continue;
+    for (uint32_t n = noff[j]; n < noff[j + 1]; ++n) {
+      ResourceInNodeV3& dst = (*jobs[j].step_res_avail)[I.node_name[nidx[n]]];
+      const uint64_t sw = dst.memory_sw_bytes;
+      dst = I.to_res(r_cpu[n], r_mem[n], r_lo[n], r_hi[n], r_g[n]);
+      dst.memory_sw_bytes = sw;   // not touched by this path in the canonical model
+    }
+  }
 }
 
 

@@ -192,6 +192,27 @@ struct AccountMetaSnapshot {
   std::unordered_map<std::string, MetaResource> qos_meta;          // m_qos_meta_map_
 };
 
+// ---- step scheduling (JobInCtld::SchedulePendingSteps, CtldPublicDefs.cpp:2038-2159) ---------------------------
+// The CommonStepInCtld fields that function reads and writes.
+struct StepInScheduler {
+  uint32_t step_id{0};
+  ResourceView req_node_res_view, req_task_res_view;
+  uint32_t node_num{1}, ntasks{1}, ntasks_per_node_min{1}, ntasks_per_node_max{1};
+  std::unordered_set<std::string> included_nodes, excluded_nodes;
+  // results (:2129-2135)
+  bool scheduled{false};
+  std::vector<CranedId> craned_ids;                                   // in the order the nodes were handed tasks
+  ResourceV3 allocated_res;                                           // step_alloc_res
+  std::unordered_map<CranedId, std::set<uint32_t>> craned_task_map;   // task ids per node
+  std::unordered_map<uint32_t, ResourceInNodeV3> task_res_map;        // per task id
+};
+// One running job with pending steps: its step_res_avail_ (updated in place) and pending_step_ids_ in queue order.
+struct JobStepQueue {
+  job_id_t job_id{0};
+  ResourceV3* step_res_avail{nullptr};
+  std::vector<StepInScheduler*> pending_steps;
+};
+
 // License (LicenseManager: total, used, reserved, last_deficit as read at LicenseManager.cpp:188-189,203-204)
 struct License {
   uint32_t total{0}, used{0}, reserved{0}, last_deficit{0};
@@ -282,6 +303,12 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // GRES names / types no node of the snapshot has are dropped from limits and usage (no job can allocate them).
   void CheckAndMallocMetaResource(AccountMetaSnapshot& meta, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
                                   std::vector<std::string>& results);
+
+  // JobScheduler::StepScheduleThread_'s loop (JobScheduler.cpp:1992-2001) in one call: SchedulePendingSteps for every
+  // job of `jobs`.  Steps that were scheduled get `scheduled`, craned_ids, allocated_res, craned_task_map and
+  // task_res_map; each job's step_res_avail is updated; the first step of a job that does not fit stops that job's
+  // queue.  A job's nodes are walked in the order of the snapshot (the reference walks an unordered_map).
+  void SchedulePendingSteps(std::vector<JobStepQueue>& jobs);
 
   // Measurement / test hook: only the host-side packing of the running jobs (what NodeSelect does before
   // cns_set_running), with or without the per-job cache; needs no device.  Returns the number of allocation records,

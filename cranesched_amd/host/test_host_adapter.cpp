@@ -327,6 +327,43 @@ int main(int argc, char** argv) {
       CHECK(meta.qos_meta["normal"].jobs_count == 2 && meta.user_meta["dave"].qos_to_resource_map["normal"].jobs_count == 0);
     }
 
+    // --- step scheduling inside two jobs' allocations (JobScheduler.cpp:1992-2001; tests/test_steps.py "fifo", "topk") ---
+    {
+      snap.craned_metas = {node("cn0", 4, 8), node("cn1", 4, 8), node("cn2", 4, 8)};
+      snap.partitions = {{"CPU", {"cn0", "cn1", "cn2"}}};
+      algo.SetClusterSnapshot(snap);
+      auto avail = [](int cores, uint64_t gib) {
+        ResourceInNodeV3 r;
+        r.cpu_set.cpu_count = cpu_t(cores);
+        for (int c = 0; c < cores; ++c) r.cpu_set.core_ids.insert((uint32_t)c);
+        r.memory_bytes = gib << 30;
+        return r;
+      };
+      auto step = [](uint32_t id, uint32_t k, uint32_t ntasks, int cpus, uint32_t tmax) {
+        auto s = std::make_unique<StepInScheduler>();
+        s->step_id = id; s->node_num = k; s->ntasks = ntasks; s->ntasks_per_node_max = tmax;
+        s->req_task_res_view.cpu_count = cpu_t(cpus); s->req_task_res_view.memory_bytes = 1ull << 30;
+        return s;
+      };
+      ResourceV3 a0{{"cn0", avail(4, 8)}, {"cn1", avail(4, 8)}};                        // job 10: "fifo"
+      ResourceV3 a1{{"cn0", avail(1, 8)}, {"cn1", avail(3, 8)}, {"cn2", avail(2, 8)}};  // job 11: "topk"
+      auto sA = step(0, 1, 2, 1, 4), sB = step(1, 2, 4, 2, 2), sC = step(2, 1, 1, 1, 1), sT = step(0, 2, 5, 1, 4);
+      std::vector<JobStepQueue> q(2);
+      q[0].job_id = 10; q[0].step_res_avail = &a0; q[0].pending_steps = {sA.get(), sB.get(), sC.get()};
+      q[1].job_id = 11; q[1].step_res_avail = &a1; q[1].pending_steps = {sT.get()};
+      algo.SchedulePendingSteps(q);
+      CHECK(algo.Ok());
+      CHECK(sA->scheduled && !sB->scheduled && !sC->scheduled);                          // B does not fit: the queue stops
+      CHECK(sA->craned_ids == std::vector<CranedId>{"cn0"});
+      CHECK(sA->craned_task_map.at("cn0") == (std::set<uint32_t>{0, 1}));
+      CHECK(sA->task_res_map.at(0).cpu_set.core_ids == std::set<uint32_t>{0} && sA->task_res_map.at(1).cpu_set.core_ids == std::set<uint32_t>{1});
+      CHECK(a0.at("cn0").cpu_set.core_ids == (std::set<uint32_t>{2, 3}) && a0.at("cn0").memory_bytes == (6ull << 30));
+      CHECK(sT->scheduled && sT->craned_ids == (std::vector<CranedId>{"cn2", "cn1"}));   // fewest tasks first
+      CHECK(sT->craned_task_map.at("cn2") == (std::set<uint32_t>{0, 1}) && sT->craned_task_map.at("cn1") == (std::set<uint32_t>{2, 3, 4}));
+      CHECK(sT->allocated_res.at("cn1").cpu_set.cpu_count == cpu_t(3));
+      CHECK(a1.at("cn0").cpu_set.cpu_count == cpu_t(1) && a1.at("cn1").cpu_set.cpu_count == cpu_t(0));
+    }
+
     // --- a running job shapes the snapshot (cost and availability) ------------------------------------------
     snap.craned_metas = {node("cn0", 2, 8), node("cn1", 2, 8)};
     snap.partitions = {{"CPU", {"cn0", "cn1"}}};
