@@ -405,3 +405,17 @@ def test_gpu_state_and_argument_checks(engine_cls):
         assert list(reason) == [0, 0, 0] and adm == 3
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed,tight", [(1, True), (2, True), (3, True), (4, False), (5, True), (6, False)])
+def test_oracle_vs_independent_python_restatement(seed, tight):
+    """The C++ oracle against a second restatement that shares no code with it (tests/limits_pyref.py: plain dicts
+    keyed like the reference's maps) — the strongest pin available while the reference itself cannot run."""
+    from tests import limits_pyref
+    cluster, jobs, now, lay, t, lj = random_limit_case(seed, J=500, N=96, tight=tight)
+    sel = pyoracle.select(cluster, jobs, now)
+    r_cpp, a_cpp, _ = pyoracle.run_limits(lay, t, lj, sel.placements)
+    r_py, a_py = limits_pyref.run(lay, t, lj, sel.placements)
+    bad = np.nonzero(r_cpp != r_py)[0]
+    assert bad.size == 0, f"job {bad[0]}: C++ {lm.LIMIT_REASON_STR[int(r_cpp[bad[0]])]!r}, python {lm.LIMIT_REASON_STR[int(r_py[bad[0]])]!r}"
+    assert a_cpp == a_py
