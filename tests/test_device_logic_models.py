@@ -1,0 +1,120 @@
+"""Bit-level models (plain Python) of two pieces of device logic whose correctness argument is not obvious from the
+code, checked against brute force on random inputs.  They pin the ALGORITHMS; the kernels themselves are checked
+against the oracle under `-m gpu`.
+
+1. `next_fit_regs` (cranesched_amd/csrc/select_kernels.hip): the lane-parallel earliest-start search must equal the
+   reference's walk over the time map (EarliestStartSubsetSelector, JobScheduler.h:792-865, on one node).
+2. the three-valued CheckGres_ of `k_par_eval` (cranesched_amd/csrc/limits_kernels.hip): "certainly passes" /
+   "certainly fails" over an interval of usage vectors must hold for EVERY vector of the interval
+   (AccountMetaContainer.cpp:1030-1050 evaluated exhaustively)."""
+import itertools
+
+import numpy as np
+import pytest
+
+INF = 1 << 62
+
+
+def next_fit_walk(t, sat, L, t0):
+    """the sequential form (the previous next_fit_regs, itself a restatement of the run walk)"""
+    n = len(t)
+    idx = max(i for i in range(n) if t[i] <= t0)
+    s = t0
+    while True:
+        if not sat[idx]:
+            above = [i for i in range(idx + 1, n) if sat[i]]
+            if not above:
+                return INF
+            idx = above[0]
+            s = t[idx]
+        unsat = [i for i in range(idx + 1, n) if not sat[i]]
+        if not unsat:
+            return s
+        ue = unsat[0]
+        if t[ue] - s >= L:
+            return s
+        idx = ue
+
+
+def next_fit_lanes(t, sat, L, t0):
+    """what every lane computes, then the lowest qualifying lane wins"""
+    n = len(t)
+    idx0 = sum(1 for i in range(n) if t[i] <= t0) - 1
+    ok = []
+    for lane in range(n):
+        here = sat[lane]
+        below = lane > 0 and sat[lane - 1]
+        starts = here and (lane == idx0 or (lane > idx0 and not below))
+        s = t0 if lane == idx0 else t[lane]
+        above = [i for i in range(lane + 1, n) if not sat[i]]
+        endt = t[above[0]] if above else None
+        ok.append(starts and (endt is None or endt - s >= L))
+    if not any(ok):
+        return INF
+    w = ok.index(True)
+    return t0 if w == idx0 else t[w]
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_next_fit_lane_parallel_equals_walk(seed):
+    rng = np.random.default_rng(seed)
+    for _ in range(4000):
+        n = int(rng.integers(1, 20))
+        t = (1000 + np.concatenate([[0], np.cumsum(rng.integers(1, 50, n - 1))])).astype(int).tolist()
+        sat = (rng.random(n) < rng.choice([0.2, 0.5, 0.8])).tolist()
+        L = int(rng.integers(1, 120))
+        t0 = int(rng.integers(1000, t[-1] + 30))
+        assert next_fit_lanes(t, sat, L, t0) == next_fit_walk(t, sat, L, t0), (t, sat, L, t0)
+
+
+# ---- CheckGres_ over an interval ------------------------------------------------------------------------------------
+def check_gres_exact(use, has, lim):
+    """components in walk order; an entry exists in `use` when its count is > 0 (:1030-1050)"""
+    for c in range(len(use)):
+        if use[c] == 0:
+            continue
+        if not has[c]:
+            return True            # `return true` at the first requested entry the limit lacks
+        if use[c] > lim[c]:
+            return False
+    return True
+
+
+def check_gres_interval(lo, hi, has, lim):
+    """the ballots of k_par_eval: returns (certain_pass, certain_fail)"""
+    n = len(lo)
+    sC = [not has[c] and lo[c] > 0 for c in range(n)]
+    sM = [not has[c] and hi[c] > 0 for c in range(n)]
+    gC = [has[c] and lo[c] > lim[c] for c in range(n)]
+    gM = [has[c] and hi[c] > lim[c] for c in range(n)]
+    m1 = [sC[c] or gC[c] or gM[c] for c in range(n)]
+    m2 = [m1[c] or sM[c] for c in range(n)]
+    g_pass = (not any(m1)) or sC[m1.index(True)]
+    g_fail = any(m2) and gC[m2.index(True)]
+    return g_pass, g_fail
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_three_valued_gres_walk_is_sound(seed):
+    rng = np.random.default_rng(100 + seed)
+    seen_pass = seen_fail = seen_unknown = 0
+    for _ in range(3000):
+        n = int(rng.integers(1, 6))
+        has = (rng.random(n) < 0.6).tolist()
+        lim = rng.integers(0, 4, n).tolist()
+        lo = rng.integers(0, 4, n).tolist()
+        hi = [lo[c] + int(rng.integers(0, 3)) for c in range(n)]
+        g_pass, g_fail = check_gres_interval(lo, hi, has, lim)
+        assert not (g_pass and g_fail)
+        outcomes = {check_gres_exact(u, has, lim) for u in itertools.product(*[range(lo[c], hi[c] + 1) for c in range(n)])}
+        if g_pass:
+            assert outcomes == {True}, (lo, hi, has, lim)
+            seen_pass += 1
+        elif g_fail:
+            assert outcomes == {False}, (lo, hi, has, lim)
+            seen_fail += 1
+        else:
+            seen_unknown += 1
+        if lo == hi:      # a zero-width interval is always decided: the progress guarantee of the rounds
+            assert g_pass or g_fail
+    assert seen_pass and seen_fail and seen_unknown
