@@ -118,3 +118,62 @@ def test_three_valued_gres_walk_is_sound(seed):
         if lo == hi:      # a zero-width interval is always decided: the progress guarantee of the rounds
             assert g_pass or g_fail
     assert seen_pass and seen_fail and seen_unknown
+
+
+# ---- the bracketing rounds as an algorithm ---------------------------------------------------------------------------
+def greedy(keys, add, lim):
+    """admission in order: job j is admitted iff every one of its keys stays within its limit"""
+    use = {}
+    out = []
+    for j in range(len(add)):
+        ok = all(use.get(k, 0) + add[j] <= lim[k] for k in keys[j])
+        out.append(ok)
+        if ok:
+            for k in keys[j]:
+                use[k] = use.get(k, 0) + add[j]
+    return out
+
+
+def bracketing(keys, add, lim):
+    """state 0 undecided / 1 admitted / 2 rejected; per round: sums over earlier admitted (L) and earlier not-rejected
+    (U) jobs of each key; passes under U -> admitted, fails under L -> rejected (k_par_tails / k_par_eval / k_par_update)"""
+    n = len(add)
+    state = [0] * n
+    rounds = 0
+    while 0 in state:
+        rounds += 1
+        sumL, sumU = {}, {}
+        new = list(state)
+        for j in range(n):
+            if state[j] == 0:
+                pass_u = all(sumU.get(k, 0) + add[j] <= lim[k] for k in keys[j])
+                fail_l = any(sumL.get(k, 0) + add[j] > lim[k] for k in keys[j])
+                if pass_u:
+                    new[j] = 1
+                elif fail_l:
+                    new[j] = 2
+            for k in keys[j]:
+                if state[j] == 1:
+                    sumL[k] = sumL.get(k, 0) + add[j]
+                if state[j] != 2:
+                    sumU[k] = sumU.get(k, 0) + add[j]
+        assert new != state, "a round must decide at least the first undecided job"
+        state = new
+    return [s == 1 for s in state], rounds
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bracketing_rounds_equal_greedy_admission(seed):
+    rng = np.random.default_rng(500 + seed)
+    worst = 0
+    for _ in range(300):
+        n = int(rng.integers(1, 60))
+        nk = int(rng.integers(1, 6))
+        keys = [tuple({int(rng.integers(0, nk)), nk + int(rng.integers(0, 2)), 2 * nk + 7}) for _ in range(n)]   # user-like, account-like, global
+        add = rng.integers(1, 9, n).tolist()
+        lim = {k: int(rng.integers(4, 60)) for k in range(3 * nk + 10)}
+        want = greedy(keys, add, lim)
+        got, rounds = bracketing(keys, add, lim)
+        assert got == want
+        worst = max(worst, rounds)
+    assert worst <= 60
