@@ -34,7 +34,8 @@ struct GpuNodeSelectionAlgo::Impl {
   std::vector<std::vector<SlotId>> class_bit_slot;          // per class: bit offset -> slot path
   cns_gres_layout layout{};
   bool have_snapshot = false;
-  std::unordered_map<const PdJobInScheduler*, uint64_t> last_index;  // job -> its index in the last cns_select
+  std::vector<const PdJobInScheduler*> last_ord;                      // the jobs of the last cns_select, in its order
+  std::unordered_map<const PdJobInScheduler*, uint64_t> last_index;  // job -> its index there (built when the run-limit pass asks)
   // Incremental packing of the running jobs: an allocation never changes while its job runs, so its
   // dense form (node indices, core / GRES masks) is kept per job id across cycles; a cycle costs one lookup per
   // running job instead of one string lookup + set -> mask conversion per allocated node.  Entries of jobs that did
@@ -78,6 +79,94 @@ struct GpuNodeSelectionAlgo::Impl {
   std::vector<int64_t> r_end, r_cpu;
   std::vector<uint32_t> r_off, r_node, r_resv;
   std::vector<uint64_t> r_mem, r_lo, r_hi, r_g;
+
+
+  // ---- pending jobs -> cns_job_soa arrays, and placements -> PdJobInScheduler.  The reference's structures — a
+  // std::set of core ids, string-keyed maps per job — are what makes the write-back expensive (~0.65 us per placed
+  // job); a caller that can consume the SoA of the C ABI directly skips it. ------------------------------------------
+  // Measured (test_host_adapter --cycle-bench): 8 host threads made the write-back 5x SLOWER (small allocations into
+  // objects owned by another thread's malloc arena) and left the packing unchanged, so both loops are plain loops.
+  template <class F>
+  static void parallel_for(size_t n, F&& body) { body((size_t)0, n); }
+  struct PackedJobs {
+    std::vector<uint32_t> part, k, nt, tmin, tmax, inodes, enodes, jresv;
+    std::vector<int64_t> L, ncpu, tcpu;
+    std::vector<uint64_t> nmem, tmem, ioff, eoff;
+    std::vector<uint8_t> excl, skip, gtot, gspec;
+  };
+  void pack_pending(const std::vector<PdJobInScheduler*>& ord, PackedJobs& B) const {
+    const size_t J = ord.size();
+    B.part.assign(J, 0); B.k.assign(J, 0); B.nt.assign(J, 0); B.tmin.assign(J, 0); B.tmax.assign(J, 0);
+    B.L.assign(J, 0); B.ncpu.assign(J, 0); B.tcpu.assign(J, 0); B.nmem.assign(J, 0); B.tmem.assign(J, 0);
+    B.excl.assign(J, 0); B.skip.assign(J, 0); B.gtot.assign(J * CNS_MAX_GRES_NAMES, 0); B.gspec.assign(J * CNS_MAX_GRES_CLASSES, 0);
+    B.jresv.assign(J, CNS_RESV_NONE);
+    parallel_for(J, [&](size_t a, size_t b) {
+      for (size_t j = a; j < b; ++j) {
+        const PdJobInScheduler& p = *ord[j];
+        auto pit = part_idx.find(p.partition_id);
+        B.part[j] = pit == part_idx.end() ? 0xFFFFFFFFu : pit->second;  // -> "Partition Not Found" (cpp:6748-6752)
+        B.L[j] = p.time_limit;
+        B.ncpu[j] = p.req_node_res_view.cpu_count.raw;
+        B.nmem[j] = p.req_node_res_view.memory_bytes;
+        B.tcpu[j] = p.req_task_res_view.cpu_count.raw;
+        B.tmem[j] = p.req_task_res_view.memory_bytes;
+        B.k[j] = p.node_num; B.nt[j] = p.ntasks; B.tmin[j] = p.ntasks_per_node_min; B.tmax[j] = p.ntasks_per_node_max;
+        B.excl[j] = p.exclusive;
+        B.skip[j] = !p.reason.empty();  // cpp:6744
+        if (!p.reservation.empty()) {  // scheduled by the reservation's scheduler (cpp:6754-6760); unknown -> "Reservation Not Found"
+          auto rit = resv_idx.find(p.reservation);
+          B.jresv[j] = rit == resv_idx.end() ? 0xFFFFFFFEu : rit->second;
+        }
+        for (const auto& [name, gc] : p.req_node_res_view.gres_map) {
+          auto nit = name_id.find(name);
+          uint64_t tot = gc.total;
+          if (nit == name_id.end()) { if (tot || !gc.specified.empty()) B.gtot[j * CNS_MAX_GRES_NAMES] = 255; continue; }  // name absent everywhere: never fits
+          B.gtot[j * CNS_MAX_GRES_NAMES + nit->second] = (uint8_t)std::min<uint64_t>(tot, 255);
+          for (const auto& [type, cnt] : gc.specified) {
+            int c = class_of(name, type);
+            if (c < 0) { if (cnt) B.gtot[j * CNS_MAX_GRES_NAMES + nit->second] = 255; continue; }               // type absent everywhere
+            B.gspec[j * CNS_MAX_GRES_CLASSES + c] = (uint8_t)std::min<uint64_t>(cnt, 127);
+          }
+        }
+      }
+    });
+    // include / exclude lists (rare): CSR, in order
+    B.ioff.assign(1, 0); B.eoff.assign(1, 0); B.inodes.clear(); B.enodes.clear();
+    B.ioff.reserve(J + 1); B.eoff.reserve(J + 1);
+    for (size_t j = 0; j < J; ++j) {
+      const PdJobInScheduler& p = *ord[j];
+      for (const auto& n : p.included_nodes) { auto it = node_idx.find(n); B.inodes.push_back(it == node_idx.end() ? 0xFFFFFFFEu : it->second); }
+      B.ioff.push_back(B.inodes.size());
+      for (const auto& n : p.excluded_nodes) { auto it = node_idx.find(n); if (it != node_idx.end()) B.enodes.push_back(it->second); }
+      B.eoff.push_back(B.enodes.size());
+    }
+    if (B.inodes.empty()) B.inodes.push_back(0);
+    if (B.enodes.empty()) B.enodes.push_back(0);
+  }
+  // what JobScheduler.cpp:1492-1600 consumes
+  void write_back(const std::vector<PdJobInScheduler*>& ord, const cns_placement_soa& o) const {
+    parallel_for(ord.size(), [&](size_t a, size_t b) {
+      for (size_t j = a; j < b; ++j) {
+        PdJobInScheduler& p = *ord[j];
+        const uint8_t r = o.reason[j];
+        if (r == CNS_REASON_SKIPPED) continue;  // the caller's reason stays
+        p.reason = kReasonStr[r];
+        p.craned_ids.clear(); p.craned_id_to_task_num.clear(); p.allocated_res.clear();
+        if (o.start_sec[j] == 0) continue;      // nothing placed ("Resource" / "Partition Not Found" / "Priority" beyond the batch)
+        p.start_time = o.start_sec[j];
+        p.end_time = p.start_time + p.time_limit;  // cpp:6772
+        for (uint64_t q = o.place_offsets[j]; q < o.place_offsets[j + 1]; ++q) {
+          if (o.node_idx[q] == CNS_NODE_NONE) continue;
+          const CranedId& cid = node_name[o.node_idx[q]];
+          p.craned_ids.push_back(cid);
+          p.craned_id_to_task_num[cid] = o.ntasks[q];
+          ResourceInNodeV3 res = to_res(o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q]);
+          res.memory_sw_bytes = p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o.ntasks[q];
+          p.allocated_res[cid] = std::move(res);
+        }
+      }
+    });
+  }
 
   // running jobs -> cns_running_soa arrays (JobScheduler.cpp:6681-6709); order = the caller's vector
   void pack_running(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
@@ -188,6 +277,37 @@ void GpuNodeSelectionAlgo::SetCranedState(const CranedId& craned_id, bool alive,
   I.n_sched[it->second] = s;
   status_ = I.push_tables(error_);     // the packed tables again, no string is looked at; dense indices stay valid
   if (status_ == 0) error_.clear();
+}
+
+void GpuNodeSelectionAlgo::PendingCycleForBench(const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                                double* pack_ms, double* write_back_ms, uint64_t* checksum) {
+  Impl& I = *impl_;
+  std::vector<PdJobInScheduler*> ord;
+  for (const auto& j : pending_jobs) ord.push_back(j.get());
+  Impl::PackedJobs B;
+  auto t0 = std::chrono::steady_clock::now();
+  I.pack_pending(ord, B);
+  *pack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  // synthetic placements: job j starts now on node j % N with the 4 lowest cores (what cns_select would hand back)
+  const size_t J = ord.size(), N = std::max<size_t>(I.node_name.size(), 1);
+  std::vector<int64_t> st(J, 1000), cpu(J, 4 * 256);
+  std::vector<uint8_t> rs(J, 0);
+  std::vector<uint64_t> off(J + 1), mem(J, 1ull << 30), lo(J, 0xF), hi(J, 0), g(J, 0);
+  std::vector<uint32_t> node(J), ntk(J, 1);
+  for (size_t j = 0; j < J; ++j) { off[j] = j; node[j] = (uint32_t)(j % N); }
+  off[J] = J;
+  cns_placement_soa o{};
+  o.place_capacity = J; o.start_sec = st.data(); o.reason = rs.data(); o.place_offsets = off.data(); o.node_idx = node.data();
+  o.ntasks = ntk.data(); o.cpu_raw = cpu.data(); o.mem = mem.data(); o.core_lo = lo.data(); o.core_hi = hi.data(); o.gres = g.data();
+  t0 = std::chrono::steady_clock::now();
+  I.write_back(ord, o);
+  *write_back_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  uint64_t hsh = 1469598103934665603ull;
+  auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ull; } };
+  mix(B.part.data(), J * 4); mix(B.L.data(), J * 8); mix(B.tcpu.data(), J * 8); mix(B.tmem.data(), J * 8); mix(B.k.data(), J * 4);
+  mix(B.gtot.data(), B.gtot.size()); mix(B.gspec.data(), B.gspec.size()); mix(B.skip.data(), J);
+  for (size_t j = 0; j < J; j += 997) { const auto& p = *ord[j]; mix(p.craned_ids[0].data(), p.craned_ids[0].size()); mix(&p.end_time, 8); }
+  *checksum = hsh;
 }
 
 size_t GpuNodeSelectionAlgo::PackRunningForBench(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
@@ -364,45 +484,12 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
     }
   }
   const size_t J = ord.size();
-  std::vector<uint32_t> part(J), k(J), nt(J), tmin(J), tmax(J);
-  std::vector<int64_t> L(J), ncpu(J), tcpu(J);
-  std::vector<uint64_t> nmem(J), tmem(J), ioff{0}, eoff{0};
-  std::vector<uint8_t> excl(J), skip(J), gtot(J * CNS_MAX_GRES_NAMES, 0), gspec(J * CNS_MAX_GRES_CLASSES, 0);
-  std::vector<uint32_t> inodes, enodes, jresv(J, CNS_RESV_NONE);
-  for (size_t j = 0; j < J; ++j) {
-    const PdJobInScheduler& p = *ord[j];
-    auto pit = I.part_idx.find(p.partition_id);
-    part[j] = pit == I.part_idx.end() ? 0xFFFFFFFFu : pit->second;  // -> "Partition Not Found" (cpp:6748-6752)
-    L[j] = p.time_limit;
-    ncpu[j] = p.req_node_res_view.cpu_count.raw;
-    nmem[j] = p.req_node_res_view.memory_bytes;
-    tcpu[j] = p.req_task_res_view.cpu_count.raw;
-    tmem[j] = p.req_task_res_view.memory_bytes;
-    k[j] = p.node_num; nt[j] = p.ntasks; tmin[j] = p.ntasks_per_node_min; tmax[j] = p.ntasks_per_node_max;
-    excl[j] = p.exclusive;
-    skip[j] = !p.reason.empty();  // cpp:6744
-    if (!p.reservation.empty()) {  // scheduled by the reservation's scheduler (cpp:6754-6760); unknown -> "Reservation Not Found"
-      auto rit = I.resv_idx.find(p.reservation);
-      jresv[j] = rit == I.resv_idx.end() ? 0xFFFFFFFEu : rit->second;
-    }
-    for (const auto& [name, gc] : p.req_node_res_view.gres_map) {
-      auto nit = I.name_id.find(name);
-      uint64_t tot = gc.total;
-      if (nit == I.name_id.end()) { if (tot || !gc.specified.empty()) gtot[j * CNS_MAX_GRES_NAMES] = 255; continue; }  // name absent everywhere: never fits
-      gtot[j * CNS_MAX_GRES_NAMES + nit->second] = (uint8_t)std::min<uint64_t>(tot, 255);
-      for (const auto& [type, cnt] : gc.specified) {
-        int c = I.class_of(name, type);
-        if (c < 0) { if (cnt) gtot[j * CNS_MAX_GRES_NAMES + nit->second] = 255; continue; }               // type absent everywhere
-        gspec[j * CNS_MAX_GRES_CLASSES + c] = (uint8_t)std::min<uint64_t>(cnt, 127);
-      }
-    }
-    for (const auto& n : p.included_nodes) { auto it = I.node_idx.find(n); inodes.push_back(it == I.node_idx.end() ? 0xFFFFFFFEu : it->second); }
-    ioff.push_back(inodes.size());
-    for (const auto& n : p.excluded_nodes) { auto it = I.node_idx.find(n); if (it != I.node_idx.end()) enodes.push_back(it->second); }
-    eoff.push_back(enodes.size());
-  }
-  if (inodes.empty()) inodes.push_back(0);
-  if (enodes.empty()) enodes.push_back(0);
+  Impl::PackedJobs B;
+  I.pack_pending(ord, B);
+  auto &part = B.part, &k = B.k, &nt = B.nt, &tmin = B.tmin, &tmax = B.tmax, &inodes = B.inodes, &enodes = B.enodes, &jresv = B.jresv;
+  auto &L = B.L, &ncpu = B.ncpu, &tcpu = B.tcpu;
+  auto &nmem = B.nmem, &tmem = B.tmem, &ioff = B.ioff, &eoff = B.eoff;
+  auto &excl = B.excl, &skip = B.skip, &gtot = B.gtot, &gspec = B.gspec;
   cns_job_soa js{};
   js.num_jobs = J;
   js.partition = part.data(); js.time_limit_sec = L.data(); js.node_cpu_raw = ncpu.data(); js.node_mem = nmem.data();
@@ -423,32 +510,13 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   out.node_idx = o_node.data(); out.ntasks = o_nt.data(); out.cpu_raw = o_cpu.data(); out.mem = o_mem.data();
   out.core_lo = o_lo.data(); out.core_hi = o_hi.data(); out.gres = o_g.data();
   I.last_index.clear();
+  I.last_ord.clear();
   st = cns_select(I.h, now, &js, &out);
   if (st != 0) return fail_all(st, cns_last_error(I.h));
-  for (size_t j = 0; j < J; ++j) I.last_index[ord[j]] = j;
+  I.last_ord.assign(ord.begin(), ord.end());
   status_ = 0;
   error_.clear();
-
-  // ---- write back (what JobScheduler.cpp:1492-1600 consumes) --------------------------------------------
-  for (size_t j = 0; j < J; ++j) {
-    PdJobInScheduler& p = *ord[j];
-    const uint8_t r = o_reason[j];
-    if (r == CNS_REASON_SKIPPED) continue;  // the caller's reason stays
-    p.reason = kReasonStr[r];
-    p.craned_ids.clear(); p.craned_id_to_task_num.clear(); p.allocated_res.clear();
-    if (o_start[j] == 0) continue;          // nothing placed ("Resource" / "Partition Not Found" / "Priority" beyond the batch)
-    p.start_time = o_start[j];
-    p.end_time = p.start_time + p.time_limit;  // cpp:6772
-    for (uint64_t q = o_off[j]; q < o_off[j + 1]; ++q) {
-      if (o_node[q] == CNS_NODE_NONE) continue;
-      const CranedId& cid = I.node_name[o_node[q]];
-      p.craned_ids.push_back(cid);
-      p.craned_id_to_task_num[cid] = o_nt[q];
-      ResourceInNodeV3 res = I.to_res(o_cpu[q], o_mem[q], o_lo[q], o_hi[q], o_g[q]);
-      res.memory_sw_bytes = p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o_nt[q];
-      p.allocated_res[cid] = std::move(res);
-    }
-  }
+  I.write_back(ord, out);
 }
 
 
@@ -639,6 +707,11 @@ void GpuNodeSelectionAlgo::CheckAndMallocMetaResource(AccountMetaSnapshot& meta,
   std::vector<uint32_t> user(J, 0), ua(J, 0), acct(J, 0), qosv(J, 0), part(J, 0);
   std::vector<int64_t> tl(J, 0);
   std::vector<uint8_t> skip(J, 0);
+  if (I.last_index.size() != I.last_ord.size()) {
+    I.last_index.clear();
+    I.last_index.reserve(I.last_ord.size());
+    for (size_t j = 0; j < I.last_ord.size(); ++j) I.last_index[I.last_ord[j]] = j;
+  }
   for (size_t i = 0; i < J; ++i) {
     const PdJobInScheduler& p = *pending_jobs[i];
     auto li = I.last_index.find(&p);

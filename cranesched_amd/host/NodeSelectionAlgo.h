@@ -313,6 +313,9 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // Measurement / test hook: only the host-side packing of the running jobs (what NodeSelect does before
   // cns_set_running), with or without the per-job cache; needs no device.  Returns the number of allocation records,
   // *checksum covers every array cns_set_running would receive, *pack_ms is the packing alone.
+  // ... and of the pending side: cns_job_soa packing + the write-back of (synthetic) placements into the jobs.
+  void PendingCycleForBench(const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs, double* pack_ms,
+                            double* write_back_ms, uint64_t* checksum);
   size_t PackRunningForBench(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs, bool use_cache,
                              uint64_t* checksum, double* pack_ms = nullptr);
 

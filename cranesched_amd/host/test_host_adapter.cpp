@@ -90,7 +90,36 @@ static int pack_bench(int n_nodes, int n_jobs) {
   return g_fail != 0;
 }
 
+// Host-side cost of the pending side of one cycle: cns_job_soa packing and the write-back of the placements into the
+// PdJobInScheduler objects; needs no device.
+static int cycle_bench(int n_nodes, int n_jobs) {
+  GpuNodeSelectionAlgo algo(0);
+  ClusterSnapshot snap;
+  std::vector<CranedId> ids;
+  for (int i = 0; i < n_nodes; ++i) {
+    char name[16];
+    snprintf(name, sizeof name, "cn%05d", i);
+    snap.craned_metas.push_back(node(name, 64, 256));
+    ids.push_back(name);
+  }
+  snap.partitions = {{"CPU", ids}};
+  algo.SetClusterSnapshot(snap);
+  std::vector<std::unique_ptr<PdJobInScheduler>> pd;
+  for (int j = 0; j < n_jobs; ++j) pd.push_back(job((job_id_t)(j + 1), 4, 600 + j % 1000));
+  double pack_ms, wb_ms;
+  uint64_t sum;
+  algo.PendingCycleForBench(pd, &pack_ms, &wb_ms, &sum);
+  CHECK(pd[n_jobs / 2]->allocated_res.begin()->second.cpu_set.core_ids == (std::set<uint32_t>{0, 1, 2, 3}));
+  CHECK(pd[n_jobs - 1]->end_time == 1000 + pd[n_jobs - 1]->time_limit && pd[0]->craned_ids[0] == "cn00000");
+  printf("cycle-bench: %d nodes, %d pending jobs (all placed, 1 node x 4 cores each), 1 host thread\n", n_nodes, n_jobs);
+  printf("  pack  PdJobInScheduler -> cns_job_soa : %8.2f ms = %.2f us / job\n", pack_ms, 1e3 * pack_ms / n_jobs);
+  printf("  write placements -> PdJobInScheduler  : %8.2f ms = %.2f us / job\n", wb_ms, 1e3 * wb_ms / n_jobs);
+  printf("%s\n", g_fail ? "FAIL" : "ok");
+  return g_fail != 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000);
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
   const bool no_gpu = argc > 1 && !strcmp(argv[1], "--no-gpu");
   const TimeSec now = 1000;

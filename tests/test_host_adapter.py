@@ -27,3 +27,9 @@ def test_incremental_running_pack_equals_full_pack(built):
     after jobs ended / started (host-only, no device needed); the printed timings are the measurement."""
     r = subprocess.run([EXE, "--pack-bench", "2048", "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_pending_pack_and_write_back_host_only(built):
+    """cns_job_soa packing + write-back of synthetic placements into PdJobInScheduler objects (no device needed)."""
+    r = subprocess.run([EXE, "--cycle-bench", "1024", "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
