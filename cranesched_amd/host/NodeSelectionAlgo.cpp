@@ -160,9 +160,9 @@ struct GpuNodeSelectionAlgo::Impl {
           const CranedId& cid = node_name[o.node_idx[q]];
           p.craned_ids.push_back(cid);
           p.craned_id_to_task_num[cid] = o.ntasks[q];
-          ResourceInNodeV3 res = to_res(o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q]);
+          ResourceInNodeV3& res = p.allocated_res[cid];   // built in place (the map was cleared above)
+          fill_res(res, o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q]);
           res.memory_sw_bytes = p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o.ntasks[q];
-          p.allocated_res[cid] = std::move(res);
         }
       }
     });
@@ -241,19 +241,27 @@ struct GpuNodeSelectionAlgo::Impl {
       else if (c < 128) hi |= 1ull << (c - 64);
     }
   }
-  ResourceInNodeV3 to_res(int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g) const {
-    ResourceInNodeV3 r;
+  // fills `r` (a fresh or cleared ResourceInNodeV3) from the mask form; ids and slot paths arrive in ascending order,
+  // so every set insertion is hinted at end()
+  void fill_res(ResourceInNodeV3& r, int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g) const {
     r.cpu_set.cpu_count = cpu_t::from_raw(cpu_raw);
-    for (int b = 0; b < 64; ++b) {
-      if ((lo >> b) & 1) r.cpu_set.core_ids.insert((uint32_t)b);
-      if ((hi >> b) & 1) r.cpu_set.core_ids.insert((uint32_t)(64 + b));
-    }
+    auto& ids = r.cpu_set.core_ids;
+    for (uint64_t m = lo; m; m &= m - 1) ids.insert(ids.end(), (uint32_t)__builtin_ctzll(m));
+    for (uint64_t m = hi; m; m &= m - 1) ids.insert(ids.end(), 64u + (uint32_t)__builtin_ctzll(m));
     r.memory_bytes = mem;
     r.memory_sw_bytes = mem;
-    for (size_t c = 0; c < classes.size(); ++c)
-      for (uint32_t i = 0; i < layout.class_width[c]; ++i)
-        if ((g >> (layout.class_shift[c] + i)) & 1)
-          r.gres[classes[c].first][classes[c].second].insert(class_bit_slot[c][i]);
+    if (g)
+      for (size_t c = 0; c < classes.size(); ++c) {
+        const uint64_t w = layout.class_width[c] >= 64 ? ~0ull : ((1ull << layout.class_width[c]) - 1ull);
+        uint64_t bits = (g >> layout.class_shift[c]) & w;
+        if (!bits) continue;
+        auto& slots = r.gres[classes[c].first][classes[c].second];
+        for (; bits; bits &= bits - 1) slots.insert(slots.end(), class_bit_slot[c][(uint32_t)__builtin_ctzll(bits)]);
+      }
+  }
+  ResourceInNodeV3 to_res(int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g) const {
+    ResourceInNodeV3 r;
+    fill_res(r, cpu_raw, mem, lo, hi, g);
     return r;
   }
 };
