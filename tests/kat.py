@@ -120,6 +120,19 @@ def scenarios():
     j = jobs([dict(L=100), dict(L=50, excl=1)])
     out.append(("exclusive_whole_node", c, j, {}, {0: (0, NOW, [(0, 1, 256, 0x1, 0)]),
                                                   1: (0, NOW, [(1, 1, 512, 0x3, 0)])}))
+
+    # I. UpdateResourceInNode when the boundaries ARE existing keys (JobScheduler.h:400-458, cases #3/#4 without an
+    #    insertion): job 1 ends where job 0 ended (no new entry), job 2 (4 cpus) cannot start before 1100 — an existing
+    #    key — and is allocated against res_total (cores {0..3}; 4 cpus <= the cycle-start res_avail -> "Priority"),
+    #    job 3 still starts now: its window [1000, 1100) does not contain the entry at 1100 (:6279 `< now + L`) and it
+    #    ends on that key.  cost = 100*1/4 + 100*1/4 + 50*4/4 + 100*2/4.
+    c = cluster([4], [8])
+    j = jobs([dict(L=100), dict(L=100), dict(cpu=4, L=50), dict(cpu=2, L=100)])
+    out.append(("time_map_existing_keys", c, j, {}, {
+        0: (0, NOW, [(0, 1, 256, 0x1, 0)]), 1: (0, NOW, [(0, 1, 256, 0x2, 0)]), 2: (1, 1100, [(0, 1, 1024, 0xF, 0)]),
+        3: (0, NOW, [(0, 1, 512, 0xC, 0)]),
+        "costs": [150.0],
+        "timeline": {0: [(NOW, 0, 0x0), (1100, 0, 0x0), (1150, 1024, 0xF), (INF, 0, 0)]}}))
     return out
 
 
