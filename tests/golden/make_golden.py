@@ -58,6 +58,19 @@ def limit_outputs(case):
     return out
 
 
+# step scheduler (tests/test_steps.py::random_step_case): every output array of the oracle's pass
+STEP_CASES = {"steps_1": 1, "steps_2": 2}
+
+
+def step_outputs(seed):
+    from tests import test_steps
+    lay, jobs, steps = test_steps.random_step_case(seed, J=200)
+    res = pyoracle.schedule_steps(lay, jobs, steps)
+    lit = pyoracle.schedule_steps(lay, jobs, steps, pyoracle.LITERAL)
+    assert res.diff(lit) is None
+    return {f: getattr(res, f) for f in res.FIELDS}
+
+
 def main():
     for name, make in CASES.items():
         c, j, now, run = make()
@@ -79,6 +92,10 @@ def main():
         out = limit_outputs(make())
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, len(out["reason"]), "jobs", int(out["admitted"][0]), "admitted")
+    for name, seed in STEP_CASES.items():
+        out = step_outputs(seed)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+        print(name, int(out["scheduled"].sum()), "steps scheduled")
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle
-from tests.golden.make_golden import CASES, HERE, LIMIT_CASES, RESV_CASES, limit_outputs
+from tests.golden.make_golden import CASES, HERE, LIMIT_CASES, RESV_CASES, STEP_CASES, limit_outputs, step_outputs
 
 
 def load(name):
@@ -37,6 +37,14 @@ def test_oracle_matches_golden_reservations(name):
 @pytest.mark.parametrize("name", sorted(LIMIT_CASES))
 def test_oracle_matches_golden_run_limits(name):
     out = limit_outputs(LIMIT_CASES[name]())
+    g = load(name)
+    for k, v in out.items():
+        assert np.array_equal(g[k], v), f"{name}: {k} differs from the golden fixture"
+
+
+@pytest.mark.parametrize("name", sorted(STEP_CASES))
+def test_oracle_matches_golden_steps(name):
+    out = step_outputs(STEP_CASES[name])
     g = load(name)
     for k, v in out.items():
         assert np.array_equal(g[k], v), f"{name}: {k} differs from the golden fixture"
