@@ -55,20 +55,3 @@ def test_golden_run_limits_on_gpu(engine_cls, name):
     finally:
         eng.close()
 
-
-@pytest.mark.parametrize("name", ["steps_1", "steps_2"])
-def test_golden_steps_on_gpu(engine_cls, name):
-    """Step scheduler vs the frozen fixture, every output array."""
-    from tests import test_steps
-    from tests.golden.make_golden import STEP_CASES
-    from tests.test_golden import load
-    lay, jobs, steps = test_steps.random_step_case(STEP_CASES[name], J=200)
-    g = load(name)
-    eng = engine_cls(device=0)
-    try:
-        eng.set_nodes(kat.cluster([4], layout=lay))
-        got, _ = eng.schedule_steps(jobs, steps)
-        for f in got.FIELDS:
-            assert np.array_equal(g[f], getattr(got, f)), f"{name}: {f}"
-    finally:
-        eng.close()
