@@ -1,0 +1,39 @@
+"""CPU side of the full-run digests: the per-partition merge of tests/golden/make_fullrun.py equals ONE oracle run
+over all partitions (so the committed fullrun_*.npz digests are digests of the oracle's whole-queue result), and
+the committed digests are self-consistent."""
+import os
+
+import numpy as np
+import pytest
+
+from cranesched_amd import synth
+from tests import fullrun
+from tests.golden import make_fullrun
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name,J,N,P", [("C4", 24000, 2048, 8), ("C5", 12000, 512, 4)])
+def test_partition_merge_equals_single_run(built, name, J, N, P):
+    from oracle import pyoracle
+    cluster, jobs, full, costs, timelines, _ = make_fullrun.merged_run(name, J=J, N=N, P=P, procs=2)
+    ref = pyoracle.select(cluster, jobs, synth.NOW)
+    assert full.diff(ref.placements) is None
+    a = fullrun.digest(full, costs, lambda n: timelines[n], cluster.num_nodes)
+    b = fullrun.digest(ref.placements, ref.costs().view(np.uint64), ref.timeline, cluster.num_nodes)
+    assert fullrun.compare(a, b) is None
+    assert (ref.placements.reason[:J] == 1).sum() > J // 20, "case must exercise backfill"
+
+
+@pytest.mark.parametrize("tag", list(make_fullrun.CASES))
+def test_committed_digests_well_formed(tag):
+    path = os.path.join(GOLDEN, f"fullrun_{tag}.npz")
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
+    d = np.load(path)
+    name, J, N, P = make_fullrun.CASES[tag]
+    J = J or synth.CONFIGS[name]["J"]
+    assert int(d["jobs"][0]) == J and int(d["nodes"][0]) == (N or synth.CONFIGS[name]["N"])
+    assert len(d["chunk_crc"]) == (J + fullrun.CHUNK - 1) // fullrun.CHUNK
+    assert int(d["counts"].sum()) == J
+    if tag != "c5":  # the frozen C5 queue does not fill its 64 k nodes (see make_fullrun.CASES["c5deep"])
+        assert d["counts"][1] >= J // 5, "the queue must reach the backfill regime (>= 20 % backfilled)"

@@ -1,0 +1,38 @@
+"""BASELINE.json's configurations at FULL size, and contended single-partition cases for every register-tile width,
+against the CPU oracle's whole-queue results (tests/golden/fullrun_*.npz, made by tests/golden/make_fullrun.py with
+one oracle process per partition).  Compared: every job's start / reason / placement records (CRC per 10 000 jobs),
+the fp64 cost bit pattern of every (partition, node) slot and the final time maps of a node sample (tests/fullrun.py).
+Unlike a prefix of the queue these runs reach the loaded-cluster regime: 24-74 % of the jobs are backfilled."""
+import os
+
+import numpy as np
+import pytest
+
+from cranesched_amd import synth
+from tests import fullrun
+from tests.golden.make_fullrun import CASES
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_full_run_matches_oracle_digest(engine_cls, tag):
+    path = os.path.join(GOLDEN, f"fullrun_{tag}.npz")
+    assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
+    ref = dict(np.load(path))
+    name, J, N, P = CASES[tag]
+    cluster, jobs, now = synth.make_config(name, J=J, N=N, P=P)
+    eng = engine_cls(device=0)
+    try:
+        eng.set_nodes(cluster)
+        got = eng.node_select(now, jobs)
+        d = fullrun.digest(got, eng.costs().view(np.uint64), eng.timeline, cluster.num_nodes)
+        msg = fullrun.compare(d, ref)
+        assert msg is None, f"{tag}: engine differs from the oracle's full run: {msg}"
+        t = eng.timing()
+        print(f"{tag}: {jobs.num_jobs} jobs x {cluster.num_nodes} nodes identical to the oracle "
+              f"(start-now {d['counts'][0]}, backfilled {d['counts'][1]}, failed {d['counts'][2]}); "
+              f"select {t['select_ms']:.1f} ms = {1e3 * jobs.num_jobs / t['select_ms']:.0f} decisions/s")
+    finally:
+        eng.close()
