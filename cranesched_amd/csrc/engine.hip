@@ -203,6 +203,22 @@ template <int NPL>
 void launch_select(cns_engine* h, const KParams& K) {
   hipLaunchKernelGGL((k_select<NPL>), dim3(h->P), dim3(kBlock), 0, h->stream, K, h->d_params.as<KParams>());
 }
+template <int NPL>
+void launch_pipe(cns_engine* h, const KParams& K) {
+  hipLaunchKernelGGL((k_pipe<NPL>), dim3(h->P), dim3(kPBlock), 0, h->stream, K, h->d_params.as<KParams>());
+}
+// Which selection kernel runs: k_pipe (decoupled test / commit pipeline) for partitions its tile covers, k_select
+// otherwise.  CNS_SELECT_KERNEL=legacy|pipe forces one (A/B measurements, and the parity tests run both).
+#ifndef CNS_DEFAULT_PIPE
+#define CNS_DEFAULT_PIPE 0
+#endif
+bool use_pipe_kernel(const cns_engine* h) {
+  const char* e = getenv("CNS_SELECT_KERNEL");
+  bool want = CNS_DEFAULT_PIPE != 0;
+  if (e && !strcmp(e, "legacy")) want = false;
+  if (e && !strcmp(e, "pipe")) want = true;
+  return want && h->max_np <= kPScan * (u32)kPNplMax;
+}
 
 // Everything that depends on the slot list (real + virtual): per-slot res_total / time-map end, node types
 // (= distinct res_total records), the device copies and the per-slot buffers.
@@ -684,6 +700,11 @@ int cns_run_resident(cns_handle* h, int64_t now) {
     launch_select<CNS_ONLY_NPL>(h, K);
 #else
     bool launched = false;
+    if (use_pipe_kernel(h)) {
+#define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; }
+      CNS_PNPL_LIST(CNS_TRY_PWIDTH)
+#undef CNS_TRY_PWIDTH
+    }
 #define CNS_TRY_WIDTH(w) if (!launched && np <= kScan * (w)) { launch_select<w>(h, K); launched = true; }
     CNS_NPL_LIST(CNS_TRY_WIDTH)
 #undef CNS_TRY_WIDTH

@@ -313,11 +313,14 @@ enum JobRecField : u32 {
   kJdRc32 = 36,   // min-view cpu clamped to the scanners' 32-bit front summary
   kJdRm16 = 37,   // min-view mem in GiB, rounded down, saturating at 0xFFFF
   kJdRq = 38,     // specified GRES counts per class as nibbles, saturating at 15 (like the node side)
-  kJdShape = 39,  // bit 0: ntasks != node_num, bit 1: tpn_min == 1, bit 2: satisfiable under the 32-bit summaries
+  kJdShape = 39,  // bit 0: ntasks != node_num, bit 1: tpn_min == 1, bit 2: satisfiable under the 32-bit summaries,
+                  // bit 3: untyped GRES of a name with several classes (which classes serve it depends on the node, :577-592)
   kJdGmode = 40,  // GRES request shape: 0 none; bit 0 one specified class, bit 1 one untyped total; 4 general
   kJdGsel = 41,   // nibble shift of that class | index of that name << 8
   kJdGneed = 42,  // its count | the total << 8, both saturated at 15
-  kJdTyok = 44    // u64: bit t = the minimum view fits res_total of node type t (:6171-6175, :6222-6223)
+  kJdTyok = 44,   // u64: bit t = the minimum view fits res_total of node type t (:6171-6175, :6222-6223)
+  kJdAcnt = 46    // GRES slots per class an allocation of the minimum view takes (nibbles, saturating at 15) — only
+                  // meaningful when kJdShape bit 3 is clear (the split over the classes does not depend on the node)
 };
 // ---------------------------------------------------------------------------------------------
 // k_pack_jobs: the caller's job SoA (uploaded as it is) -> dwords 0..29 of the 64-dword job records, grouped by
@@ -472,6 +475,24 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
       gneed = ((rq >> (4 * g0)) & 15u) | ((tot > 15u ? 15u : tot) << 8);
     }
   }
+  // per-class slot counts of GetFeasibleResourceInNode's allocation (:556-592) when they do not depend on the node
+  u32 acnt = 0;
+  bool dyn_gres = false;
+  if (flags & kJfGres) {
+    u64 cnt = nv.gspec;
+    for (u32 a = 0; a < (u32)kMaxNames; ++a) {
+      const u32 tot = (nv.gtot >> (8 * a)) & 0xFFu;
+      const u64 nb = P.gres.name_bytes[a];
+      const u32 ssum = byte_sum(nv.gspec & nb);
+      if (tot <= ssum) continue;
+      u32 ncls = 0, g0 = 0;
+      for (u32 g = 0; g < 8; ++g)
+        if ((nb >> (8 * g)) & 0xFFull) { ++ncls; g0 = g; }
+      if (ncls == 1) cnt += (u64)(tot - ssum) << (8 * g0);
+      else dyn_gres = true;
+    }
+    acnt = nibbles_of(cnt);
+  }
   u64 tyok = 0;
   for (u32 t = 0; t < P.num_types; ++t) {
     const Res tt = P.type_total[t];
@@ -483,13 +504,15 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
   rec[kJdRc32] = (u32)(mv.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)mv.cpu);
   rec[kJdRm16] = (mv.mem >> 30) > 0xFFFFull ? 0xFFFFu : (u32)(mv.mem >> 30);
   rec[kJdRq] = rq;
-  rec[kJdShape] = (ntasks != k ? 1u : 0u) | (tmin == 1 ? 2u : 0u) | (possible ? 4u : 0u);
+  rec[kJdShape] = (ntasks != k ? 1u : 0u) | (tmin == 1 ? 2u : 0u) | (possible ? 4u : 0u) | (dyn_gres ? 8u : 0u);
+  rec[kJdAcnt] = acnt;
   rec[kJdGmode] = gmode; rec[kJdGsel] = gsel; rec[kJdGneed] = gneed;
   rec[kJdTyok] = (u32)tyok; rec[kJdTyok + 1] = (u32)(tyok >> 32);
 }
 
 // slot code = row << 10 | t, t = scanner lane 0..kScan-1; partition-local slot = row * kScan + t
-__device__ __forceinline__ u32 slot_of_code(u32 code) { return (code >> 10) * kScan + (code & 1023u); }
+template <u32 kS> __device__ __forceinline__ u32 slot_of_code_t(u32 code) { return (code >> 10) * kS + (code & 1023u); }
+__device__ __forceinline__ u32 slot_of_code(u32 code) { return slot_of_code_t<kScan>(code); }
 // wave that owns the slot: scanner index t / 64 -> waves 1,2,3,5,6,7 (wave kIdleWave holds no nodes)
 __device__ __forceinline__ u32 owner_wave(u32 code) {
   const u32 sid = (code & 1023u) >> 6;
@@ -730,6 +753,7 @@ __device__ __forceinline__ i64 next_fit_regs(const TlEntry& e, u32 len, const Re
 // Shared by the "start now" and "backfill" endings of the general path: H[0..k) holds the selected
 // nodes with their assigned task counts and allocations; commits them into the time maps and costs,
 // emits the placement records (sorted by node index) and the owner updates.
+template <u32 kS = kScan>
 __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J, HeapEnt* H, u32 qbeg, i64 start,
                                  u32 lane, UpdRec* s_upd, int* s_nupd) {
   const i64 end = start + J.L;  // job->end_time = start_time + time_limit, JobScheduler.cpp:6772
@@ -737,7 +761,7 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
   const u64 poff = J.poff;
   for (u32 i = 0; i < J.k; ++i) {
     HeapEnt ent = H[i];
-    const u32 q = qbeg + slot_of_code(ent.p);
+    const u32 q = qbeg + slot_of_code_t<kS>(ent.p);
     NodeHdr* hd = hdr_of(P, q);
     const Res tot = hd->total;
     const Res e0 = tl_of(hd)[0].r;
@@ -923,6 +947,7 @@ struct WorkerShared {
 // multi-node jobs, ntasks > node_num (priority_queue emulation) and exclusive jobs.  Enters after the
 // round-0 barrier with the A and T winners, leaves after the job's last barrier; returns the LDS
 // double-buffer parity.
+template <u32 kS = kScan>
 __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared sh, const JobCtx* Jp, int par,
                                             u64 wc, u32 wcode, u64 tc, u32 tcode, u32 qbeg, HeapEnt* gheap) {
   const JobCtx J = *Jp;
@@ -944,7 +969,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   // ---- Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) -------------
   int hsize = 0, hsum = 0;  // topk_nodes_avail.size(), topk_ntasks_sum_avail
   while (wcode != kNone) {
-    const u32 q = qbeg + slot_of_code(wcode);
+    const u32 q = qbeg + slot_of_code_t<kS>(wcode);
     NodeHdr* const hd = hdr_of(P, q);
     TlEntry* const T = tl_of(hd);
     int code = 0;
@@ -985,7 +1010,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       code = 1;
       if (hsize == (int)J.k && (u32)hsum >= J.ntasks) {                   // :6294-6297
         if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 2, orig, n, 2); }
-        commit_selection(P, J, H, qbeg, P.now, lane, s_upd, s_nupd);      // start_time = now (:6326)
+        commit_selection<kS>(P, J, H, qbeg, P.now, lane, s_upd, s_nupd);      // start_time = now (:6326)
         if (lane == 0) { P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
         code = 2;
       }
@@ -1010,7 +1035,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   u64 cc = tc;
   u32 ccode = tcode;
   while (ccode != kNone) {
-    NodeHdr* const hd = hdr_of(P, qbeg + slot_of_code(ccode));
+    NodeHdr* const hd = hdr_of(P, qbeg + slot_of_code_t<kS>(ccode));
     HeapEnt x;
     x.p = ccode; x.node = hd->node; x.pad = 0;
     x.cost = __longlong_as_double((long long)cc);
@@ -1048,7 +1073,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     __threadfence_block();
     for (u32 i = lane; i < J.k; i += 64) {
       HeapEnt x = H[i];
-      x.res = hdr_of(P, qbeg + slot_of_code(x.p))->total;
+      x.res = hdr_of(P, qbeg + slot_of_code_t<kS>(x.p))->total;
       H[i] = x;
       P.bf_j[qbeg + i] = 0;
     }
@@ -1061,7 +1086,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       i64 Tm = t;
       for (u32 i = 0; i < J.k; ++i) {
         const HeapEnt x = H[i];
-        NodeHdr* hd = hdr_of(P, qbeg + slot_of_code(x.p));
+        NodeHdr* hd = hdr_of(P, qbeg + slot_of_code_t<kS>(x.p));
         const i64 sx = next_fit_wave(tl_of(hd), hd->len, &H[i].res, J.L, t);
         Tm = sx > Tm ? sx : Tm;
       }
@@ -1075,14 +1100,14 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
         bool notle = false, reserved = false;
         for (u32 i = lane; i < J.k; i += 64) {
           const HeapEnt x = H[i];
-          const u32 qx = qbeg + slot_of_code(x.p);
+          const u32 qx = qbeg + slot_of_code_t<kS>(x.p);
           if (!res_le(x.res, hdr_of(P, qx)->avail0)) notle = true;
           if (P.first_resv[qx] < P.now + J.L) reserved = true;
         }
         const bool resv_part = blockIdx.x >= P.num_real_parts;
         reason = (!resv_part && __any(reserved)) ? 3 /*Resource Reserved*/ : (__any(notle) ? 2 /*Resource*/ : 1 /*Priority*/);
       }
-      commit_selection(P, J, H, qbeg, t, lane, s_upd, s_nupd);
+      commit_selection<kS>(P, J, H, qbeg, t, lane, s_upd, s_nupd);
       if (lane == 0) { P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
       code = 2;
     }
@@ -1439,6 +1464,7 @@ __device__ __forceinline__ u64 bytes_of_nibbles(u32 nb) {
 
 // included / excluded node lists of a job (JobScheduler.cpp:6202-6220) for the nodes of one scanner lane
 // whose bit is set in bmask; out of line: rare, and it touches no tile register.
+template <u32 kS = kScan>
 __device__ __noinline__ u64 list_mask(const KParams* Pp, u32 flags, u64 ji, u64 bmask, u32 slot0, u32 npl) {
   const u32* rec = Pp->jobrec + ji * kJobRecDwords;  // rare path: the list bounds are read from the record itself
   const u64 incl_b = ((u64)rec[kJrInclB + 1] << 32) | rec[kJrInclB], incl_e = ((u64)rec[kJrInclE + 1] << 32) | rec[kJrInclE];
@@ -1446,7 +1472,7 @@ __device__ __noinline__ u64 list_mask(const KParams* Pp, u32 flags, u64 ji, u64 
   u64 lm = 0;
   for (u32 r = 0; r < npl; ++r) {
     if (!((bmask >> r) & 1ull)) continue;
-    const u32 n = Pp->slot_node[slot0 + r * kScan];
+    const u32 n = Pp->slot_node[slot0 + r * kS];
     bool okl = true;
     if ((flags & kJfIncl) && !in_list(Pp->incl_nodes, incl_b, incl_e, n)) okl = false;
     if ((flags & kJfExcl) && in_list(Pp->excl_nodes, excl_b, excl_e, n)) okl = false;
@@ -2282,6 +2308,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     }
   }
 }
+
+#include "pipe_kernel.inc"
 
 #ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
 template __global__ void k_select<CNS_ONLY_NPL>(const KParams, const KParams*);

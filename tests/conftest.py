@@ -20,10 +20,13 @@ def built():
     return g
 
 
-@pytest.fixture(scope="session")
-def engine_cls(built):
+@pytest.fixture(params=["legacy", "pipe"])
+def engine_cls(built, request, monkeypatch):
+    """The engine class, once per selection kernel: k_select (one worker wave carries test + commit) and k_pipe
+    (decoupled test / commit pipeline).  The library reads CNS_SELECT_KERNEL at every run."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    monkeypatch.setenv("CNS_SELECT_KERNEL", request.param)
     from cranesched_amd.engine import GpuNodeSelector
     return GpuNodeSelector
