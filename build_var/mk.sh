@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: mk.sh name [extra -D flags]   (experiment build; pass -DCNS_ONLY_NPL=<w> to compile one tile width only)
-n=$1; shift
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared -I../include \
-  "$@" ../cranesched_amd/csrc/engine.hip -o v_$n.so 2> v_$n.log && echo built $n
+# experiment builds of the engine: build_var/mk.sh <tag> <extra hipcc flags...>  ->  build_var/v_<tag>.so
+tag=$1; shift
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared "$@" cranesched_amd/csrc/engine.hip -o build_var/v_$tag.so 2> build_var/$tag.log || { tail -20 build_var/$tag.log; exit 1; }
+echo built v_$tag.so

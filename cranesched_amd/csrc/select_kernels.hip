@@ -319,8 +319,13 @@ enum JobRecField : u32 {
   kJdGsel = 41,   // nibble shift of that class | index of that name << 8
   kJdGneed = 42,  // its count | the total << 8, both saturated at 15
   kJdTyok = 44,   // u64: bit t = the minimum view fits res_total of node type t (:6171-6175, :6222-6223)
-  kJdAcnt = 46    // GRES slots per class an allocation of the minimum view takes (nibbles, saturating at 15) — only
+  kJdAcnt = 46,   // GRES slots per class an allocation of the minimum view takes (nibbles, saturating at 15) — only
                   // meaningful when kJdShape bit 3 is clear (the split over the classes does not depend on the node)
+  // k_pipe's scanners read everything they need from 12 consecutive dwords (12 v_readlane instead of 35):
+  kJsHead = 48,   // flags | min(node_num, 0xFFFF) << 8 | shape << 24
+  kJsRc32 = 49, kJsMem = 50 /* rm16 | dm16 << 16 (min-view mem in whole GiB, rounded down) */, kJsRq = 51, kJsGtot = 52,
+  kJsGres = 53,   // gmode | gsel << 4 | gneed << 16
+  kJsL = 54, kJsAcnt = 56, kJsTyok = 58
 };
 // ---------------------------------------------------------------------------------------------
 // k_pack_jobs: the caller's job SoA (uploaded as it is) -> dwords 0..29 of the 64-dword job records, grouped by
@@ -506,6 +511,19 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
   rec[kJdRq] = rq;
   rec[kJdShape] = (ntasks != k ? 1u : 0u) | (tmin == 1 ? 2u : 0u) | (possible ? 4u : 0u) | (dyn_gres ? 8u : 0u);
   rec[kJdAcnt] = acnt;
+  {
+    const u64 mgib = mv.mem >> 30;
+    const u32 rm16 = mgib > 0xFFFFull ? 0xFFFFu : (u32)mgib;
+    const u32 shape = (ntasks != k ? 1u : 0u) | (tmin == 1 ? 2u : 0u) | (possible ? 4u : 0u) | (dyn_gres ? 8u : 0u);
+    rec[kJsHead] = (flags & 0xFFu) | ((k > 0xFFFFu ? 0xFFFFu : k) << 8) | (shape << 24);
+    rec[kJsRc32] = (u32)(mv.cpu > 0x7FFFFFFFll ? 0x7FFFFFFF : (int)mv.cpu);
+    rec[kJsMem] = rm16 | (rm16 << 16);
+    rec[kJsRq] = rq; rec[kJsGtot] = nv.gtot;
+    rec[kJsGres] = gmode | (gsel << 4) | (gneed << 16);
+    rec[kJsL] = rec[kJrL]; rec[kJsL + 1] = rec[kJrL + 1];
+    rec[kJsAcnt] = acnt; rec[kJsAcnt + 1] = 0;
+    rec[kJsTyok] = (u32)tyok; rec[kJsTyok + 1] = (u32)(tyok >> 32);
+  }
   rec[kJdGmode] = gmode; rec[kJdGsel] = gsel; rec[kJdGneed] = gneed;
   rec[kJdTyok] = (u32)tyok; rec[kJdTyok + 1] = (u32)(tyok >> 32);
 }

@@ -19,9 +19,10 @@ t = e.timing(); pr = e.prof().astype(np.float64)
 jobs = j.num_jobs / c.num_partitions
 m = pr.mean(axis=0)
 print(f"{name} J={j.num_jobs} N={c.num_nodes} P={c.num_partitions}: selection kernel {t['select_ms']:.1f} ms = "
-      f"{1e3*t['select_ms']/jobs:.2f} us/job/partition; selector loop {m[19]/jobs:.0f} cycles/job")
-per_job = {0: "selector: waiting for the scan", 1: "selector: decision + posting", 4: "selector: serial-mode jobs",
-           6: "selector: waiting for a task slot", 16: "scanner w6: update + scan + publish", 17: "scanner w6: waiting for a command"}
+      f"{1e3*t['select_ms']/jobs:.2f} us/job/partition; supervisor loop {m[19]/jobs:.0f} cycles/job")
+per_job = {1: "supervisor: decision -> task", 4: "supervisor: serial-mode jobs", 6: "supervisor: waiting for a task slot",
+           16: "scanner w0: whole job (autonomous)", 17: "scanner w0: waiting for a command", 22: "scanner w0:   row loop",
+           23: "scanner w0:   wave argmins", 24: "scanner w0:   publish + exchange wait", 20: "scanner w0:   decision + own-row update"}
 for k, v in per_job.items():
     print(f"  {v:40s} {m[k]/jobs:10.0f} cyc/job")
 print(f"  {'#tasks':40s} {m[5]:10.0f}   #serial jobs {m[2]:.0f}   #flushes {m[3]:.0f}   #scans (w6) {m[18]:.0f}")
