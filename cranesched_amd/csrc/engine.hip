@@ -210,7 +210,7 @@ void launch_pipe(cns_engine* h, const KParams& K) {
 // Which selection kernel runs: k_pipe (decoupled test / commit pipeline) for partitions its tile covers, k_select
 // otherwise.  CNS_SELECT_KERNEL=legacy|pipe forces one (A/B measurements, and the parity tests run both).
 #ifndef CNS_DEFAULT_PIPE
-#define CNS_DEFAULT_PIPE 0
+#define CNS_DEFAULT_PIPE 1
 #endif
 bool use_pipe_kernel(const cns_engine* h) {
   const char* e = getenv("CNS_SELECT_KERNEL");
