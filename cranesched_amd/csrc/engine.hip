@@ -62,7 +62,17 @@ struct cns_engine {
   u32 N = 0, P = 0, S = 0, T = 0, max_np = 0;
   bool big_nodes = false;  // any GRES or > 64 cores (48-byte node record in the traffic model)
   std::vector<u32> part_off, slot_node, orig_pos_slot;  // orig_pos_slot: caller's part_nodes position -> slot or kNone
-  std::vector<u32> node_slot;
+  std::vector<u32> node_slot;                 // node -> its PRIMARY slot (the one whose NodeBlock holds the shared time map)
+  // Overlapping partitions (one NodeState per craned shared by every partition that lists it, one cost per partition:
+  // JobScheduler.cpp:6585-6615, JobScheduler.h:498-516): partitions connected through shared nodes form ONE engine
+  // partition (workgroup) that runs their jobs in queue order; a node then has one slot per member partition.
+  u32 Pu = 0;                                 // partitions of the caller
+  bool shared = false;                        // some node belongs to several partitions
+  std::vector<u32> upart_eng, upart_size;     // caller's partition -> engine partition, its schedulable node count
+  std::vector<uint8_t> upart_tag;             // ... and its member tag inside that engine partition
+  std::vector<std::vector<u32>> node_slots;   // node -> all its slots
+  std::vector<uint8_t> slot_tag;              // slot -> member tag
+  DevBuf d_slot_block, d_sib_off, d_sib, d_type_tag, d_jtag;
   GresDev gres{};
   bool have_nodes = false, have_jobs = false, have_run = false;
 
@@ -197,6 +207,10 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.fault = h->d_fault.as<u32>();
   K.prof = h->d_prof.as<u64>();
   K.gres = h->gres;
+  if (h->shared) {
+    K.slot_block = h->d_slot_block.as<u32>(); K.sib_off = h->d_sib_off.as<u32>(); K.sib = h->d_sib.as<u32>();
+    K.slot_tag = h->d_type_tag.as<uint8_t>();
+  }
 }
 
 template <int NPL>
@@ -217,7 +231,7 @@ bool use_pipe_kernel(const cns_engine* h) {
   bool want = CNS_DEFAULT_PIPE != 0;
   if (e && !strcmp(e, "legacy")) want = false;
   if (e && !strcmp(e, "pipe")) want = true;
-  return want && h->max_np <= kPScan * (u32)kPNplMax;
+  return want && !h->shared && h->max_np <= kPScan * (u32)kPNplMax;   // (shared nodes: k_select's sequential protocol)
 }
 
 // Everything that depends on the slot list (real + virtual): per-slot res_total / time-map end, node types
@@ -235,6 +249,7 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
   std::vector<uint8_t> slot_type(std::max<u32>(S, 1), 0);
+  h->slot_tag.resize(S, 0);   // virtual (reservation) slots: tag 0
   for (u32 q = 0; q < S; ++q) {
     const Res& r = h->slot_total[q];
     auto key = std::make_tuple(r.cpu, r.mem, r.clo, r.chi, r.gres);
@@ -248,6 +263,23 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
     slot_type[q] = (uint8_t)it->second;
   }
   h->T = (u32)type_total.size();
+  if (h->shared) {
+    std::vector<u32> slot_block(S), sib_off(S + 1, 0), sib;
+    for (u32 q = 0; q < S; ++q) {
+      slot_block[q] = q;
+      if (q < h->S_real) {
+        const auto& all = h->node_slots[h->slot_node[q]];
+        slot_block[q] = all.front();
+        for (u32 o : all) if (o != q) sib.push_back(o);
+      }
+      sib_off[q + 1] = (u32)sib.size();
+    }
+    if (sib.empty()) sib.push_back(0);
+    if (int rc = upload(h, h->d_slot_block, slot_block)) return rc;
+    if (int rc = upload(h, h->d_sib_off, sib_off)) return rc;
+    if (int rc = upload(h, h->d_sib, sib)) return rc;
+    if (int rc = upload(h, h->d_type_tag, h->slot_tag)) return rc;   // per slot: member partition inside the group
+  }
   std::vector<i64> resv_se(2 * std::max<u32>(h->V, 1), 0);
   for (u32 v = 0; v < h->V; ++v) { resv_se[2 * v] = h->resv_start[v]; resv_se[2 * v + 1] = h->resv_end[v]; }
   if (int rc = upload(h, h->d_part_off, h->part_off)) return rc;
@@ -339,6 +371,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
+  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag}) b->release();
   for (DevBuf& b : h->d_prio) b.release();
   for (DevBuf& b : h->d_lim) b.release();
   for (DevBuf& b : h->d_raw) b.release();
@@ -357,7 +390,8 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   HIPCHK(h, hipSetDevice(h->device));
   if (int rc = build_gres(h, nd->gres)) return rc;
   h->have_nodes = h->have_jobs = h->have_run = false;
-  const u32 N = nd->num_nodes, P = nd->num_partitions;
+  const u32 N = nd->num_nodes;
+  u32 P = nd->num_partitions;
   std::vector<Res> total(N);
   u64 all_gres = 0;
   for (u32 c = 0; c < h->gres.num_classes; ++c) all_gres |= h->gres.class_mask[c];
@@ -371,39 +405,77 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
     if (total[n].gres & ~all_gres) return fail(h, CNS_ERR_INVALID_ARG, "node GRES slot outside every class");
     if (total[n].gres || total[n].chi) big = true;
   }
-  // partitions: schedulable nodes only, ascending dense index (= canonical cost tie-break), disjoint
-  std::vector<u32> part_off(P + 1, 0), slot_node, node_slot(N, kNone);
+  // partitions: schedulable nodes only, ascending dense index (= canonical cost tie-break).  Partitions that share a
+  // node are merged into one engine partition (union-find over the shared nodes); without sharing the engine
+  // partitions are the caller's, one to one.
   const u32 total_pos = nd->part_offsets[P];
-  std::vector<u32> orig_pos_slot(total_pos, kNone);
-  u32 max_np = 0;
+  std::vector<std::vector<std::pair<u32, u32>>> plist(P);  // per caller partition: (node, original position)
+  std::vector<u32> uf(P);
+  for (u32 p = 0; p < P; ++p) uf[p] = p;
+  auto find = [&](u32 x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+  std::vector<u32> first_part(N, kNone);
+  bool shared = false;
   for (u32 p = 0; p < P; ++p) {
     if (nd->part_offsets[p + 1] < nd->part_offsets[p]) return fail(h, CNS_ERR_INVALID_ARG, "part_offsets not monotone");
-    std::vector<std::pair<u32, u32>> lst;  // (node, original position)
+    auto& lst = plist[p];
     for (u32 i = nd->part_offsets[p]; i < nd->part_offsets[p + 1]; ++i) {
       u32 n = nd->part_nodes[i];
       if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "part_nodes entry >= num_nodes");
       if (nd->schedulable && !nd->schedulable[n]) continue;  // JobScheduler.cpp:6595
+      if (total[n].cpu <= 0 || total[n].cpu >= 0x7FFFFFFEll)
+        return fail(h, CNS_ERR_UNSUPPORTED, "node cpu_total_raw must be in (0, 2^31-2)");
       lst.emplace_back(n, i);
     }
     std::sort(lst.begin(), lst.end());
-    part_off[p] = (u32)slot_node.size();
+    for (size_t i = 1; i < lst.size(); ++i)
+      if (lst[i].first == lst[i - 1].first) return fail(h, CNS_ERR_INVALID_ARG, "node listed twice in one partition");
     for (auto& [n, pos] : lst) {
-      if (node_slot[n] != kNone)
-        return fail(h, CNS_ERR_UNSUPPORTED,
-                    "node " + std::to_string(n) + " belongs to more than one partition (overlapping partitions "
-                    "share a NodeState; not supported by this engine yet)");
-      if (total[n].cpu <= 0 || total[n].cpu >= 0x7FFFFFFEll)
-        return fail(h, CNS_ERR_UNSUPPORTED, "node cpu_total_raw must be in (0, 2^31-2)");
-      node_slot[n] = (u32)slot_node.size();
-      orig_pos_slot[pos] = (u32)slot_node.size();
-      slot_node.push_back(n);
+      if (first_part[n] == kNone) first_part[n] = p;
+      else { shared = true; u32 a = find(first_part[n]), b = find(p); if (a != b) uf[std::max(a, b)] = std::min(a, b); }
     }
-    max_np = std::max<u32>(max_np, (u32)lst.size());
   }
-  part_off[P] = (u32)slot_node.size();
+  std::vector<u32> upart_eng(P), upart_size(P);
+  std::vector<uint8_t> upart_tag(P, 0);
+  std::vector<std::vector<u32>> members;  // engine partition -> caller partitions, ascending
+  {
+    std::vector<u32> eng_of_root(P, kNone);
+    for (u32 p = 0; p < P; ++p) {
+      const u32 r = find(p);
+      if (eng_of_root[r] == kNone) { eng_of_root[r] = (u32)members.size(); members.emplace_back(); }
+      upart_eng[p] = eng_of_root[r];
+      if (members[upart_eng[p]].size() >= 255) return fail(h, CNS_ERR_UNSUPPORTED, "more than 255 partitions connected through shared nodes");
+      upart_tag[p] = (uint8_t)members[upart_eng[p]].size();
+      members[upart_eng[p]].push_back(p);
+      upart_size[p] = (u32)plist[p].size();
+    }
+  }
+  const u32 PE = (u32)members.size();
+  std::vector<u32> part_off(PE + 1, 0), slot_node, node_slot(N, kNone);
+  std::vector<std::vector<u32>> node_slots(N);
+  std::vector<uint8_t> slot_tag;
+  std::vector<u32> orig_pos_slot(total_pos, kNone);
+  u32 max_np = 0;
+  for (u32 e = 0; e < PE; ++e) {
+    part_off[e] = (u32)slot_node.size();
+    for (u32 p : members[e])
+      for (auto& [n, pos] : plist[p]) {
+        const u32 q = (u32)slot_node.size();
+        if (node_slot[n] == kNone) node_slot[n] = q;
+        node_slots[n].push_back(q);
+        orig_pos_slot[pos] = q;
+        slot_node.push_back(n);
+        slot_tag.push_back(upart_tag[p]);
+      }
+    max_np = std::max<u32>(max_np, (u32)slot_node.size() - part_off[e]);
+  }
+  part_off[PE] = (u32)slot_node.size();
   const u32 S = (u32)slot_node.size();
   if (max_np > kScan * (u32)CNS_NPL_MAX)
-    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(kScan * CNS_NPL_MAX) + " schedulable nodes");
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition (or group of partitions sharing nodes) with more than " +
+                                            std::to_string(kScan * CNS_NPL_MAX) + " schedulable (partition, node) slots");
+  h->Pu = P; h->shared = shared; h->upart_eng = upart_eng; h->upart_size = upart_size; h->upart_tag = upart_tag;
+  h->node_slots = node_slots; h->slot_tag = slot_tag;
+  P = PE;
   h->N = N; h->P = P; h->S = S; h->max_np = max_np; h->big_nodes = big;
   h->P_real = P; h->S_real = S; h->V = 0;
   h->part_off = part_off; h->slot_node = slot_node; h->node_slot = node_slot; h->orig_pos_slot = orig_pos_slot;
@@ -458,7 +530,7 @@ int cns_set_reservations(cns_handle* h, const cns_resv_soa* rv) {
       h->resv_node_slot[v][n] = (u32)h->slot_node.size();  // virtual node: its own NodeState (:6661-6664)
       h->slot_node.push_back(n);
       virt_total.push_back(r);
-      if (h->node_slot[n] != kNone) per_slot[h->node_slot[n]].emplace_back(rv->start_sec[v], rv->end_sec[v], r);
+      for (u32 q : h->node_slots[n]) per_slot[q].emplace_back(rv->start_sec[v], rv->end_sec[v], r);   // every partition's slot of the node
     }
     h->part_off.push_back((u32)h->slot_node.size());
     h->max_np = std::max<u32>(h->max_np, (u32)al.size());
@@ -488,12 +560,17 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
   const u32 N = h->N, S = h->S;
   // allocations are grouped by SLOT: the node's own slot, or — for a job running inside a reservation
   // (JobScheduler.cpp:6692-6707) — the reservation's virtual node
-  auto slot_of = [&](u32 job, u32 n) -> u32 {
+  // (slots of the node: one per partition that lists it — they all start from the same NodeState, JobScheduler.h:498-511)
+  static const std::vector<u32> kNoSlots;
+  std::vector<u32> one(1);
+  auto slots_of = [&](u32 job, u32 n) -> const std::vector<u32>& {
     const u32 v = rn->reservation ? rn->reservation[job] : CNS_RESV_NONE;
-    if (v == CNS_RESV_NONE) return h->node_slot[n];  // kNone: unschedulable node, ignored (:6685-6686)
-    if (v >= h->V) return kNone;                      // reservation not found (:6693-6700)
+    if (v == CNS_RESV_NONE) return h->node_slots[n];  // empty: unschedulable node, ignored (:6685-6686)
+    if (v >= h->V) return kNoSlots;                    // reservation not found (:6693-6700)
     auto it = h->resv_node_slot[v].find(n);
-    return it == h->resv_node_slot[v].end() ? kNone : it->second;
+    if (it == h->resv_node_slot[v].end()) return kNoSlots;
+    one[0] = it->second;
+    return one;
   };
   std::vector<u32> rn_off(S + 1, 0);
   std::vector<i64> rn_end;
@@ -507,8 +584,7 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
       for (u32 a = rn->alloc_offsets[j]; a < rn->alloc_offsets[j + 1]; ++a) {
         const u32 n = rn->alloc_node[a];
         if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "running allocation on node >= num_nodes");
-        const u32 q = slot_of(j, n);
-        if (q != kNone) rn_off[q + 1]++;
+        for (u32 q : slots_of(j, n)) rn_off[q + 1]++;
       }
     for (u32 q = 0; q < S; ++q) {
       const u32 nrv = h->rv_off[q + 1] - h->rv_off[q];
@@ -521,17 +597,17 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
     std::vector<u32> cur(rn_off.begin(), rn_off.end() - 1);
     for (u32 j = 0; j < rn->num_jobs; ++j)  // stable: per slot, input order (cost accumulation order)
       for (u32 a = rn->alloc_offsets[j]; a < rn->alloc_offsets[j + 1]; ++a) {
-        const u32 q = slot_of(j, rn->alloc_node[a]);
-        if (q == kNone) continue;
-        u32 d = cur[q]++;
-        rn_end[d] = rn->end_sec[j];
         Res r;
         r.cpu = rn->alloc_cpu_raw[a];
         r.mem = rn->alloc_mem[a];
         r.clo = rn->alloc_core_lo[a];
         r.chi = rn->alloc_core_hi ? rn->alloc_core_hi[a] : 0;
         r.gres = rn->alloc_gres ? rn->alloc_gres[a] : 0;
-        rn_res[d] = r;
+        for (u32 q : slots_of(j, rn->alloc_node[a])) {
+          u32 d = cur[q]++;
+          rn_end[d] = rn->end_sec[j];
+          rn_res[d] = r;
+        }
       }
   }
   if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
@@ -581,12 +657,13 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
       if (rsv >= h->V) { reason[j] = CNS_REASON_RESERVATION_NOT_FOUND; continue; }
       p = h->P_real + rsv;
     } else {
-      if (jb->partition[j] >= h->P_real) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
-      p = jb->partition[j];
+      if (jb->partition[j] >= h->Pu) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
+      p = h->upart_eng[jb->partition[j]];   // the engine partition that runs the job's partition (its group, if it shares nodes)
     }
     part_of[j] = p;
     pj_cnt[p + 1]++;
-    algo += (u64)(h->part_off[p + 1] - h->part_off[p]) * s_node + 64 + 16 + 24ull * k;
+    const u64 np = rsv != CNS_RESV_NONE ? (u64)(h->part_off[p + 1] - h->part_off[p]) : (u64)h->upart_size[jb->partition[j]];
+    algo += np * s_node + 64 + 16 + 24ull * k;
   }
   h->place_off[J] = places;
   std::vector<u64> pj_off(h->P + 1, 0);
@@ -631,6 +708,12 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   if (jb->excl_offsets) { if (int rc = raw(rb_[13], jb->excl_offsets, (J + 1) * 8)) return rc; }
   if (int rc = raw(rb_[14], h->place_off.data(), (J + 1) * 8)) return rc;
   if (int rc = upload(h, rb_[15], grouped)) return rc;
+  if (h->shared) {
+    std::vector<uint8_t> jtag((size_t)std::max<u64>(J, 1), 0);
+    for (u64 j = 0; j < J; ++j)
+      if ((!jb->reservation || jb->reservation[j] == CNS_RESV_NONE) && jb->partition[j] < h->Pu) jtag[(size_t)j] = h->upart_tag[jb->partition[j]];
+    if (int rc = upload(h, h->d_jtag, jtag)) return rc;
+  }
   const u64 n_incl = jb->incl_offsets ? jb->incl_offsets[J] : 0, n_excl = jb->excl_offsets ? jb->excl_offsets[J] : 0;
   HIPCHK(h, h->d_incl.ensure(std::max<u64>(n_incl, 1) * 4));
   HIPCHK(h, h->d_excl.ensure(std::max<u64>(n_excl, 1) * 4));
@@ -647,6 +730,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
     K.gtot = jb->gres_total ? rb_[10].as<uint8_t>() : nullptr; K.gspec = jb->gres_spec ? rb_[11].as<uint8_t>() : nullptr;
     K.incl_off = jb->incl_offsets ? rb_[12].as<u64>() : nullptr; K.excl_off = jb->excl_offsets ? rb_[13].as<u64>() : nullptr;
     K.place_off = rb_[14].as<u64>(); K.jobrec = h->d_jobs.as<u32>();
+    K.tag = h->shared ? h->d_jtag.as<uint8_t>() : nullptr;
     hipLaunchKernelGGL(k_pack_jobs, dim3((unsigned)((Jg + 255) / 256)), dim3(256), 0, h->stream, K);
     HIPCHK(h, hipGetLastError());
   }

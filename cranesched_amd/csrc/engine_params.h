@@ -73,7 +73,7 @@ struct UpdRec {  // what the owning scanner lane must refresh after a commit
   int fcpu;
   u32 fmem;
   u64 fcnt;
-  u32 has_front;
+  u32 has_front;   // bit 0: the front summary changed; bit 1: keep the cost (the slot of ANOTHER partition on a shared node)
   u32 pad;
 };
 
@@ -130,6 +130,11 @@ struct KParams {
   u32* fault;              // [4] != 0: an internal invariant failed (code, job, aux, aux)
   u64* prof;               // [P*32] cycle counters (only written by -DCNS_PROF builds)
   GresDev gres;
+  // ---- partitions that share nodes (null otherwise) ----------------------------------------------------------------
+  const u32* slot_block;   // [S] slot whose NodeBlock holds the node's (shared) time map = the node's first slot
+  const u32* sib_off;      // [S+1] the other slots of the same node (other partitions of the group) ...
+  const u32* sib;          //       ... CSR
+  const uint8_t* slot_tag; // [S] which partition of its group a slot belongs to (a job only sees the slots of its own partition)
 };
 
 }  // namespace cns

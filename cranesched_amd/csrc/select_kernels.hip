@@ -177,7 +177,13 @@ __device__ __forceinline__ void set_fault(const KParams& P, u32 code, u32 a, u32
 }
 __device__ __forceinline__ Res res_zero() { Res r; r.cpu = 0; r.mem = 0; r.clo = 0; r.chi = 0; r.gres = 0; return r; }
 
-__device__ __forceinline__ NodeHdr* hdr_of(const KParams& P, u32 q) { return (NodeHdr*)(P.blocks + (u64)q * P.block_stride); }
+// The NodeBlock of slot q.  When partitions share nodes (P.slot_block != null) every slot of a node points at the block
+// of the node's first slot: ONE time map per craned, whatever partition a job came through (JobScheduler.cpp:6563,6609-6617).
+__device__ __forceinline__ NodeHdr* hdr_raw(const KParams& P, u32 q) { return (NodeHdr*)(P.blocks + (u64)q * P.block_stride); }
+__device__ __forceinline__ NodeHdr* hdr_of(const KParams& P, u32 q) {
+  if (P.slot_block) q = P.slot_block[q];
+  return hdr_raw(P, q);
+}
 __device__ __forceinline__ TlEntry* tl_of(NodeHdr* h) { return (TlEntry*)((char*)h + sizeof(NodeHdr)); }
 
 // ---------------------------------------------------------------------------------------------
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
   const i64 end_h = P.slot_end[q];
   Res a0 = tot;
   double cost = 0.0;
-  NodeHdr* hd = hdr_of(P, q);
+  NodeHdr* hd = hdr_raw(P, q);      // (a secondary slot of a shared node builds a private copy nobody reads: same values)
   TlEntry* T = tl_of(hd);           // T[i].t / T[i].r: change times and what is RELEASED there
   TlEntry* A2 = T + kTlCap / 2;     // A2[i].r: what is ALLOCATED at T[i].t (only with reservations; host bounds the count)
   u32 len = 1;  // T[0] reserved for {now, avail0}
@@ -340,6 +346,7 @@ struct PackParams {
   const uint8_t* excl; const uint8_t* gtot; const uint8_t* gspec;
   const u64* incl_off; const u64* excl_off; const u64* place_off;
   u32* jobrec;
+  const uint8_t* tag;   // member tag of the job's partition inside its group (null: no partitions share nodes)
 };
 __global__ __launch_bounds__(256) void k_pack_jobs(const PackParams P) {
   const u64 i = (u64)blockIdx.x * 256 + threadIdx.x;
@@ -353,6 +360,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackParams P) {
   if (P.gspec) { const uint8_t* g = P.gspec + j * 8; for (u32 c = 0; c < 8; ++c) gs |= (u64)g[c] << (8 * c); }
   if (gt | gs) flags |= kJfGres;
   if (P.excl && P.excl[j]) flags |= kJfExclusive;
+  if (P.tag) flags |= (u32)P.tag[j] << 8;
   u64 ib = 0, ie = 0, eb = 0, ee = 0;
   if (P.incl_off) { ib = P.incl_off[j]; ie = P.incl_off[j + 1]; if (ie > ib) flags |= kJfIncl; else ie = ib; }
   if (P.excl_off) { eb = P.excl_off[j]; ee = P.excl_off[j + 1]; if (ee > eb) flags |= kJfExcl; else ee = eb; }
@@ -777,6 +785,7 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
   const i64 end = start + J.L;  // job->end_time = start_time + time_limit, JobScheduler.cpp:6772
   const u32 orig = J.orig;
   const u64 poff = J.poff;
+  u32 nup = J.k;
   for (u32 i = 0; i < J.k; ++i) {
     HeapEnt ent = H[i];
     const u32 q = qbeg + slot_of_code_t<kS>(ent.p);
@@ -804,8 +813,24 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
       if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
       s_upd[i] = u;
     }
+    if (P.sib_off) {
+      // the node's slots in the OTHER partitions of the group see the same time map: new length and front summary,
+      // their own cost untouched (NodeRater.cost is per selector, JobScheduler.h:498-516); listed after the k own records
+      for (u32 a = P.sib_off[q]; a < P.sib_off[q + 1]; ++a) {
+        const u32 qs = P.sib[a];
+        if (lane == 0) {
+          UpdRec us = u;
+          const u32 ps = qs - qbeg;
+          us.p = ((ps / kS) << 10) | (ps % kS);
+          us.has_front = u.has_front | 2u;
+          if (u.has_front) { P.f_cpu[qs] = u.fcpu; P.f_mem[qs] = u.fmem; P.f_cnt[qs] = u.fcnt; }
+          s_upd[nup] = us;
+        }
+        ++nup;
+      }
+    }
   }
-  if (lane == 0) *s_nupd = (int)J.k;
+  if (lane == 0) *s_nupd = (int)nup;
   // placement records, ascending node index: rank = #selected nodes with a smaller index
   for (u32 i = lane; i < J.k; i += 64) {
     const HeapEnt me = H[i];
@@ -981,7 +1006,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   }
   const u32 orig = J.orig;
   HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
-  UpdRec* const s_upd = (J.k <= (u32)kMaxUpd) ? sh.upd : P.g_upd + qbeg;  // long lists go through HBM
+  UpdRec* const s_upd = (J.k <= (u32)kMaxUpd && !P.sib_off) ? sh.upd : P.g_upd + qbeg;  // long lists (and sibling slots of shared nodes) go through HBM
   int* const s_nupd = sh.nupd;
 
   // ---- Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) -------------
@@ -1033,7 +1058,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
         code = 2;
       }
     }
-    if (J.k > (u32)kMaxUpd) __threadfence_block();  // the owner updates went through HBM (g_upd)
+    if (J.k > (u32)kMaxUpd || P.sib_off) __threadfence_block();  // the owner updates went through HBM (g_upd)
     if (lane == 0) *sh.flag = code;
     wg_barrier();  // B2: verdict (and, on success, the owner updates) visible to the scanners
     if (code == 2) return par;
@@ -1131,7 +1156,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     }
   }
   if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
-  if (J.k > (u32)kMaxUpd) __threadfence_block();  // the owner updates went through HBM (g_upd)
+  if (J.k > (u32)kMaxUpd || P.sib_off) __threadfence_block();  // the owner updates went through HBM (g_upd)
   if (lane == 0) *sh.flag = code;
   wg_barrier();  // B3
   return par;
@@ -1606,7 +1631,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       PROF_T(p0);
       const FastJob F = make_fast_job(P, raw);
       const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
-      const bool fast = simple && F.k == 1 && F.tmin == 1;
+      const bool shared_nodes = P.sib_off != nullptr;   // partitions that share nodes: everything through the general path
+      const bool fast = simple && F.k == 1 && F.tmin == 1 && !shared_nodes;
 
       if (!pre_valid) {
         wg_barrier();  // B1 (round 0): A and T argmins published by the scanners
@@ -1764,7 +1790,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         job_to_lds(PG, ji, raw, &s_job);
         PROF_T(d1);
         PROF_ADD(24, d0, d1);  // job record -> LDS
-        if (simple && F.k > 1 && F.k <= (u32)kMultiK && F.tmin == 1) {
+        if (simple && F.k > 1 && F.k <= (u32)kMultiK && F.tmin == 1 && !shared_nodes) {
           // ---- multi-node job, parallel protocol: every scanner wave lists its k best candidates, the
           // worker merges the 15 sorted lists into the first k nodes in cost order, then the candidates are
           // verified and committed in parallel, one helper wave per node ----------------------------------
@@ -1833,7 +1859,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_T(p8);
           PROF_ADD(6, d0, p8);
           PROF_CNT(15);
-        } else if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1) {
+        } else if (simple && F.k > 1 && F.k <= (u32)kMaxUpd && F.tmin == 1 && !shared_nodes) {
           par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);  // 15 < k <= 32: sequential protocol
           PROF_T(p8);
           PROF_ADD(6, d0, p8);
@@ -1908,7 +1934,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         const NodeHdr* hd = hdr_of(P, q);
         cost[r] = P.cost[q];
         fcpu[r] = P.f_cpu[q];
-        mw[r] = mem_gib16(P.f_mem[q]) | (hd->len << 16) | (hd->type << 26);
+        mw[r] = mem_gib16(P.f_mem[q]) | (hd->len << 16) | ((u32)P.slot_type[q] << 26);
         gn[r] = nibbles_of(P.f_cnt[q]);
       } else {
         cost[r] = 0.0; fcpu[r] = 0; mw[r] = 1023u << 16; gn[r] = 0;
@@ -1932,6 +1958,18 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       if (len != 1023u) wave_types |= 1ull << (mw[r] >> 26);
     }
     wave_types = wave_or_u64(wave_types);
+    // Partitions that share nodes run as ONE group: a row then belongs to one member partition (byte r of tg) and a job
+    // only sees the rows of its own partition (its tag sits in bits 8..15 of the job flags).
+    u32 tg[(NPL + 3) / 4];
+#pragma unroll
+    for (int x = 0; x < (NPL + 3) / 4; ++x) tg[x] = 0;
+    if (P.slot_tag) {
+#pragma unroll
+      for (int r = 0; r < NPL; ++r) {
+        const u32 p = (u32)r * kScan + t;
+        if (!idle && p < nn) tg[r / 4] |= (u32)P.slot_tag[qbeg + p] << (8 * (r % 4));
+      }
+    }
 
     // What a scanner keeps of a job: the request side of the filters, ~10 scalars (the full JobCtx only
     // exists in LDS for the out-of-line paths).  Decoded from the lane-striped record with v_readlane.
@@ -2015,6 +2053,13 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         tybits = 0;
 #pragma unroll
         for (int r = 0; r < NPL; ++r) tybits |= (RM)((tyok >> (mw[r] >> 26)) & 1ull) << r;
+      }
+      if (P.slot_tag) {   // (uniform) only the rows of the job's own partition
+        const u32 jt = (S.flags >> 8) & 0xFFu;
+        RM tb = 0;
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) tb |= (RM)(((tg[r / 4] >> (8 * (r % 4))) & 0xFFu) == jt ? 1u : 0u) << r;
+        tybits &= tb;
       }
       const RM bl = (S.shape & 4u) ? (RM)(okbits & tybits & ~skip) : (RM)0;
       u32 gme = 0, gmo = 0;
@@ -2106,7 +2151,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       const int rr = (int)(up >> 10);
       const bool own = (up & 1023u) == t;
       const double ucost = u.cost;
-      const u32 ulen = u.len, ufront = u.has_front;
+      const u32 ulen = u.len, ufront = u.has_front & 1u;
+      const bool keep_cost = (u.has_front & 2u) != 0;   // the slot of another partition on a shared node
       const int ucpu = u.fcpu;
       const u32 um16 = mem_gib16(u.fmem), ugn = nibbles_of(u.fcnt);
 #pragma unroll
@@ -2114,7 +2160,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         if (r == rr) {
           u32 w = (mw[r] & ~(0x3FFu << 16)) | (ulen << 16);
           if (ufront) w = (w & ~0xFFFFu) | um16;
-          cost[r] = own ? ucost : cost[r];
+          cost[r] = (own && !keep_cost) ? ucost : cost[r];
           mw[r] = own ? w : mw[r];
           okbits = own ? (RM)((okbits & ~(kOne << r)) | ((RM)(ulen < maxlen ? 1u : 0u) << r)) : okbits;
           fcpu[r] = (own && ufront) ? ucpu : fcpu[r];
@@ -2178,7 +2224,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       ScanJob Jn = J;
       u64 typeok_n = typeok;
       const bool have_next = ji + 1 < jend;
-      const bool spec_ok = !excl_job && !general && kk == 1;  // this job touches one node, a round-0 winner
+      const bool shared_nodes = P.sib_off != nullptr;
+      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes;  // this job touches one node, a round-0 winner
       RM skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= kOne << (wcode >> 10);
       if ((tcode & 1023u) == t && tcode != kNone) {
@@ -2209,7 +2256,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       RM used = 0;
       bool round0 = true;  // resolved without a second scan round
       bool sequential = true;  // run the one-candidate-per-round protocol below
-      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMultiK && (J.shape & 2u)) {
+      if (!excl_job && !general && kk >= 2 && kk <= (u32)kMultiK && (J.shape & 2u) && !shared_nodes) {
         // ---- multi-node job, parallel protocol (mirror of the worker's): this wave lists its k best
         // candidates (sorted), the worker merges the lists, then wave i+1 verifies / commits candidate i ----
         sequential = false;
@@ -2300,7 +2347,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       // ---- owners refresh their registers ---------------------------------------------------------------
       if (verdict == 2) {
         const int nu = s_nupd;
-        const UpdRec* const ub = nu <= kMaxUpd ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
+        const UpdRec* const ub = (nu <= kMaxUpd && !shared_nodes) ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
         for (int i = 0; i < nu; ++i) {
           const u32 up = uni32(ub[i].p);
           if (owner_wave(up) == wave) apply_upd(ub[i], up);  // only the owner's wave does any work

@@ -133,6 +133,22 @@ def scenarios():
         3: (0, NOW, [(0, 1, 512, 0xC, 0)]),
         "costs": [150.0],
         "timeline": {0: [(NOW, 0, 0x0), (1100, 0, 0x0), (1150, 1024, 0xF), (INF, 0, 0)]}}))
+
+    # J. partitions that SHARE a node (JobScheduler.cpp:6563,6585-6617: one NodeState per craned; JobScheduler.h:498-516:
+    #    one cost per partition selector).  Partition 0 = {0, 1}, partition 1 = {1, 2}.  Job 1 (partition 1) fills half of
+    #    node 1; job 2 (partition 0, 4 cpus) still walks node 1 FIRST — partition 0's cost of node 1 is untouched by
+    #    partition 1's job — finds only 2 cpus in its window there and on node 0, and is backfilled on node 1 behind job 1
+    #    ("Priority": 4 cpus <= the cycle-start res_avail).  Job 4 (partition 1) sees that reservation in the shared time
+    #    map and fits in front of it; job 5 ties 50.0 / 50.0 in partition 0 and takes the lower node index.
+    c = cluster([4, 4, 4], parts=[[0, 1], [1, 2]])
+    j = jobs([dict(part=0, cpu=2, L=100), dict(part=1, cpu=2, L=100), dict(part=0, cpu=4, L=50),
+              dict(part=1, cpu=2, L=200), dict(part=1, cpu=2, L=40), dict(part=0, cpu=2, L=200)])
+    out.append(("shared_node_two_partitions", c, j, {}, {
+        0: (0, NOW, [(0, 1, 512, 0x3, 0)]), 1: (0, NOW, [(1, 1, 512, 0x3, 0)]), 2: (1, 1100, [(1, 1, 1024, 0xF, 0)]),
+        3: (0, NOW, [(2, 1, 512, 0x3, 0)]), 4: (0, NOW, [(1, 1, 512, 0xC, 0)]), 5: (0, NOW, [(0, 1, 512, 0xC, 0)]),
+        "costs": [150.0, 50.0, 70.0, 100.0],   # per (partition, node): [p0/n0, p0/n1, p1/n1, p1/n2]
+        "timeline": {0: [(NOW, 0, 0x0), (1100, 512, 0x3), (1200, 1024, 0xF), (INF, 0, 0)],
+                     1: [(NOW, 0, 0x0), (1040, 512, 0xC), (1100, 0, 0x0), (1150, 1024, 0xF), (INF, 0, 0)]}}))
     return out
 
 
