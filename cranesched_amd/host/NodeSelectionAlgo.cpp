@@ -24,6 +24,7 @@ struct GpuNodeSelectionAlgo::Impl {
   cns_handle* h = nullptr;
   // dense indices of the current snapshot
   std::vector<CranedId> node_name;
+  std::vector<uint64_t> node_mem_sw;   // res_total.memory_sw_bytes per node (what an exclusive job is allocated)
   std::unordered_map<CranedId, uint32_t> node_idx;
   std::unordered_map<PartitionId, uint32_t> part_idx;
   std::unordered_map<std::string, uint32_t> resv_idx;
@@ -144,6 +145,10 @@ struct GpuNodeSelectionAlgo::Impl {
     if (B.enodes.empty()) B.enodes.push_back(0);
   }
   // what JobScheduler.cpp:1492-1600 consumes
+  // lazy (default): a job that did not start now leaves NodeSelect with a pending reason, and the commit loop then reads
+  // nothing but that reason, start_time and priority (JobScheduler.cpp:1503-1510) — its node list and ResourceInNodeV3
+  // objects are not materialised (3.3 us per job at 1 M jobs: more than half a GPU cycle, profiles/r01_host_pack_bench.txt)
+  bool lazy_write_back = true;
   void write_back(const std::vector<PdJobInScheduler*>& ord, const cns_placement_soa& o) const {
     parallel_for(ord.size(), [&](size_t a, size_t b) {
       for (size_t j = a; j < b; ++j) {
@@ -155,6 +160,7 @@ struct GpuNodeSelectionAlgo::Impl {
         if (o.start_sec[j] == 0) continue;      // nothing placed ("Resource" / "Partition Not Found" / "Priority" beyond the batch)
         p.start_time = o.start_sec[j];
         p.end_time = p.start_time + p.time_limit;  // cpp:6772
+        if (lazy_write_back && r != CNS_REASON_NONE) continue;   // backfilled for later: only reason + start time are consumed
         for (uint64_t q = o.place_offsets[j]; q < o.place_offsets[j + 1]; ++q) {
           if (o.node_idx[q] == CNS_NODE_NONE) continue;
           const CranedId& cid = node_name[o.node_idx[q]];
@@ -162,7 +168,9 @@ struct GpuNodeSelectionAlgo::Impl {
           p.craned_id_to_task_num[cid] = o.ntasks[q];
           ResourceInNodeV3& res = p.allocated_res[cid];   // built in place (the map was cleared above)
           fill_res(res, o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q]);
-          res.memory_sw_bytes = p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o.ntasks[q];
+          // an exclusive job is allocated the node's whole res_total, memory_sw_bytes included (JobScheduler.cpp:6309-6310)
+          res.memory_sw_bytes = p.exclusive ? node_mem_sw[o.node_idx[q]]
+                                            : p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o.ntasks[q];
         }
       }
     });
@@ -234,11 +242,16 @@ struct GpuNodeSelectionAlgo::Impl {
       }
     return m;
   }
-  static void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi) {
+  // core ids as two 64-bit masks; an id >= 128 does not fit the engine's model: it is RECORDED (core_overflow) and the
+  // snapshot / cycle is refused — silently dropping it would make integer requests fail the `popc < n` test, or come back
+  // without core ids, where ResourceView::GetFeasibleResourceInNode (PublicHeader.cpp:528-538) fits them
+  bool core_overflow = false;
+  void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi) {
     lo = hi = 0;
     for (uint32_t c : ids) {
       if (c < 64) lo |= 1ull << c;
       else if (c < 128) hi |= 1ull << (c - 64);
+      else core_overflow = true;
     }
   }
   // fills `r` (a fresh or cleared ResourceInNodeV3) from the mask form; ids and slot paths arrive in ascending order,
@@ -341,12 +354,20 @@ GpuNodeSelectionAlgo::~GpuNodeSelectionAlgo() {
   if (impl_ && impl_->h) cns_destroy(impl_->h);
 }
 
+void GpuNodeSelectionAlgo::SetFullWriteBack(bool full) { impl_->lazy_write_back = !full; }
+
 void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   Impl& I = *impl_;
   I.have_snapshot = false;
   I.alloc_cache.clear();   // dense node indices and GRES bit positions are per snapshot
   const uint32_t N = (uint32_t)snap.craned_metas.size();
-  I.node_name.clear(); I.node_idx.clear(); I.part_idx.clear();
+  I.node_name.clear(); I.node_mem_sw.clear(); I.node_idx.clear(); I.part_idx.clear();
+  I.core_overflow = false;
+  if (snap.preempt_enabled) {
+    status_ = CNS_ERR_UNSUPPORTED;
+    error_ = "preemption is enabled (PreemptType != NONE): TryPreempt_ / PreemptSegTree are not implemented by the GPU engine; keep the CPU SchedulerAlgo";
+    return;
+  }
   I.classes.clear(); I.name_id.clear(); I.class_slot_bit.clear(); I.class_bit_slot.clear();
   // GRES classes: every (name,type) seen in any res_total; bits per class = union of its slot paths
   std::map<std::pair<std::string, std::string>, std::set<SlotId>> cls;
@@ -385,10 +406,11 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   for (uint32_t n = 0; n < N; ++n) {
     const CranedMeta& m = snap.craned_metas[n];
     I.node_name.push_back(m.craned_id);
+    I.node_mem_sw.push_back(m.res_total.memory_sw_bytes);
     I.node_idx[m.craned_id] = n;
     cpu[n] = m.res_total.cpu_set.cpu_count.raw;
     mem[n] = m.res_total.memory_bytes;
-    Impl::core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n]);
+    I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n]);
     gres[n] = I.gres_mask(m.res_total.gres);
     sched[n] = m.alive && !m.drain;  // JobScheduler.cpp:6595
   }
@@ -418,11 +440,16 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
       I.v_cpu.push_back(res.cpu_set.cpu_count.raw);
       I.v_mem.push_back(res.memory_bytes);
       uint64_t l, hh;
-      Impl::core_masks(res.cpu_set.core_ids, l, hh);
+      I.core_masks(res.cpu_set.core_ids, l, hh);
       I.v_lo.push_back(l); I.v_hi.push_back(hh);
       I.v_g.push_back(I.gres_mask(res.gres));
     }
     I.v_off.push_back((uint32_t)I.v_node.size());
+  }
+  if (I.core_overflow) {
+    status_ = CNS_ERR_UNSUPPORTED;
+    error_ = "a node or reservation lists a core id >= 128 (the engine keeps core ids in two 64-bit masks); keep the CPU SchedulerAlgo";
+    return;
   }
   if (!I.h) return;   // no device: the dictionaries above still serve PackRunningForBench
   status_ = I.push_tables(error_);
@@ -443,6 +470,7 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
 
   // ---- running jobs (JobScheduler.cpp:6681-6709), packed incrementally -----------------------------------------
   I.pack_running(running_jobs);
+  if (I.core_overflow) return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 128");
   const auto &r_end = I.r_end, &r_cpu = I.r_cpu;
   const auto &r_off = I.r_off, &r_node = I.r_node, &r_resv = I.r_resv;
   const auto &r_mem = I.r_mem, &r_lo = I.r_lo, &r_hi = I.r_hi, &r_g = I.r_g;
@@ -802,7 +830,7 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
       acpu.push_back(res->cpu_set.cpu_count.raw);
       amem.push_back(res->memory_bytes);
       uint64_t lo, hi;
-      Impl::core_masks(res->cpu_set.core_ids, lo, hi);
+      I.core_masks(res->cpu_set.core_ids, lo, hi);
       alo.push_back(lo); ahi.push_back(hi);
       ag.push_back(I.gres_mask(res->gres));
     }

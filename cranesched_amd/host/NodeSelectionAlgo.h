@@ -150,6 +150,10 @@ struct ClusterSnapshot {
   std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
   std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
   std::vector<ResvMeta> reservations;                                     // g_meta_container->GetResvMetaMapPtr(); vector order = canonical order
+  // g_config.PreemptType != NONE: NodeSelect would call LocalScheduler::TryPreempt_ (JobScheduler.cpp:6140-6143), which
+  // the engine does not implement.  SetClusterSnapshot then refuses the snapshot (status() = CNS_ERR_UNSUPPORTED) so that
+  // the integrator keeps the CPU SchedulerAlgo instead of getting "GpuEngineError" on every job of every cycle.
+  bool preempt_enabled{false};
 };
 
 // ---- what the commit loop's run-limit admission reads (JobScheduler.cpp:1557-1573) -----------------------------
@@ -286,6 +290,10 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // Optional: the sorter NodeSelect consults first (SchedulerAlgo's ctor argument, JobScheduler.h:247);
   // nullptr = BasicPriority (input order, JobScheduler.h:185-200).  Not owned.
   void SetPrioritySorter(IPrioritySorter* sorter) { sorter_ = sorter; }
+  // Default: jobs that did not start now (pending reason set) get reason, start_time and end_time only — all the commit
+  // loop reads of them (JobScheduler.cpp:1503-1510).  SetFullWriteBack(true) also fills craned_ids / allocated_res of the
+  // jobs NodeSelect backfilled for later, exactly as the reference's NodeSelect leaves them.
+  void SetFullWriteBack(bool full);
   // The cycle's license table for the pre-pass NodeSelect runs between ordering and selection
   // (g_license_manager->CheckLicenseCountSufficient, JobScheduler.cpp:6739; LicenseManager.cpp:167-221): a tiny
   // sequential counter pass over the ordered jobs, done on the host; jobs it rejects get reason "License" and are

@@ -121,6 +121,23 @@ static int cycle_bench(int n_nodes, int n_jobs) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000);
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
+  if (argc > 1 && !strcmp(argv[1], "--config-checks")) {
+    // configurations the engine cannot serve are refused when the SNAPSHOT is set (host-only; no device needed), so
+    // that the integrator keeps the CPU SchedulerAlgo instead of seeing "GpuEngineError" on every job of every cycle
+    GpuNodeSelectionAlgo algo(0);
+    ClusterSnapshot snap;
+    snap.craned_metas = {node("cn0", 4, 16), node("cn1", 4, 16)};
+    snap.partitions = {{"CPU", {"cn0", "cn1"}}};
+    snap.preempt_enabled = true;
+    algo.SetClusterSnapshot(snap);
+    CHECK(algo.LastStatus() == -4 /* CNS_ERR_UNSUPPORTED */ && algo.LastError().find("preemption") != std::string::npos);
+    snap.preempt_enabled = false;
+    snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: id >= 128
+    algo.SetClusterSnapshot(snap);
+    CHECK(algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);
+    printf("%s\n", g_fail ? "FAIL" : "ok");
+    return g_fail != 0;
+  }
   const bool no_gpu = argc > 1 && !strcmp(argv[1], "--no-gpu");
   const TimeSec now = 1000;
   std::vector<std::unique_ptr<RnJobInScheduler>> running;
@@ -194,6 +211,15 @@ int main(int argc, char** argv) {
     CHECK(pd[1]->reason == "Priority" && pd[1]->start_time == 1100);
     CHECK(pd[2]->reason == "Priority" && pd[2]->start_time == 1150);
     CHECK(pd[3]->reason == "Priority" && pd[3]->start_time == 1100);
+    // default (lazy) write-back: a job that did not start now carries reason + start time only (cpp:1503-1510 reads no more)
+    CHECK(pd[1]->craned_ids.empty() && pd[1]->allocated_res.empty());
+    algo.SetFullWriteBack(true);   // ... the reference's own NodeSelect also leaves its backfill placement behind
+    pd.clear();
+    pd.push_back(job(1, 2, 100)); pd.push_back(job(2, 1, 50));
+    algo.NodeSelect(now, running, pd);
+    CHECK(pd[1]->reason == "Priority" && pd[1]->start_time == 1100 && pd[1]->craned_ids.size() == 1 && pd[1]->craned_ids[0] == "cn0");
+    CHECK(pd[1]->allocated_res.at("cn0").cpu_set.core_ids == std::set<uint32_t>{0});   // allocated against res_total (:6354-6356)
+    algo.SetFullWriteBack(false);
 
     // --- scenario F: GRES slot choice, slot paths in lexicographic order -------------------------------------
     CranedMeta g0 = node("gn0", 8, 16), g1 = node("gn1", 8, 16);

@@ -33,3 +33,10 @@ def test_pending_pack_and_write_back_host_only(built):
     """cns_job_soa packing + write-back of synthetic placements into PdJobInScheduler objects (no device needed)."""
     r = subprocess.run([EXE, "--cycle-bench", "1024", "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_unsupported_configurations_are_refused_at_the_snapshot(built):
+    """core ids >= 128 and PreemptType != NONE must surface as CNS_ERR_UNSUPPORTED when the snapshot is set
+    (host-only check), not as silently wrong placements or a per-cycle GpuEngineError."""
+    r = subprocess.run([EXE, "--config-checks"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
