@@ -1,0 +1,379 @@
+"""A SECOND, independent restatement of the node-selection cycle in plain Python — test infrastructure only.
+
+It shares no code with oracle/ (C++) or with the device code: written from the reference lines cited below and from
+SURVEY.md Appendix A, with Python ints, sets and dicts (literal containers: core ids and GRES slots are sets of ids,
+time maps are sorted lists).  tests/test_select_pyref.py runs it against the C++ oracle on the hand-derived scenarios and
+on random small clusters; agreement of two restatements that share nothing is what "parity unpinned" can be narrowed to
+while the reference itself cannot be compiled here.
+
+Reference:  src/CraneCtld/JobScheduler.cpp:6127-6376 (select / backfill), :6507-6836 (cycle),
+            src/CraneCtld/JobScheduler.h:41-55 (cost), :272-460 (NodeState), :492-595 (selector), :678-865 (backfill),
+            src/Utilities/PublicHeader/PublicHeader.cpp:519-599 (GetFeasibleResourceInNode), :781-827, :886-890.
+Canonicalisations (same as everywhere in this repo): cost ties break on the dense node index; a job's nodes are reported
+in ascending index; unordered_map walks (GRES names / types) go in ascending id.
+"""
+from __future__ import annotations
+
+import copy
+
+INF = (1 << 63) - 1
+MAX_WINDOW = 7 * 24 * 3600
+MAX_JOBS_PER_NODE = 1000
+
+
+class Res:
+    """ResourceInNodeV3: cpu raw (x256), mem bytes, core id set, GRES: {(name, type): set(slot)}."""
+    __slots__ = ("cpu", "mem", "cores", "gres")
+
+    def __init__(self, cpu=0, mem=0, cores=(), gres=None):
+        self.cpu, self.mem, self.cores = cpu, mem, set(cores)
+        self.gres = {k: set(v) for k, v in (gres or {}).items() if v}
+
+    def copy(self):
+        return Res(self.cpu, self.mem, self.cores, self.gres)
+
+    def key(self):
+        return (self.cpu, self.mem, tuple(sorted(self.cores)), tuple(sorted((k, tuple(sorted(v))) for k, v in self.gres.items() if v)))
+
+
+def res_sub(a: Res, b: Res):       # PublicHeader.cpp:789-796, CpuSet -= :758-766 (tolerant erase)
+    a.cpu -= b.cpu
+    a.mem -= b.mem
+    a.cores -= b.cores
+    for k, v in b.gres.items():
+        if k in a.gres:
+            a.gres[k] -= v
+            if not a.gres[k]:
+                del a.gres[k]
+
+
+def res_add(a: Res, b: Res):       # :781-787
+    a.cpu += b.cpu
+    a.mem += b.mem
+    a.cores |= b.cores
+    for k, v in b.gres.items():
+        a.gres.setdefault(k, set()).update(v)
+
+
+def res_le(a: Res, b: Res) -> bool:  # :886-890 — core ids are NOT compared; requested slots must be a subset
+    if a.cpu > b.cpu or a.mem > b.mem:
+        return False
+    return all(v <= b.gres.get(k, set()) for k, v in a.gres.items())
+
+
+def res_ckmin(a: Res, b: Res):     # :815-827
+    a.cpu = min(a.cpu, b.cpu)
+    a.mem = min(a.mem, b.mem)
+    if a.cores and b.cores:
+        a.cores &= b.cores
+    for k in list(a.gres):
+        a.gres[k] &= b.gres.get(k, set())
+        if not a.gres[k]:
+            del a.gres[k]
+
+
+class Req:
+    """ResourceView of a request: cpu raw, mem, GRES per name: total count and {type: specified count}."""
+
+    def __init__(self, cpu=0, mem=0, gtot=None, gspec=None):
+        self.cpu, self.mem = cpu, mem
+        self.gtot = dict(gtot or {})        # name -> total
+        self.gspec = dict(gspec or {})      # (name, type) -> count
+
+
+def compose(node: Req, task_cpu, task_mem, n) -> Req:   # req_node + req_task * n (:473-481, :601-611); tasks carry no GRES
+    return Req(node.cpu + task_cpu * n, node.mem + task_mem * n, node.gtot, node.gspec)
+
+
+def feasible(req: Req, avail: Res, types_of):   # GetFeasibleResourceInNode, :519-599 -> allocation or None
+    if req.cpu > avail.cpu or req.mem > avail.mem:           # :522-523 (mem_sw is not tested)
+        return None
+    out = Res(req.cpu, req.mem)
+    n = req.cpu // 256 if req.cpu >= 0 else -((-req.cpu) // 256)
+    if n * 256 == req.cpu and avail.cores:                   # :528-530 integer request and the node tracks core ids
+        if len(avail.cores) < n:                             # :534
+            return None
+        out.cores = set(sorted(avail.cores)[:n])             # the n lowest ids, :535-537
+    names = sorted(set(req.gtot) | {k[0] for k in req.gspec})
+    for name in names:
+        total = req.gtot.get(name, 0)
+        spec = {t: c for (nm, t), c in req.gspec.items() if nm == name and c}
+        if total == 0 and not spec:
+            continue
+        if not any(k[0] == name and v for k, v in avail.gres.items()):   # :550-551 no slot of that name at all
+            return None
+        untyped = max(total - sum(spec.values()), 0)         # :556-559
+        for t in sorted(spec):                               # specified types (canonical: ascending type id)
+            slots = sorted(avail.gres.get((name, t), set()))
+            if len(slots) < spec[t]:                         # :566-569
+                return None
+            take = slots[:spec[t]]
+            rest = slots[spec[t]:]
+            extra = rest[:untyped]                           # the same type serves the untyped remainder first, :577-578
+            untyped -= len(extra)
+            out.gres.setdefault((name, t), set()).update(take + extra)
+        if untyped > 0:                                      # :582-592 the other types of the name, ascending
+            for t in types_of(name):
+                if t in spec or untyped == 0:
+                    continue
+                slots = sorted(avail.gres.get((name, t), set()))
+                extra = slots[:untyped]
+                untyped -= len(extra)
+                if extra:
+                    out.gres.setdefault((name, t), set()).update(extra)
+        if untyped != 0:                                     # :594
+            return None
+    return out
+
+
+# ---- std::priority_queue<node_info> as libstdc++ builds it (bits/stl_heap.h: __push_heap / __adjust_heap) ---------------
+# comp(a, b) = a < b  <=>  a.ntasks > b.ntasks  (node_info::operator<, JobScheduler.cpp:6157-6163): the TOP is the smallest
+# ntasks_on_node; which of several equal entries is evicted is an artefact of the heap layout.
+def _comp(a, b):
+    return a[0] > b[0]
+
+
+def heap_push(h, x):
+    h.append(x)
+    hole = len(h) - 1
+    parent = (hole - 1) // 2
+    while hole > 0 and _comp(h[parent], x):
+        h[hole] = h[parent]
+        hole = parent
+        parent = (hole - 1) // 2
+    h[hole] = x
+
+
+def heap_pop(h):
+    top = h[0]
+    value = h.pop()
+    n = len(h)
+    if n == 0:
+        return top
+    hole, second = 0, 0          # __adjust_heap(first, 0, n, value)
+    while second < (n - 1) // 2:
+        second = 2 * (second + 1)
+        if _comp(h[second], h[second - 1]):
+            second -= 1
+        h[hole] = h[second]
+        hole = second
+    if (n & 1) == 0 and second == (n - 2) // 2:
+        second = 2 * (second + 1)
+        h[hole] = h[second - 1]
+        hole = second - 1
+    parent = (hole - 1) // 2     # __push_heap(first, hole, 0, value)
+    while hole > 0 and _comp(h[parent], value):
+        h[hole] = h[parent]
+        hole = parent
+        parent = (hole - 1) // 2
+    h[hole] = value
+    return top
+
+
+class Node:
+    def __init__(self, idx, total: Res):
+        self.idx, self.total = idx, total
+        self.avail0 = total.copy()
+        self.allocated = []   # (end, Res) in arrival order
+        self.tmap = []        # sorted [[t, Res]]
+
+    def init_map(self, now, end=INF):   # InitTimeAvailResMap, JobScheduler.h:301-338 (no future reservations in this restatement)
+        changes = []
+        for e, r in self.allocated:
+            changes.append(e)
+            res_sub(self.avail0, r)
+        self.tmap = [[now, self.avail0.copy()]]
+        for e, r in sorted(self.allocated, key=lambda x: x[0]):   # stable: equal end times accumulate on one entry
+            if e != self.tmap[-1][0]:
+                self.tmap.append([e, self.tmap[-1][1].copy()])
+            res_add(self.tmap[-1][1], r)
+        if self.tmap[-1][0] == end:
+            self.tmap[-1][1] = Res()
+        else:
+            self.tmap.append([end, Res()])
+
+    def commit(self, start, end, res: Res):   # UpdateResourceInNode (allocate), JobScheduler.h:340-459
+        ts = [e[0] for e in self.tmap]
+        ib = max(i for i, t in enumerate(ts) if t <= start)
+        if ts[ib] != start:
+            self.tmap.insert(ib + 1, [start, self.tmap[ib][1].copy()])
+            ib += 1
+        ts = [e[0] for e in self.tmap]
+        ie = max(i for i, t in enumerate(ts) if t <= end)
+        if ts[ie] != end:
+            self.tmap.insert(ie + 1, [end, self.tmap[ie][1].copy()])   # copies the value BEFORE the subtraction below
+            ie += 1
+        for i in range(ib, ie):
+            res_sub(self.tmap[i][1], res)
+
+
+class Cycle:
+    """One NodeSelect cycle (JobScheduler.cpp:6507-6836) without reservations / preemption / licenses."""
+
+    def __init__(self, now, totals, part_nodes, schedulable=None, types_of=None, max_jobs_per_node=MAX_JOBS_PER_NODE,
+                 max_window=MAX_WINDOW):
+        self.now, self.max_jobs, self.max_window = now, max_jobs_per_node, max_window
+        self.types_of = types_of or (lambda name: [])
+        n = len(totals)
+        sched = schedulable if schedulable is not None else [1] * n
+        in_part = set(x for p in part_nodes for x in p)
+        self.nodes = {i: Node(i, totals[i].copy()) for i in range(n) if sched[i] and i in in_part}   # cpp:6584-6606
+        self.parts = [[i for i in p if i in self.nodes] for p in part_nodes]
+        self.cost = None
+
+    def add_running(self, end, allocs):          # cpp:6513-6514, :6681-6709
+        end = max(end, self.now + 1)
+        for node, res in allocs:
+            if node in self.nodes:
+                self.nodes[node].allocated.append((end, res))
+
+    def start(self):
+        for nd in self.nodes.values():
+            nd.init_map(self.now)
+        # one cost per (partition, node): NodeRater ctor, JobScheduler.h:498-511, in allocated_res order
+        self.cost = []
+        for p in self.parts:
+            c = {}
+            for i in p:
+                nd, v = self.nodes[i], 0.0
+                for e, r in nd.allocated:
+                    v += float(e - self.now) * ((float(r.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
+                c[i] = v
+            self.cost.append(c)
+
+    # -- get_max_tasks, cpp:6171-6186
+    def max_tasks(self, job, res: Res):
+        f = feasible(job["min_view"], res, self.types_of)
+        if f is None:
+            return 0
+        left = res.copy()
+        res_sub(left, f)
+        t = job["tmin"]
+        one = Req(job["tcpu"], job["tmem"])
+        while t < job["tmax"]:
+            f = feasible(one, left, self.types_of)
+            if f is None:
+                break
+            t += 1
+            res_sub(left, f)
+        return t
+
+    # -- GetNodesAndTrySchedule_, cpp:6147-6369: returns ("now", picks) | ("later", picks) | None
+    def try_schedule(self, job):
+        p = job["part"]
+        E = self.now + job["L"]
+        k, ntasks = job["k"], job["ntasks"]
+        h_total, sum_total, h_avail, sum_avail = [], 0, [], 0
+        for i in sorted(self.parts[p], key=lambda x: (self.cost[p][x], x)):     # :6188 ascending (cost, node)
+            nd = self.nodes[i]
+            if len(nd.tmap) >= self.max_jobs:                                    # :6194
+                continue
+            if job["incl"] and i not in job["incl"]:                             # :6202-6220
+                continue
+            if i in job["excl"]:
+                continue
+            tt = self.max_tasks(job, nd.total)                                   # :6222
+            if tt == 0:
+                continue
+            if len(h_total) < k or sum_total < ntasks:                           # :6233-6242
+                sum_total += tt
+                heap_push(h_total, (tt, nd.total, i))
+                if len(h_total) > k:
+                    sum_total -= h_total[0][0]
+                    heap_pop(h_total)
+            if job["exclusive"]:                                                 # :6249-6271
+                if any(not res_le(nd.total, r) for t, r in nd.tmap if t < E):
+                    continue
+                cand = (tt, nd.total, i)
+            else:                                                                # :6272-6299
+                if feasible(job["min_view"], nd.avail0, self.types_of) is None:  # cycle-start res_avail, never updated
+                    continue
+                m = nd.avail0.copy()
+                for t, r in nd.tmap:
+                    if t >= E:
+                        break
+                    res_ckmin(m, r)
+                ta = self.max_tasks(job, m)
+                if ta == 0:
+                    continue
+                cand = (ta, m, i)
+            sum_avail += cand[0]
+            heap_push(h_avail, cand)
+            if len(h_avail) > k:
+                sum_avail -= h_avail[0][0]
+                heap_pop(h_avail)
+            if len(h_avail) == k and sum_avail >= ntasks:                        # :6294-6297
+                break
+
+        def distribute(h):                                                       # :6304-6325 / :6345-6367
+            rest = ntasks - k
+            picks = []
+            while h:
+                cap, res, i = h[0]               # top = smallest ntasks_on_node
+                t = min(rest, cap - 1) + 1
+                if job["exclusive"]:
+                    alloc = res.copy()
+                else:
+                    alloc = feasible(compose(job["node_view"], job["tcpu"], job["tmem"], t), res, self.types_of)
+                    assert alloc is not None
+                picks.append((i, t, alloc))
+                rest -= t - 1
+                heap_pop(h)
+            return picks
+
+        if len(h_avail) == k and sum_avail >= ntasks:
+            return "now", distribute(h_avail)
+        if len(h_total) < k or sum_total < ntasks:                               # :6335-6343
+            return None
+        return "later", distribute(h_total)
+
+    # -- Backfill_ / EarliestStartSubsetSelector on exactly the k nodes (JobScheduler.h:792-865): the earliest time at
+    # which every node satisfies `alloc <= entry` for a whole time limit; candidate starts are `now` and the map keys
+    def earliest_start(self, job, picks):
+        L = job["L"]
+        cands = sorted({self.now} | {t for i, _, _ in picks for t, _ in self.nodes[i].tmap if t > self.now})
+        for s in cands:
+            if s == INF or s - self.now > self.max_window:                       # h:815
+                return None
+            ok = True
+            for i, _, alloc in picks:
+                tm = self.nodes[i].tmap
+                for x, (t, r) in enumerate(tm):
+                    nxt = tm[x + 1][0] if x + 1 < len(tm) else None
+                    if nxt is not None and nxt <= s:
+                        continue                 # entry ends before the window
+                    if t >= s + L:
+                        break                    # entry starts after the window
+                    if not res_le(alloc, r):
+                        ok = False
+                        break
+                if not ok:
+                    break
+            if ok:
+                return s
+        return None
+
+    def run_job(self, job):
+        """Returns (reason, start, [(node, ntasks, alloc Res)] ascending node).  reason: 0 none, 1 Priority, 2 Resource."""
+        r = self.try_schedule(job)
+        if r is None:
+            return 2, 0, []
+        kind, picks = r
+        if kind == "now":
+            start = self.now
+        else:
+            start = self.earliest_start(job, picks)
+            if start is None:
+                return 2, 0, []
+        end = start + job["L"]
+        p = job["part"]
+        for i, t, alloc in picks:                                                # :6795 + NodeSelector::AllocateResource h:567-575
+            nd = self.nodes[i]
+            nd.commit(start, end, alloc)
+            self.cost[p][i] += float(end - start) * ((float(alloc.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
+        reason = 0
+        if start != self.now:                                                    # :6797-6833 (no reservations here)
+            reason = 1
+            if any(not res_le(alloc, self.nodes[i].avail0) for i, _, alloc in picks):
+                reason = 2
+        return reason, start, sorted(picks, key=lambda x: x[0])
