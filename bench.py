@@ -12,7 +12,7 @@ ends with one RCCL all-gather of the packed placement buffers; total work is fix
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_select) with the ALGORITHMIC
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_pipe; k_select when CNS_SELECT_KERNEL=legacy) with the ALGORITHMIC
 bytes of SURVEY.md §8(d) (N_p*S_node + S_job + S_out per decision) over its HIP-event duration;
 `cpu_baseline` times the CPU oracle (a port of the reference algorithm; the reference itself cannot
 be built offline) on ONE WHOLE PARTITION of the same queue (partitions never interact), single pinned
@@ -161,6 +161,7 @@ def main():
         except (OSError, KeyError):
             pass
         got = eng.download()
+        kernel = eng.last_kernel()
         # SURVEY.md 8(d) bracket (the reference's own, JobScheduler.cpp:1439-1447): the whole cns_select call from host
         # buffers — H2D of the job arrays, record packing, the kernels, D2H of the placements.  Median of 5 after the
         # warm-up above; reported beside `value` (which, per the bench contract, starts with the inputs resident in HBM).
@@ -186,15 +187,18 @@ def main():
                                    f"seed 0x43524E45^{synth.CONFIGS[args.config]['idx']}",
                        "jobs": jobs.num_jobs, "nodes": cluster.num_nodes, "partitions": cluster.num_partitions,
                        "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else "single GPU, one workgroup per partition",
+                       "selection_kernel": kernel,
                        "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),
                                          "resource": int((r == 2).sum())},
-                       "kernel_ms": {"k_select": avg_sel_ms, "k_init_nodes+fill": float(np.mean(init_ms))},
+                       "kernel_ms": {kernel: avg_sel_ms, "k_init_nodes+k_prep_jobs+fill": float(np.mean(init_ms))},
                        "h2d_job_table_ms": h2d_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_prof,
-                         "kernel": "k_select", "algorithmic_bytes_per_launch": tm["algorithmic_bytes"],
-                         "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); "
-                                 "the node tile is register-resident, so HBM traffic is far below this"},
+                         "kernel": kernel, "algorithmic_bytes_per_launch": tm["algorithmic_bytes"],
+                         "avg_launch_ms": avg_sel_ms,
+                         "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); the node "
+                                 "tile is register-resident, so HBM traffic is ~1 % of this: the kernel is bound by the VALU "
+                                 "issue rate of the one CU a partition's sequential chain runs on (DESIGN.md 5), not by HBM"},
         }
         if incl is not None:
             line["incl_h2d_d2h"] = incl

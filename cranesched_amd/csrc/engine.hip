@@ -98,6 +98,7 @@ struct cns_engine {
   std::vector<u64> place_off;
   struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, total; } ro{};
   cns_timing timing{};
+  std::string last_kernel;
   i64 last_now = 0;
   // MultiFactorPriority (priority_host.inc)
   DevBuf d_prio[27];
@@ -785,11 +786,11 @@ int cns_run_resident(cns_handle* h, int64_t now) {
 #else
     bool launched = false;
     if (use_pipe_kernel(h)) {
-#define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; }
+#define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; h->last_kernel = "k_pipe<" #w ">"; }
       CNS_PNPL_LIST(CNS_TRY_PWIDTH)
 #undef CNS_TRY_PWIDTH
     }
-#define CNS_TRY_WIDTH(w) if (!launched && np <= kScan * (w)) { launch_select<w>(h, K); launched = true; }
+#define CNS_TRY_WIDTH(w) if (!launched && np <= kScan * (w)) { launch_select<w>(h, K); launched = true; h->last_kernel = "k_select<" #w ">"; }
     CNS_NPL_LIST(CNS_TRY_WIDTH)
 #undef CNS_TRY_WIDTH
     if (!launched) return fail(h, CNS_ERR_UNSUPPORTED, "partition too large for the widest register tile");
@@ -877,6 +878,8 @@ int cns_debug_get_costs(cns_handle* h, double* out) {
   for (size_t i = 0; i < h->orig_pos_slot.size(); ++i) out[i] = h->orig_pos_slot[i] == kNone ? 0.0 : c[h->orig_pos_slot[i]];
   return CNS_OK;
 }
+
+const char* cns_debug_last_kernel(const cns_handle* h) { return h ? h->last_kernel.c_str() : ""; }
 
 int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity) {
   // cycle counters of the last run, 32 per partition; all zero unless the library was built with -DCNS_PROF

@@ -27,7 +27,7 @@ _LIB = None
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
                "cns_set_reservations", "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
                "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline",
-               "cns_debug_get_prof")
+               "cns_debug_last_kernel", "cns_debug_get_prof")
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
 # ... and include/crane_gpu/run_limits.h
@@ -56,6 +56,8 @@ def lib():
         L.cns_last_error.argtypes = [C.c_void_p]
         L.cns_destroy.restype = None
         L.cns_destroy.argtypes = [C.c_void_p]
+        L.cns_debug_last_kernel.restype = C.c_char_p
+        L.cns_debug_last_kernel.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -222,6 +224,10 @@ class GpuNodeSelector:
         t = abi.CnsTiming()
         self._check(self._L.cns_get_timing(self._h, C.byref(t)))
         return {f: getattr(t, f) for f, _ in abi.CnsTiming._fields_}
+
+    def last_kernel(self) -> str:
+        """Selection kernel of the last run: 'k_pipe<NPL>' (decoupled test / commit pipeline) or 'k_select<NPL>'."""
+        return (self._L.cns_debug_last_kernel(self._h) or b"").decode()
 
     # -- parity helpers ------------------------------------------------------------------------------
     def costs(self) -> np.ndarray:

@@ -245,6 +245,9 @@ int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint
                            int64_t* t, int64_t* cpu_raw, uint64_t* mem, uint64_t* core_lo,
                            uint64_t* core_hi, uint64_t* gres);
 
+/* Name of the selection kernel the last cns_run_resident launched ("k_pipe<16>", "k_select<19>", ...; "" before a run). */
+const char* cns_debug_last_kernel(const cns_handle* h);
+
 /* Cycle counters of the last run (32 per partition); zeros unless the library was built with -DCNS_PROF. */
 int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity);
 
