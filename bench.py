@@ -5,8 +5,10 @@ A "step" is one whole NodeSelect cycle (SchedulerAlgo::NodeSelect, reference
 src/CraneCtld/JobScheduler.cpp:6507-6836, bracket :1439-1447) over the synthetic C4 queue:
 1 M pending jobs x 64 k nodes in 8 disjoint partitions, CPU+mem+GRES requests,
 with the job table and node snapshot already resident in HBM when the timed region starts.
-At N > 1 the queue is job-sharded by partition (rank r owns partitions p % N == r) and each step
-ends with one RCCL all-gather of the packed placement buffers; total work is fixed ("strong").
+At N > 1 the queue is job-sharded by partition (rank r owns partitions p % N == r; partitions that share nodes
+stay together) and each step ends with one RCCL all-gather of the packed placement buffers; total work is fixed
+("strong").  A partition is ONE sequential chain on one workgroup, so with P = 8 partitions the curve is flat by
+construction: more GPUs do not add chains.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -126,6 +128,25 @@ def main():
     elapsed = float(el.item())
     total_jobs = int(ordered.item())
 
+    # N > 1 (or CNS_BENCH_FORCE_DIST=1): what the all-gather delivered is unpacked and merged on rank 0 and compared with
+    # ONE engine run over the whole queue on rank 0's GPU (untimed): the collective path is checked, not just exercised
+    gather_check = None
+    if use_dist and rank == 0:
+        torch.cuda.synchronize()
+        host = gather_out.cpu().numpy()
+        shards = []
+        for rk in range(world):
+            sj, sidx = sharding.shard(cluster, jobs, rk, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))
+            shards.append((sharding.unpack_results(host[rk * pad:(rk + 1) * pad], sj), sidx))
+        merged = sharding.merge(jobs, shards)
+        eng1 = GpuNodeSelector(device=local_rank)
+        eng1.set_nodes(cluster)
+        single = eng1.node_select(now, jobs)
+        eng1.close()
+        gather_check = merged.diff(single) is None
+    if use_dist:
+        dist.barrier()
+
     lim_line = None
     if limits is not None:
         eng.upload_limit_jobs(limits[1])       # keys resident before the timed passes
@@ -202,6 +223,8 @@ def main():
         }
         if incl is not None:
             line["incl_h2d_d2h"] = incl
+        if gather_check is not None:
+            line["allgather_merged_identical_to_single_gpu"] = bool(gather_check)
         if lim_line is not None:
             from cranesched_amd import limits as lm
             lim_line["rejected_by"] = {lm.LIMIT_REASON_STR[int(k)]: v for k, v in lim_line["rejected_by"].items()}

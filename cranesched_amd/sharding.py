@@ -5,8 +5,11 @@ Each partition has its own LocalScheduler, node set and cost order in the refere
 interact when the partitions' node sets are disjoint.  Rank r therefore owns the partitions
 {p : p % world == r}: their node lists and their slice of the queue (order preserved), runs the
 engine on that shard alone, and one RCCL all-gather of the packed placement buffers leaves every
-rank with the merged claim list.  With disjoint partitions there is no claim to resolve, so the
-replay step is a no-op (overlapping partitions are rejected by cns_set_nodes).
+rank with the merged claim list.  Partitions that SHARE nodes also share those nodes' time maps
+(one NodeState per craned, :6563,6609-6617): they form a group that must stay on one rank (the
+engine runs a group as one workgroup, in queue order), so the unit of sharding is the group of
+partitions connected through shared nodes; groups never interact, and the merge has no claim to
+resolve.
 """
 from __future__ import annotations
 
@@ -15,13 +18,46 @@ import numpy as np
 from . import abi, synth
 
 
-def partition_plan(num_parts: int, world: int) -> list[list[int]]:
-    return [[p for p in range(num_parts) if p % world == r] for r in range(world)]
+def partition_groups(cluster: abi.Cluster) -> list[list[int]]:
+    """Partitions connected through shared nodes, each group ascending, groups ordered by their first partition
+    (the same union-find as cns_set_nodes in csrc/engine.hip)."""
+    P = cluster.num_partitions
+    uf = list(range(P))
+
+    def find(x):
+        while uf[x] != x:
+            uf[x] = uf[uf[x]]
+            x = uf[x]
+        return x
+
+    first = {}
+    for p in range(P):
+        for n in cluster.part_nodes[cluster.part_offsets[p]:cluster.part_offsets[p + 1]]:
+            n = int(n)
+            if n in first:
+                a, b = find(first[n]), find(p)
+                if a != b:
+                    uf[max(a, b)] = min(a, b)
+            else:
+                first[n] = p
+    groups: dict[int, list[int]] = {}
+    for p in range(P):
+        groups.setdefault(find(p), []).append(p)
+    return [groups[r] for r in sorted(groups)]
+
+
+def partition_plan(num_parts: int, world: int, groups: list[list[int]] | None = None) -> list[list[int]]:
+    """Partitions of every rank: group g goes to rank g % world (without shared nodes a group is one partition)."""
+    groups = groups if groups is not None else [[p] for p in range(num_parts)]
+    plan = [[] for _ in range(world)]
+    for g, members in enumerate(groups):
+        plan[g % world] += members
+    return [sorted(x) for x in plan]
 
 
 def shard(cluster: abi.Cluster, jobs: abi.Jobs, rank: int, world: int):
     """(jobs of this rank's partitions, their indices in the global queue)."""
-    parts = partition_plan(cluster.num_partitions, world)[rank]
+    parts = partition_plan(cluster.num_partitions, world, partition_groups(cluster))[rank]
     return synth.select_partitions(cluster, jobs, parts)
 
 

@@ -77,3 +77,17 @@ def test_partition_plan_covers_everything():
         for w in (1, 2, 4, 8):
             plan = sharding.partition_plan(P, w)
             assert sorted(p for r in plan for p in r) == list(range(P))
+
+
+def test_groups_of_partitions_that_share_nodes_stay_on_one_rank():
+    import numpy as np
+    from cranesched_amd import abi, sharding
+    # p0 = {0,1,2}, p1 = {2,3} (shares node 2 with p0), p2 = {4,5}, p3 = {5,6,0} (shares 5 with p2 and 0 with p0)
+    parts = [[0, 1, 2], [2, 3], [4, 5], [5, 6, 0], [7]]
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint32)
+    n = 8
+    c = abi.Cluster(np.full(n, 1024, np.int64), np.full(n, 1 << 30, np.uint64), np.full(n, 0xF, np.uint64), np.zeros(n, np.uint64),
+                    np.zeros(n, np.uint64), off, np.concatenate(parts).astype(np.uint32))
+    assert sharding.partition_groups(c) == [[0, 1, 2, 3], [4]]
+    plan = sharding.partition_plan(5, 2, sharding.partition_groups(c))
+    assert plan == [[0, 1, 2, 3], [4]]
