@@ -110,7 +110,8 @@ typedef struct cns_node_soa {
   const uint64_t* gres_slots;     /* [num_nodes] may be NULL = 0                     */
   const uint8_t* schedulable;     /* [num_nodes] alive && !drain (JobScheduler.cpp:6595); NULL = all */
   const uint32_t* part_offsets;   /* [num_partitions+1] CSR into part_nodes          */
-  const uint32_t* part_nodes;     /* node indices, ascending inside each partition   */
+  const uint32_t* part_nodes;     /* node indices of each partition; a node may be listed by several partitions:
+                                     one NodeState per node, one cost per (partition, node), JobScheduler.cpp:6585-6617 */
   cns_gres_layout gres;
 } cns_node_soa;
 
