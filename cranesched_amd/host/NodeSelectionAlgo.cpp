@@ -176,6 +176,58 @@ struct GpuNodeSelectionAlgo::Impl {
     });
   }
 
+  // ---- event-fed mirror: job id -> what MallocResourceFromNode was told, packed when it was told -----------------------
+  struct MirrorRec { CranedId craned; ResourceInNodeV3 res; AllocRec packed; bool known; };
+  struct MirrorJob { TimeSec end_time = 0; std::string resv; std::vector<MirrorRec> recs; };
+  std::map<job_id_t, MirrorJob> mirror;   // ascending job id = the order of the reference's running-job map
+  void pack_rec(MirrorRec& r) {
+    auto it = node_idx.find(r.craned);
+    r.known = it != node_idx.end();
+    if (!r.known) return;
+    r.packed.node = it->second;
+    r.packed.cpu = r.res.cpu_set.cpu_count.raw;
+    r.packed.mem = r.res.memory_bytes;
+    core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi);
+    r.packed.g = gres_mask(r.res.gres);
+  }
+  void repack_mirror() {   // after a new snapshot
+    for (auto& [id, mj] : mirror)
+      for (auto& r : mj.recs) pack_rec(r);
+  }
+  void pack_from_mirror() {
+    r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
+    r_off.assign(1, 0);
+    for (const auto& [id, mj] : mirror) {
+      uint32_t rv = CNS_RESV_NONE;
+      if (!mj.resv.empty()) {
+        auto it = resv_idx.find(mj.resv);
+        if (it == resv_idx.end()) continue;
+        rv = it->second;
+      }
+      r_resv.push_back(rv);
+      r_end.push_back(mj.end_time);
+      for (const MirrorRec& r : mj.recs) {
+        if (!r.known) continue;
+        const AllocRec& a = r.packed;
+        r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
+        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g);
+      }
+      r_off.push_back((uint32_t)r_node.size());
+    }
+  }
+  // checksum of the packed running arrays that ignores the order of a job's per-node records
+  uint64_t running_checksum_canonical() const {
+    auto h64 = [](uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; return x ^ (x >> 33); };
+    uint64_t acc = 1469598103934665603ull;
+    for (size_t j = 0; j + 1 < r_off.size(); ++j) {
+      uint64_t s = h64((uint64_t)r_end[j]) ^ h64(r_resv[j] + 0x9e37ull);
+      for (uint32_t a = r_off[j]; a < r_off[j + 1]; ++a)
+        s += h64(h64(r_node[a]) ^ h64((uint64_t)r_cpu[a] + 1) ^ h64(r_mem[a] + 2) ^ h64(r_lo[a] + 3) ^ h64(r_hi[a] + 4) ^ h64(r_g[a] + 5));
+      acc = (acc ^ h64(s)) * 1099511628211ull;
+    }
+    return acc;
+  }
+
   // running jobs -> cns_running_soa arrays (JobScheduler.cpp:6681-6709); order = the caller's vector
   void pack_running(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
     r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
@@ -446,6 +498,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     }
     I.v_off.push_back((uint32_t)I.v_node.size());
   }
+  I.repack_mirror();
   if (I.core_overflow) {
     status_ = CNS_ERR_UNSUPPORTED;
     error_ = "a node or reservation lists a core id >= 128 (the engine keeps core ids in two 64-bit masks); keep the CPU SchedulerAlgo";
@@ -457,9 +510,66 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   I.have_snapshot = true;
 }
 
+// ---- event-fed mirror (the calls CranedMetaContainer gets, CranedMetaContainer.cpp:178-277) ------------------------------
+void GpuNodeSelectionAlgo::MallocResourceFromNode(const CranedId& craned_id, job_id_t job_id, const ResourceV3& resources) {
+  Impl& I = *impl_;
+  auto rit = resources.find(craned_id);   // resources.At(node_id), :198
+  if (rit == resources.end()) return;
+  auto& mj = I.mirror[job_id];
+  Impl::MirrorRec* rec = nullptr;
+  for (auto& r : mj.recs) if (r.craned == craned_id) rec = &r;   // (rn_job_res_map.emplace: one record per (craned, job))
+  if (!rec) { mj.recs.emplace_back(); rec = &mj.recs.back(); rec->craned = craned_id; }
+  rec->res = rit->second;
+  I.pack_rec(*rec);
+}
+
+void GpuNodeSelectionAlgo::FreeResourceFromNode(const CranedId& craned_id, job_id_t job_id) {
+  Impl& I = *impl_;
+  auto it = I.mirror.find(job_id);
+  if (it == I.mirror.end()) return;   // "Try to free resource from an unknown job", :247-251
+  auto& recs = it->second.recs;
+  for (size_t i = 0; i < recs.size(); ++i)
+    if (recs[i].craned == craned_id) { recs.erase(recs.begin() + i); break; }
+  if (recs.empty()) I.mirror.erase(it);
+}
+
+void GpuNodeSelectionAlgo::SetRunningJobInfo(job_id_t job_id, TimeSec end_time, const std::string& reservation) {
+  auto& mj = impl_->mirror[job_id];
+  mj.end_time = end_time;
+  mj.resv = reservation;
+}
+
+size_t GpuNodeSelectionAlgo::MirroredRunningJobs() const { return impl_->mirror.size(); }
+
+size_t GpuNodeSelectionAlgo::PackMirrorForBench(uint64_t* checksum_canonical, double* pack_ms) {
+  Impl& I = *impl_;
+  const auto t0 = std::chrono::steady_clock::now();
+  I.pack_from_mirror();
+  if (pack_ms) *pack_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (checksum_canonical) *checksum_canonical = I.running_checksum_canonical();
+  return I.r_node.size();
+}
+
+uint64_t GpuNodeSelectionAlgo::LastRunningChecksumCanonical() const { return impl_->running_checksum_canonical(); }
+
+void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                      const std::vector<std::unique_ptr<RnJobInScheduler>>* running_for_priority) {
+  static const std::vector<std::unique_ptr<RnJobInScheduler>> kNone;
+  impl_->pack_from_mirror();
+  SelectPacked_(now, pending_jobs, running_for_priority ? *running_for_priority : kNone);
+}
+
 void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
                                       const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
                                       const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) {
+  // ---- running jobs (JobScheduler.cpp:6681-6709), packed incrementally -----------------------------------------
+  if (impl_->h && impl_->have_snapshot) impl_->pack_running(running_jobs);
+  SelectPacked_(now, pending_jobs, running_jobs);
+}
+
+// the cycle proper, on the running allocations already packed in Impl::r_*
+void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                                         const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
   Impl& I = *impl_;
   auto fail_all = [&](int st, const std::string& msg) {
     status_ = st; error_ = msg;
@@ -468,8 +578,6 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
   if (!I.h) return fail_all(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
   if (!I.have_snapshot) return fail_all(CNS_ERR_STATE, "NodeSelect before SetClusterSnapshot");
 
-  // ---- running jobs (JobScheduler.cpp:6681-6709), packed incrementally -----------------------------------------
-  I.pack_running(running_jobs);
   if (I.core_overflow) return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 128");
   const auto &r_end = I.r_end, &r_cpu = I.r_cpu;
   const auto &r_off = I.r_off, &r_node = I.r_node, &r_resv = I.r_resv;

@@ -303,6 +303,24 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
                   const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) override;
 
+  // ---- event-fed mirror of the running allocations -------------------------------------------------
+  // Instead of re-deriving the running jobs' allocations from the vector NodeSelect is handed every cycle, the adapter
+  // can be told what the meta container is told: the same calls, at the same places (JobScheduler.cpp:1590-1612 for the
+  // start of a job, the job-end path for the release) —
+  //   MallocResourceFromNode(craned, job, resources)   CranedMetaContainer.cpp:178-224
+  //   FreeResourceFromNode(craned, job)                CranedMetaContainer.cpp:226-277
+  // plus the two facts of RnJobInScheduler the meta container does not hold: the job's end time and its reservation.
+  // The allocation is packed ONCE, when it is made; NodeSelect(now, pending_jobs) then runs the cycle on the mirror
+  // (running jobs in ascending job id, the order of the reference's running-job map).  A new snapshot re-packs the
+  // mirror (dense node indices and GRES bit positions are per snapshot).
+  void MallocResourceFromNode(const CranedId& craned_id, job_id_t job_id, const ResourceV3& resources);
+  void FreeResourceFromNode(const CranedId& craned_id, job_id_t job_id);
+  void SetRunningJobInfo(job_id_t job_id, TimeSec end_time, const std::string& reservation = "");
+  size_t MirroredRunningJobs() const;
+  // (`running_for_priority`: only read by a multifactor sorter, JobScheduler.cpp:7692-7746; not needed with BasicPriority)
+  void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                  const std::vector<std::unique_ptr<RnJobInScheduler>>* running_for_priority = nullptr);
+
   // The run-limit admission of the commit loop, batched: AccountMetaContainer::CheckAndMallocMetaResource
   // (AccountMetaContainer.cpp:180-224) for every job of `pending_jobs` — in THAT order, JobScheduler.cpp:1492 — that the
   // last NodeSelect started (`reason` empty).  results[i] = "" (admitted: `meta`'s usage maps now include the job, as
@@ -326,6 +344,10 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
                             double* write_back_ms, uint64_t* checksum);
   size_t PackRunningForBench(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs, bool use_cache,
                              uint64_t* checksum, double* pack_ms = nullptr);
+  // ... the same from the event-fed mirror.  *checksum_canonical (both functions) does not depend on the order of a job's
+  // per-node records (the explicit path walks an unordered_map, the mirror keeps event order).
+  size_t PackMirrorForBench(uint64_t* checksum_canonical, double* pack_ms = nullptr);
+  uint64_t LastRunningChecksumCanonical() const;
 
   bool Ok() const { return status_ == 0; }
   int LastStatus() const { return status_; }
@@ -334,6 +356,8 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
  private:
   struct Impl;
   std::unique_ptr<Impl> impl_;
+  void SelectPacked_(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
+                     const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs);
   IPrioritySorter* sorter_{nullptr};
   std::unordered_map<std::string, License> licenses_;
   uint64_t batch_{0};

@@ -1,3 +1,4 @@
+#include <map>
 // Drives GpuNodeSelectionAlgo the way JobScheduler::ScheduleThread_ drives SchedulerAlgo
 // (src/CraneCtld/JobScheduler.cpp:1375-1447): build PdJobInScheduler objects, call NodeSelect once,
 // read start_time / craned_ids / allocated_res / reason back.  Expected values are the hand-derived
@@ -90,6 +91,81 @@ static int pack_bench(int n_nodes, int n_jobs) {
   return g_fail != 0;
 }
 
+// Event-fed mirror: the adapter is told what CranedMetaContainer is told — MallocResourceFromNode at a job's
+// start, FreeResourceFromNode at its end — and must hand the engine the same running tables as the per-cycle walk over
+// the running vector (ascending job id).  Host-only.
+static int mirror_check(int n_nodes, int n_jobs) {
+  GpuNodeSelectionAlgo algo(0), ref(0);
+  ClusterSnapshot snap;
+  std::vector<CranedId> ids;
+  for (int i = 0; i < n_nodes; ++i) {
+    char name[16];
+    snprintf(name, sizeof name, "cn%05d", i);
+    snap.craned_metas.push_back(node(name, 64, 256));
+    ids.push_back(name);
+  }
+  snap.partitions = {{"CPU", ids}};
+  algo.SetClusterSnapshot(snap);
+  ref.SetClusterSnapshot(snap);
+  uint64_t x = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  std::map<job_id_t, std::unique_ptr<RnJobInScheduler>> live;   // what the controller's running-job map holds
+  auto start_job = [&](job_id_t id) {
+    auto r = std::make_unique<RnJobInScheduler>();
+    r->job_id = id; r->partition_id = "CPU"; r->start_time = 900; r->end_time = 2000 + (int64_t)(rnd() % 5000);
+    const int k = 1 + (int)(rnd() % 4);
+    for (int a = 0; a < k; ++a) {
+      ResourceInNodeV3& res = r->allocated_res[ids[rnd() % ids.size()]];
+      res.cpu_set.cpu_count = cpu_t(4);
+      const uint32_t c0 = (uint32_t)(rnd() % 60);
+      res.cpu_set.core_ids.clear();
+      for (uint32_t c = c0; c < c0 + 4; ++c) res.cpu_set.core_ids.insert(c);
+      res.memory_bytes = 8ull << 30;
+    }
+    for (const auto& [cid, res] : r->allocated_res) algo.MallocResourceFromNode(cid, id, r->allocated_res);   // cpp:1602-1604
+    algo.SetRunningJobInfo(id, r->end_time);
+    live[id] = std::move(r);
+  };
+  auto end_job = [&](job_id_t id) {
+    for (const auto& [cid, res] : live[id]->allocated_res) algo.FreeResourceFromNode(cid, id);
+    live.erase(id);
+  };
+  auto same = [&]() {
+    std::vector<std::unique_ptr<RnJobInScheduler>> vec;   // the vector NodeSelect would be handed, ascending job id
+    for (auto& [id, r] : live) { auto c = std::make_unique<RnJobInScheduler>(*r); vec.push_back(std::move(c)); }
+    uint64_t a = 0, b = 0;
+    double ms_m = 0, ms_v = 0;
+    const size_t na = algo.PackMirrorForBench(&a, &ms_m);
+    uint64_t raw;
+    const size_t nb = ref.PackRunningForBench(vec, false, &raw, &ms_v);
+    b = ref.LastRunningChecksumCanonical();
+    CHECK(na == nb && a == b && algo.MirroredRunningJobs() == live.size());
+    printf("  %zu running jobs, %zu allocation records: mirror %.2f ms, walk over the running vector %.2f ms, identical: %s\n",
+           live.size(), na, ms_m, ms_v, (na == nb && a == b) ? "yes" : "NO");
+  };
+  job_id_t next = 1;
+  for (int j = 0; j < n_jobs; ++j) start_job(next++);
+  same();
+  for (int round = 0; round < 3; ++round) {   // churn: jobs end in random order, new ones start, one end time changes
+    std::vector<job_id_t> idsv;
+    for (auto& [id, r] : live) idsv.push_back(id);
+    for (int e = 0; e < n_jobs / 10; ++e) {
+      const size_t i = rnd() % idsv.size();
+      end_job(idsv[i]);
+      idsv[i] = idsv.back(); idsv.pop_back();
+    }
+    for (int e = 0; e < n_jobs / 10; ++e) start_job(next++);
+    const job_id_t any = live.begin()->first;
+    live[any]->end_time += 777;
+    algo.SetRunningJobInfo(any, live[any]->end_time);
+    same();
+  }
+  algo.SetClusterSnapshot(snap);   // a new snapshot re-packs the mirror (dense indices / GRES bits are per snapshot)
+  same();
+  printf("%s\n", g_fail ? "FAIL" : "ok");
+  return g_fail != 0;
+}
+
 // Host-side cost of the pending side of one cycle: cns_job_soa packing and the write-back of the placements into the
 // PdJobInScheduler objects; needs no device.
 static int cycle_bench(int n_nodes, int n_jobs) {
@@ -121,6 +197,7 @@ static int cycle_bench(int n_nodes, int n_jobs) {
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000);
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
+  if (argc > 1 && !strcmp(argv[1], "--mirror-check")) return mirror_check(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 20000);
   if (argc > 1 && !strcmp(argv[1], "--config-checks")) {
     // configurations the engine cannot serve are refused when the SNAPSHOT is set (host-only; no device needed), so
     // that the integrator keeps the CPU SchedulerAlgo instead of seeing "GpuEngineError" on every job of every cycle

@@ -40,3 +40,10 @@ def test_unsupported_configurations_are_refused_at_the_snapshot(built):
     (host-only check), not as silently wrong placements or a per-cycle GpuEngineError."""
     r = subprocess.run([EXE, "--config-checks"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+def test_event_fed_mirror_equals_running_vector_walk(built):
+    """fed by MallocResourceFromNode / FreeResourceFromNode, the adapter hands the engine the same running
+    tables as the per-cycle walk over the running vector (after churn, an end-time change and a new snapshot)."""
+    r = subprocess.run([EXE, "--mirror-check", "2048", "20000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
