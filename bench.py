@@ -66,6 +66,7 @@ def main():
     # rank too — a self-test of that path on a 1-GPU box; the reported line is then not a headline number
     use_dist = world > 1 or os.environ.get("CNS_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        os.environ.setdefault("NCCL_DEBUG", "WARN")   # no RCCL version banner on stdout next to the one JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
