@@ -26,6 +26,7 @@ per_job = {1: "supervisor: decision -> task", 4: "supervisor: serial-mode jobs",
 for k, v in per_job.items():
     print(f"  {v:40s} {m[k]/jobs:10.0f} cyc/job")
 print(f"  {'#tasks':40s} {m[5]:10.0f}   #serial jobs {m[2]:.0f}   #flushes {m[3]:.0f}   #scans (w6) {m[18]:.0f}")
+print(f"  scanner w0 scans: full {m[28]:.0f}, lean {m[25]:.0f}")
 busy = m[8:13]
 print(f"  tester busy cycles per task (all testers): {busy.sum()/max(m[5],1):.0f}; per tester share of the kernel: "
       + ", ".join(f"{b/max(m[19],1):.2f}" for b in busy))
