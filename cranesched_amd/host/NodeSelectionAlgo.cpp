@@ -329,6 +329,88 @@ struct GpuNodeSelectionAlgo::Impl {
     fill_res(r, cpu_raw, mem, lo, hi, g);
     return r;
   }
+
+  // ---- the last cycle's packed placements, kept for the wire emission ---------------------------------------------
+  struct PlacementStore {
+    std::vector<int64_t> start, cpu;
+    std::vector<uint8_t> reason, excl;
+    std::vector<uint64_t> off, mem, lo, hi, g, msw_node, msw_task;   // msw_*: the job's memory_sw request (node + per task)
+    std::vector<uint32_t> node, nt;
+    size_t jobs = 0;
+  } last;
+  uint64_t mem_sw_of(size_t j, uint64_t q) const {   // what write_back puts into memory_sw_bytes
+    return last.excl[j] ? node_mem_sw[last.node[q]] : last.msw_node[j] + last.msw_task[j] * last.nt[q];
+  }
+
+  // ---- protobuf wire format (varint / length-delimited / fixed64), fields in number order ---------------------------
+  static void put_varint(std::string& s, uint64_t v) {
+    while (v >= 0x80) { s.push_back((char)(v | 0x80)); v >>= 7; }
+    s.push_back((char)v);
+  }
+  static size_t varint_size(uint64_t v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
+  static void put_bytes(std::string& s, uint32_t field, const char* p, size_t n) {
+    put_varint(s, ((uint64_t)field << 3) | 2u);
+    put_varint(s, n);
+    s.append(p, n);
+  }
+  static void put_str(std::string& s, uint32_t field, const std::string& v) { put_bytes(s, field, v.data(), v.size()); }
+  static void put_u64(std::string& s, uint32_t field, uint64_t v) {   // proto3: a zero scalar is not written
+    if (!v) return;
+    put_varint(s, (uint64_t)field << 3);
+    put_varint(s, v);
+  }
+  // crane.grpc.DedicatedResourceInNode of a slot mask: map<name, DeviceTypeSlotsMap{map<type, Slots{repeated string}>}>
+  // (PublicDefs.proto:33-44).  `classes` is sorted by (name, type), so the classes of one name are adjacent.
+  void append_gres_wire(std::string& out, uint64_t g, std::string& tmp_name, std::string& tmp_type, std::string& tmp_slots) const {
+    size_t c = 0;
+    while (c < classes.size()) {
+      size_t e = c;
+      tmp_name.clear();   // DeviceTypeSlotsMap of this name
+      for (; e < classes.size() && classes[e].first == classes[c].first; ++e) {
+        const uint64_t w = layout.class_width[e] >= 64 ? ~0ull : ((1ull << layout.class_width[e]) - 1ull);
+        uint64_t bits = (g >> layout.class_shift[e]) & w;
+        if (!bits) continue;
+        tmp_slots.clear();  // Slots
+        for (; bits; bits &= bits - 1) put_str(tmp_slots, 1, class_bit_slot[e][(uint32_t)__builtin_ctzll(bits)]);
+        tmp_type.clear();   // map entry {1: type, 2: Slots}
+        put_str(tmp_type, 1, classes[e].second);
+        put_str(tmp_type, 2, tmp_slots);
+        put_str(tmp_name, 1, tmp_type);
+      }
+      if (!tmp_name.empty()) {
+        tmp_type.clear();   // map entry {1: name, 2: DeviceTypeSlotsMap}
+        put_str(tmp_type, 1, classes[c].first);
+        put_str(tmp_type, 2, tmp_name);
+        put_str(out, 1, tmp_type);
+      }
+      c = e;
+    }
+  }
+  // crane.grpc.ResourceInNodeV3 (PublicDefs.proto:63-69) of one packed allocation
+  void append_res_wire(std::string& out, int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t lo, uint64_t hi, uint64_t g,
+                       std::string& t1, std::string& t2, std::string& t3, std::string& t4) const {
+    if (lo | hi) {   // repeated uint32 cpu_ids = 1, packed, ascending (std::set order)
+      size_t n = 0;
+      for (uint64_t m = lo; m; m &= m - 1) n += 1;                                       // ids 0..63: one byte each
+      for (uint64_t m = hi; m; m &= m - 1) n += varint_size(64u + (uint32_t)__builtin_ctzll(m));
+      out.push_back((char)0x0A);
+      put_varint(out, n);
+      for (uint64_t m = lo; m; m &= m - 1) out.push_back((char)__builtin_ctzll(m));
+      for (uint64_t m = hi; m; m &= m - 1) put_varint(out, 64u + (uint32_t)__builtin_ctzll(m));
+    }
+    if (cpu_raw != 0) {   // double cpu_count = 2: static_cast<double>(cpu_t) = raw / 2^8, exact
+      const double d = (double)cpu_raw / 256.0;
+      uint64_t b;
+      std::memcpy(&b, &d, 8);
+      out.push_back((char)0x11);
+      for (int i = 0; i < 8; ++i) out.push_back((char)(b >> (8 * i)));
+    }
+    put_u64(out, 3, mem);
+    put_u64(out, 4, mem_sw);
+    t4.clear();           // DedicatedResourceInNode gres = 5: always present (mutable_gres(), PublicHeader.cpp:994)
+    if (g) append_gres_wire(t4, g, t1, t2, t3);
+    put_str(out, 5, t4);
+  }
 };
 
 GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(int device, uint64_t scheduled_batch_size) : impl_(new Impl) {
@@ -375,6 +457,14 @@ void GpuNodeSelectionAlgo::PendingCycleForBench(const std::vector<std::unique_pt
   t0 = std::chrono::steady_clock::now();
   I.write_back(ord, o);
   *write_back_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  {  // the same placements as "the last cycle" of the wire emission (EmitWireForBench)
+    Impl::PlacementStore& S = I.last;
+    S.start = st; S.cpu = cpu; S.reason = rs; S.off = off; S.mem = mem; S.lo = lo; S.hi = hi; S.g = g; S.node = node; S.nt = ntk;
+    S.excl.assign(J, 0); S.msw_node.assign(J, 0); S.msw_task.assign(J, 0);
+    S.jobs = J;
+    I.last_ord.assign(ord.begin(), ord.end());
+    I.last_index.clear();
+  }
   uint64_t hsh = 1469598103934665603ull;
   auto mix = [&](const void* p, size_t n) { const unsigned char* c = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { hsh ^= c[i]; hsh *= 1099511628211ull; } };
   mix(B.part.data(), J * 4); mix(B.L.data(), J * 8); mix(B.tcpu.data(), J * 8); mix(B.tmem.data(), J * 8); mix(B.k.data(), J * 4);
@@ -644,23 +734,114 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
 
   uint64_t places = 0;
   for (size_t j = 0; j < J; ++j) places += k[j];
-  std::vector<int64_t> o_start(J + 1), o_cpu(places + 1);
-  std::vector<uint8_t> o_reason(J + 1);
-  std::vector<uint64_t> o_off(J + 1), o_mem(places + 1), o_lo(places + 1), o_hi(places + 1), o_g(places + 1);
-  std::vector<uint32_t> o_node(places + 1), o_nt(places + 1);
+  Impl::PlacementStore& S = I.last;   // kept after the cycle: the wire emission reads the packed placements
+  S.jobs = 0;
+  S.start.assign(J + 1, 0); S.cpu.assign(places + 1, 0); S.reason.assign(J + 1, 0); S.off.assign(J + 1, 0);
+  S.mem.assign(places + 1, 0); S.lo.assign(places + 1, 0); S.hi.assign(places + 1, 0); S.g.assign(places + 1, 0);
+  S.node.assign(places + 1, 0); S.nt.assign(places + 1, 0);
+  S.excl.resize(J); S.msw_node.resize(J); S.msw_task.resize(J);
+  for (size_t j = 0; j < J; ++j) {
+    S.excl[j] = ord[j]->exclusive;
+    S.msw_node[j] = ord[j]->req_node_res_view.memory_sw_bytes;
+    S.msw_task[j] = ord[j]->req_task_res_view.memory_sw_bytes;
+  }
   cns_placement_soa out{};
   out.place_capacity = places;
-  out.start_sec = o_start.data(); out.reason = o_reason.data(); out.place_offsets = o_off.data();
-  out.node_idx = o_node.data(); out.ntasks = o_nt.data(); out.cpu_raw = o_cpu.data(); out.mem = o_mem.data();
-  out.core_lo = o_lo.data(); out.core_hi = o_hi.data(); out.gres = o_g.data();
+  out.start_sec = S.start.data(); out.reason = S.reason.data(); out.place_offsets = S.off.data();
+  out.node_idx = S.node.data(); out.ntasks = S.nt.data(); out.cpu_raw = S.cpu.data(); out.mem = S.mem.data();
+  out.core_lo = S.lo.data(); out.core_hi = S.hi.data(); out.gres = S.g.data();
   I.last_index.clear();
   I.last_ord.clear();
   st = cns_select(I.h, now, &js, &out);
   if (st != 0) return fail_all(st, cns_last_error(I.h));
   I.last_ord.assign(ord.begin(), ord.end());
+  S.jobs = J;
   status_ = 0;
   error_.clear();
   I.write_back(ord, out);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Placement -> wire
+// ---------------------------------------------------------------------------------------------------------
+const std::vector<const PdJobInScheduler*>& GpuNodeSelectionAlgo::LastOrder() const { return impl_->last_ord; }
+
+size_t GpuNodeSelectionAlgo::EmitStartedResourcesWire(WireBatch* out) const {
+  const Impl& I = *impl_;
+  const Impl::PlacementStore& S = I.last;
+  out->bytes.clear();
+  out->recs.clear();
+  std::string t1, t2, t3, t4;
+  for (size_t j = 0; j < S.jobs; ++j) {
+    if (S.reason[j] != CNS_REASON_NONE || S.start[j] == 0) continue;   // only a job that starts now is dispatched (cpp:1507-1510)
+    for (uint64_t q = S.off[j]; q < S.off[j + 1]; ++q) {
+      if (S.node[q] == CNS_NODE_NONE) continue;
+      const size_t at = out->bytes.size();
+      I.append_res_wire(out->bytes, S.cpu[q], S.mem[q], I.mem_sw_of(j, q), S.lo[q], S.hi[q], S.g[q], t1, t2, t3, t4);
+      out->recs.push_back({(uint32_t)j, S.node[q], (uint32_t)at, (uint32_t)(out->bytes.size() - at)});
+    }
+  }
+  return out->recs.size();
+}
+
+bool GpuNodeSelectionAlgo::AppendResourceInNodeV3Wire(const PdJobInScheduler& job, const CranedId& craned_id, std::string* out) {
+  Impl& I = *impl_;
+  const Impl::PlacementStore& S = I.last;
+  if (I.last_index.size() != I.last_ord.size()) {
+    I.last_index.clear();
+    I.last_index.reserve(I.last_ord.size());
+    for (size_t j = 0; j < I.last_ord.size(); ++j) I.last_index[I.last_ord[j]] = j;
+  }
+  auto li = I.last_index.find(&job);
+  auto ni = I.node_idx.find(craned_id);
+  if (li == I.last_index.end() || ni == I.node_idx.end() || li->second >= S.jobs || S.start[li->second] == 0) return false;
+  const size_t j = li->second;
+  std::string t1, t2, t3, t4;
+  for (uint64_t q = S.off[j]; q < S.off[j + 1]; ++q)
+    if (S.node[q] == ni->second) {
+      I.append_res_wire(*out, S.cpu[q], S.mem[q], I.mem_sw_of(j, q), S.lo[q], S.hi[q], S.g[q], t1, t2, t3, t4);
+      return true;
+    }
+  return false;
+}
+
+void GpuNodeSelectionAlgo::ComposeJobToDWire(uint32_t job_id, uint32_t uid, const std::string& partition, const std::string& account,
+                                             const std::string& qos, const std::string& name, const std::string& res_wire,
+                                             std::string* out) {
+  Impl::put_u64(*out, 1, job_id);
+  Impl::put_u64(*out, 2, uid);
+  Impl::put_str(*out, 4, res_wire);   // a message field is written whenever it is set (mutable_res(), CtldPublicDefs.cpp:537-554)
+  if (!partition.empty()) Impl::put_str(*out, 5, partition);
+  if (!account.empty()) Impl::put_str(*out, 6, account);
+  if (!qos.empty()) Impl::put_str(*out, 7, qos);
+  if (!name.empty()) Impl::put_str(*out, 9, name);
+}
+
+bool GpuNodeSelectionAlgo::AppendJobToDWire(const PdJobInScheduler& job, uint32_t uid, const std::string& name,
+                                            const CranedId& craned_id, std::string* out) {
+  std::string res;
+  if (!AppendResourceInNodeV3Wire(job, craned_id, &res)) return false;
+  ComposeJobToDWire(job.job_id, uid, job.partition_id, job.account, job.qos, name, res, out);
+  return true;
+}
+
+void GpuNodeSelectionAlgo::WireOfPackedForTest(int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t core_lo, uint64_t core_hi,
+                                               uint64_t gres, std::string* wire, ResourceInNodeV3* obj) const {
+  const Impl& I = *impl_;
+  std::string t1, t2, t3, t4;
+  I.append_res_wire(*wire, cpu_raw, mem, mem_sw, core_lo, core_hi, gres, t1, t2, t3, t4);
+  *obj = ResourceInNodeV3{};
+  I.fill_res(*obj, cpu_raw, mem, core_lo, core_hi, gres);
+  obj->memory_sw_bytes = mem_sw;
+}
+
+double GpuNodeSelectionAlgo::EmitWireForBench(size_t* records, size_t* bytes) {
+  WireBatch wb;
+  const auto t0 = std::chrono::steady_clock::now();
+  *records = EmitStartedResourcesWire(&wb);
+  const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  *bytes = wb.bytes.size();
+  return ms;
 }
 
 

@@ -349,6 +349,34 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   size_t PackMirrorForBench(uint64_t* checksum_canonical, double* pack_ms = nullptr);
   uint64_t LastRunningChecksumCanonical() const;
 
+  // ---- placement -> wire: the protobuf encoding of what JobToD carries, written straight from the
+  // packed placements of the last NodeSelect — no ResourceInNodeV3 object, no std::set, no map is built on the way.
+  //   crane.grpc.ResourceInNodeV3 {cpu_ids=1 (packed), cpu_count=2, memory_bytes=3, memory_sw_bytes=4, gres=5}
+  //                                                  protos/PublicDefs.proto:63-69, PublicHeader.cpp:981-998,255-266
+  //   crane.grpc.JobToD {job_id=1, uid=2, res=4, partition=5, account=6, qos=7, name=9}
+  //                                                  protos/PublicDefs.proto:396-409, CtldPublicDefs.cpp:537-554
+  // Fields are written in field-number order, map entries in (name, type) order and slots in std::set order, i.e. what
+  // protobuf's deterministic serialisation of the reference's message produces.
+  struct WireBatch {
+    struct Rec { uint32_t job, node, off, len; };   // job: index in the vector handed to NodeSelect's order (LastOrder())
+    std::string bytes;                              // the serialised ResourceInNodeV3 messages, back to back
+    std::vector<Rec> recs;                          // one per (job that starts now, allocated node), queue order
+  };
+  // every allocation of the jobs that start in this cycle; returns the number of records
+  size_t EmitStartedResourcesWire(WireBatch* out) const;
+  const std::vector<const PdJobInScheduler*>& LastOrder() const;
+  // one allocation / one JobToD of a job of the last cycle (appends to *out; false: job or node not in the last cycle's result)
+  bool AppendResourceInNodeV3Wire(const PdJobInScheduler& job, const CranedId& craned_id, std::string* out);
+  bool AppendJobToDWire(const PdJobInScheduler& job, uint32_t uid, const std::string& name, const CranedId& craned_id,
+                        std::string* out);
+  static void ComposeJobToDWire(uint32_t job_id, uint32_t uid, const std::string& partition, const std::string& account,
+                                const std::string& qos, const std::string& name, const std::string& res_wire, std::string* out);
+  // test / bench hook (no device): the wire bytes and the ResourceInNodeV3 object of one packed allocation
+  void WireOfPackedForTest(int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t core_lo, uint64_t core_hi, uint64_t gres,
+                           std::string* wire, ResourceInNodeV3* obj) const;
+  // ... and the emission of PendingCycleForBench's synthetic placements (ms per call)
+  double EmitWireForBench(size_t* records, size_t* bytes);
+
   bool Ok() const { return status_ == 0; }
   int LastStatus() const { return status_; }
   const std::string& LastError() const { return error_; }

@@ -190,13 +190,82 @@ static int cycle_bench(int n_nodes, int n_jobs) {
   printf("cycle-bench: %d nodes, %d pending jobs (all placed, 1 node x 4 cores each), 1 host thread\n", n_nodes, n_jobs);
   printf("  pack  PdJobInScheduler -> cns_job_soa : %8.2f ms = %.2f us / job\n", pack_ms, 1e3 * pack_ms / n_jobs);
   printf("  write placements -> PdJobInScheduler  : %8.2f ms = %.2f us / job\n", wb_ms, 1e3 * wb_ms / n_jobs);
+  size_t recs = 0, bytes = 0;
+  double wire_ms = algo.EmitWireForBench(&recs, &bytes);
+  wire_ms = std::min(wire_ms, algo.EmitWireForBench(&recs, &bytes));
+  CHECK(recs == (size_t)n_jobs);
+  printf("  placements -> ResourceInNodeV3 wire    : %8.2f ms = %.3f us / job (%zu records, %.1f MB, no objects built)\n", wire_ms,
+         1e3 * wire_ms / n_jobs, recs, bytes / 1e6);
+  std::string one;
+  CHECK(algo.AppendResourceInNodeV3Wire(*pd[n_jobs / 2], pd[n_jobs / 2]->craned_ids[0], &one) && !one.empty());
   printf("%s\n", g_fail ? "FAIL" : "ok");
   return g_fail != 0;
+}
+
+// Placement -> wire: random packed allocations on a node with two GRES names / three types; for every one
+// the adapter's wire bytes and, as text, the fields of the ResourceInNodeV3 object the write-back builds from the same
+// packed record.  tests/test_wire.py decodes the bytes with protobuf (message classes built from
+// protos/PublicDefs.proto:33-44,63-69,396-409) and compares.  Host-only.
+static int wire_dump(const char* path, int n, bool jobtod) {
+  GpuNodeSelectionAlgo algo(0);
+  ClusterSnapshot snap;
+  CranedMeta m = node("cn0", 128, 512);
+  for (int i = 0; i < 8; ++i) m.res_total.gres["gpu"]["a100"].insert("/dev/nvidia" + std::to_string(i));
+  for (int i = 0; i < 4; ++i) m.res_total.gres["gpu"]["h100"].insert("/dev/nvidia1" + std::to_string(i));
+  for (int i = 0; i < 6; ++i) m.res_total.gres["npu"]["910b"].insert("/dev/davinci" + std::to_string(i));
+  snap.craned_metas.push_back(m);
+  snap.partitions = {{"GPU", {"cn0"}}};
+  algo.SetClusterSnapshot(snap);
+  FILE* f = fopen(path, "w");
+  if (!f) return 1;
+  uint64_t x = 0x243F6A8885A308D3ull;
+  auto rnd = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+  for (int i = 0; i < n; ++i) {
+    const int mode = i % 6;
+    uint64_t lo = rnd() & rnd(), hi = rnd() & rnd() & rnd(), g = rnd() & 0x3FFFF;   // 18 slots in the snapshot
+    int64_t cpu = 256 * (int64_t)(__builtin_popcountll(lo) + __builtin_popcountll(hi));
+    uint64_t mem = (rnd() % 1000) << 20, msw = (rnd() % 3) ? mem : mem + (1ull << 30);
+    if (mode == 1) { lo = hi = 0; cpu = 1 + (int64_t)(rnd() % 2000); }      // fractional: no core ids (PublicHeader.h:550-556)
+    if (mode == 2) g = 0;
+    if (mode == 3) { g &= 0xFF; }                                            // one type only
+    if (mode == 4) { lo = hi = 0; cpu = 0; mem = 0; msw = 0; g = 0; }       // all defaults
+    if (mode == 5) { hi = ~0ull; lo = ~0ull; cpu = 128 * 256; }
+    std::string wire;
+    ResourceInNodeV3 obj;
+    algo.WireOfPackedForTest(cpu, mem, msw, lo, hi, g, &wire, &obj);
+    fprintf(f, "REC %zu\nHEX ", wire.size());
+    for (unsigned char c : wire) fprintf(f, "%02x", c);
+    fprintf(f, "\nCPU %.17g\nMEM %llu %llu\nIDS", (double)obj.cpu_set.cpu_count.raw / 256.0, (unsigned long long)obj.memory_bytes,
+            (unsigned long long)obj.memory_sw_bytes);
+    for (uint32_t c : obj.cpu_set.core_ids) fprintf(f, " %u", c);
+    fprintf(f, "\n");
+    for (const auto& [name, tm] : obj.gres)
+      for (const auto& [type, slots] : tm) {
+        fprintf(f, "GRES %s %s", name.c_str(), type.c_str());
+        for (const auto& sl : slots) fprintf(f, " %s", sl.c_str());
+        fprintf(f, "\n");
+      }
+    if (jobtod) {   // crane.grpc.JobToD around the same ResourceInNodeV3 (empty strings / zero ids are not written)
+      const uint32_t job_id = (i % 7) ? (uint32_t)(rnd() % 5000000) : 0, uid = (i % 5) ? (uint32_t)(1000 + rnd() % 60000) : 0;
+      const std::string part = (i % 4) ? "GPU" : "", acct = "acct" + std::to_string(i % 9), qos = (i % 3) ? "normal" : "",
+                        name = (i % 6) ? "job_" + std::to_string(i) : "";
+      std::string jw;
+      GpuNodeSelectionAlgo::ComposeJobToDWire(job_id, uid, part, acct, qos, name, wire, &jw);
+      fprintf(f, "JOB %u %u %s %s %s %s\nJOBHEX ", job_id, uid, part.empty() ? "-" : part.c_str(), acct.c_str(), qos.empty() ? "-" : qos.c_str(), name.empty() ? "-" : name.c_str());
+      for (unsigned char c : jw) fprintf(f, "%02x", c);
+      fprintf(f, "\n");
+    }
+    fprintf(f, "END\n");
+  }
+  fclose(f);
+  printf("wire-dump: %d records -> %s\n", n, path);
+  return 0;
 }
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000);
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
+  if (argc > 2 && !strcmp(argv[1], "--wire-dump")) return wire_dump(argv[2], argc > 3 ? atoi(argv[3]) : 600, argc > 4 && !strcmp(argv[4], "jobtod"));
   if (argc > 1 && !strcmp(argv[1], "--mirror-check")) return mirror_check(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 20000);
   if (argc > 1 && !strcmp(argv[1], "--config-checks")) {
     // configurations the engine cannot serve are refused when the SNAPSHOT is set (host-only; no device needed), so
@@ -523,6 +592,18 @@ int main(int argc, char** argv) {
     pd.push_back(job(2, 2, 100));
     algo.NodeSelect(now, pd);
     CHECK(pd[0]->is_scheduled() && pd[0]->craned_ids[0] == want0 && pd[1]->start_time == want1);
+    // ... and what goes on the wire for it: one record, for the job that starts now, equal to the per-job emission
+    GpuNodeSelectionAlgo::WireBatch wb;
+    CHECK(algo.EmitStartedResourcesWire(&wb) == 1 && wb.recs.size() == 1);
+    if (wb.recs.size() == 1) {
+      CHECK(algo.LastOrder()[wb.recs[0].job] == pd[0].get());
+      std::string one, jtd;
+      CHECK(algo.AppendResourceInNodeV3Wire(*pd[0], want0, &one) && one == wb.bytes.substr(wb.recs[0].off, wb.recs[0].len));
+      // {cpu_ids [c], cpu_count 1.0, memory_bytes = request, memory_sw_bytes, gres {}}: 0A 01 cc 11 <1.0> 18 .. 20 .. 2A 00
+      CHECK(one.size() > 12 && (unsigned char)one[0] == 0x0A && one[1] == 1 && (unsigned char)one[3] == 0x11 && one.back() == 0);
+      CHECK(!algo.AppendResourceInNodeV3Wire(*pd[1], want0, &one));   // backfilled for later: nothing to dispatch
+      CHECK(algo.AppendJobToDWire(*pd[0], 1000, "j", want0, &jtd) && jtd.size() > one.size());
+    }
   }
   printf("%s\n", g_fail ? "FAIL" : "ok");
   return g_fail != 0;
