@@ -91,7 +91,7 @@ struct cns_engine {
   // device buffers
   DevBuf d_part_off, d_slot_node, d_type_total, d_blocks, d_cost, d_fcpu,
       d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
-  DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results, d_params, d_prof;
+  DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results, d_params, d_prof, d_wide;
   DevBuf d_raw[16];  // the caller's job arrays as uploaded (k_pack_jobs reads them; d_raw[14] = place offsets)
   // job table
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
@@ -207,6 +207,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.g_upd = h->d_gupd.as<UpdRec>();
   K.fault = h->d_fault.as<u32>();
   K.prof = h->d_prof.as<u64>();
+  K.wide_ctl = h->d_wide.as<char>();
   K.gres = h->gres;
   if (h->shared) {
     K.slot_block = h->d_slot_block.as<u32>(); K.sib_off = h->d_sib_off.as<u32>(); K.sib = h->d_sib.as<u32>();
@@ -222,16 +223,47 @@ template <int NPL>
 void launch_pipe(cns_engine* h, const KParams& K) {
   hipLaunchKernelGGL((k_pipe<NPL>), dim3(h->P), dim3(kPBlock), 0, h->stream, K, h->d_params.as<KParams>());
 }
+// k_wide: 1 + 8 workgroups per partition; the workgroups of a partition share blockIdx % 8 (= the XCD, observed).  A pad of
+// dynamic LDS keeps it at one workgroup per CU (one scanner wave per SIMD is the point of the kernel).
+template <int NPL>
+int launch_wide(cns_engine* h, const KParams& K) {
+  const unsigned groups = (h->P + 7u) / 8u;
+  const unsigned grid = 8u * groups * (unsigned)kWGroup;
+  const size_t need = (size_t)h->P * sizeof(WideCtl);
+  if (h->d_wide.ensure(need) != hipSuccess) return 1;
+  if (hipMemsetAsync(h->d_wide.p, 0, need, h->stream) != hipSuccess) return 1;
+  KParams K2 = K;
+  K2.wide_ctl = h->d_wide.as<char>();
+  if (hipMemcpyAsync(&h->d_params.as<KParams>()->wide_ctl, &K2.wide_ctl, sizeof(char*), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+  size_t dyn = 0;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, (const void*)k_wide<NPL>) == hipSuccess && fa.sharedSizeBytes < 84u * 1024u) {
+    dyn = 84u * 1024u - fa.sharedSizeBytes;
+    if (hipFuncSetAttribute((const void*)k_wide<NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { dyn = 0; (void)hipGetLastError(); }
+  }
+  hipLaunchKernelGGL((k_wide<NPL>), dim3(grid), dim3(kWBlock), dyn, h->stream, K2, h->d_params.as<KParams>());
+  return 0;
+}
 // Which selection kernel runs: k_pipe (decoupled test / commit pipeline) for partitions its tile covers, k_select
 // otherwise.  CNS_SELECT_KERNEL=legacy|pipe forces one (A/B measurements, and the parity tests run both).
 #ifndef CNS_DEFAULT_PIPE
 #define CNS_DEFAULT_PIPE 1
 #endif
+#ifndef CNS_DEFAULT_WIDE
+#define CNS_DEFAULT_WIDE 0
+#endif
+// k_wide (many CUs per partition) when every workgroup of the launch can be resident at once and the partitions fit its tile
+bool use_wide_kernel(const cns_engine* h) {
+  const char* e = getenv("CNS_SELECT_KERNEL");
+  bool want = CNS_DEFAULT_WIDE != 0;
+  if (e) want = !strcmp(e, "wide");
+  return want && !h->shared && h->P <= kWMaxParts && h->max_np <= kWLanes * (u32)kWNplMax;
+}
 bool use_pipe_kernel(const cns_engine* h) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_PIPE != 0;
   if (e && !strcmp(e, "legacy")) want = false;
-  if (e && !strcmp(e, "pipe")) want = true;
+  if (e && (!strcmp(e, "pipe") || !strcmp(e, "wide"))) want = true;
   return want && !h->shared && h->max_np <= kPScan * (u32)kPNplMax;   // (shared nodes: k_select's sequential protocol)
 }
 
@@ -310,7 +342,7 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   HIPCHK(h, h->d_bfj.ensure(S1 * sizeof(u32)));
   HIPCHK(h, h->d_gupd.ensure(S1 * sizeof(UpdRec)));
   HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
-  HIPCHK(h, h->d_prof.ensure((size_t)h->P * 32 * sizeof(u64)));
+  HIPCHK(h, h->d_prof.ensure((size_t)(h->P + 8) * (size_t)kWGroup * 32 * sizeof(u64)));   // (k_wide: blocks > partitions)
   // no running jobs until cns_set_running
   std::vector<u32> rn_off(S + 1, 0);
   if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
@@ -368,7 +400,7 @@ void cns_destroy(cns_handle* h) {
   for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_type_total,
                     &h->d_blocks, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
                     &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_gupd, &h->d_fault, &h->d_pj_off, &h->d_jobs,
-                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof, &h->d_slot_total,
+                    &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof, &h->d_wide, &h->d_slot_total,
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
@@ -785,7 +817,12 @@ int cns_run_resident(cns_handle* h, int64_t now) {
     launch_select<CNS_ONLY_NPL>(h, K);
 #else
     bool launched = false;
-    if (use_pipe_kernel(h)) {
+    if (use_wide_kernel(h)) {
+#define CNS_TRY_WWIDTH(w) if (!launched && np <= kWLanes * (w)) { if (launch_wide<w>(h, K)) return fail(h, CNS_ERR_HIP, "k_wide: control block allocation / upload failed"); launched = true; h->last_kernel = "k_wide<" #w ">"; }
+      CNS_WNPL_LIST(CNS_TRY_WWIDTH)
+#undef CNS_TRY_WWIDTH
+    }
+    if (!launched && use_pipe_kernel(h)) {
 #define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; h->last_kernel = "k_pipe<" #w ">"; }
       CNS_PNPL_LIST(CNS_TRY_PWIDTH)
 #undef CNS_TRY_PWIDTH

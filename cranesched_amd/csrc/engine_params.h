@@ -129,6 +129,7 @@ struct KParams {
   UpdRec* g_upd;           // [S] owner updates of selections larger than the LDS list
   u32* fault;              // [4] != 0: an internal invariant failed (code, job, aux, aux)
   u64* prof;               // [P*32] cycle counters (only written by -DCNS_PROF builds)
+  char* wide_ctl;          // [P] WideCtl blocks of k_wide (exchange rings + control words), zeroed before every launch
   GresDev gres;
   // ---- partitions that share nodes (null otherwise) ----------------------------------------------------------------
   const u32* slot_block;   // [S] slot whose NodeBlock holds the node's (shared) time map = the node's first slot

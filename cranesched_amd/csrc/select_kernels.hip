@@ -972,6 +972,7 @@ struct WorkerShared {
   int* nupd;
   UpdRec* upd;
   HeapEnt* heap;
+  u32 part;   // engine partition this workgroup serves (k_select / k_pipe: blockIdx.x; k_wide: several workgroups per partition)
 };
 
 #ifdef CNS_PROF
@@ -1147,7 +1148,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
           if (!res_le(x.res, hdr_of(P, qx)->avail0)) notle = true;
           if (P.first_resv[qx] < P.now + J.L) reserved = true;
         }
-        const bool resv_part = blockIdx.x >= P.num_real_parts;
+        const bool resv_part = sh.part >= P.num_real_parts;
         reason = (!resv_part && __any(reserved)) ? 3 /*Resource Reserved*/ : (__any(notle) ? 2 /*Resource*/ : 1 /*Priority*/);
       }
       commit_selection<kS>(P, J, H, qbeg, t, lane, s_upd, s_nupd);
@@ -1614,7 +1615,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     }
     wg_barrier();  // type tables visible to the scanners
     WorkerShared sh;
-    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap;
+    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap; sh.part = part;
     HeapEnt* const gheap = P.heap + qbeg + part;
     // The worker is the serial chain of the whole partition and shares its SIMD with three scanner waves
     // that pre-scan the next job at the same time: let its instructions issue first.
@@ -2375,6 +2376,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 }
 
 #include "pipe_kernel.inc"
+#include "wide_kernel.inc"
 
 #ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
 template __global__ void k_select<CNS_ONLY_NPL>(const KParams, const KParams*);

@@ -35,6 +35,6 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
         t = eng.timing()
         print(f"{tag}: {jobs.num_jobs} jobs x {cluster.num_nodes} nodes identical to the oracle "
               f"(start-now {d['counts'][0]}, backfilled {d['counts'][1]}, failed {d['counts'][2]}); "
-              f"select {t['select_ms']:.1f} ms = {1e3 * jobs.num_jobs / t['select_ms']:.0f} decisions/s")
+              f"{eng.last_kernel()} {t['select_ms']:.1f} ms = {1e3 * jobs.num_jobs / t['select_ms']:.0f} decisions/s")
     finally:
         eng.close()
