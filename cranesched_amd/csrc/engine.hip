@@ -250,13 +250,14 @@ int launch_wide(cns_engine* h, const KParams& K) {
 #define CNS_DEFAULT_PIPE 1
 #endif
 #ifndef CNS_DEFAULT_WIDE
-#define CNS_DEFAULT_WIDE 0
+#define CNS_DEFAULT_WIDE 1
 #endif
 // k_wide (many CUs per partition) when every workgroup of the launch can be resident at once and the partitions fit its tile
 bool use_wide_kernel(const cns_engine* h) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_WIDE != 0;
-  if (e) want = !strcmp(e, "wide");
+  if (e && (!strcmp(e, "legacy") || !strcmp(e, "pipe"))) want = false;
+  if (e && !strcmp(e, "wide")) want = true;
   return want && !h->shared && h->P <= kWMaxParts && h->max_np <= kWLanes * (u32)kWNplMax;
 }
 bool use_pipe_kernel(const cns_engine* h) {

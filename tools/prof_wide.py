@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Cycle breakdown of k_wide (needs the -DCNS_PROF build):
+   CNS_SELECT_KERNEL=wide CNS_ENGINE_LIB=cranesched_amd/libcrane_gpu_nodeselect_prof.so python tools/prof_wide.py [config] [J] [N] [P]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from cranesched_amd import synth
+from cranesched_amd.engine import GpuNodeSelector
+
+name = sys.argv[1] if len(sys.argv) > 1 else "C4"
+J = int(sys.argv[2]) if len(sys.argv) > 2 else None
+N = int(sys.argv[3]) if len(sys.argv) > 3 else None
+P = int(sys.argv[4]) if len(sys.argv) > 4 else None
+c, j, now = synth.make_config(name, J=J, N=N, P=P)
+e = GpuNodeSelector()
+e.set_nodes(c); e.upload_jobs(j); e.run_resident(now)
+t = e.timing(); pr = e.prof().astype(np.float64)
+jobs = j.num_jobs / c.num_partitions
+m = pr.mean(axis=0)
+print(f"{name} J={j.num_jobs} N={c.num_nodes} P={c.num_partitions} {e.last_kernel()}: {t['select_ms']:.1f} ms = "
+      f"{1e3*t['select_ms']/jobs:.2f} us/job/partition; supervisor loop {m[28]/jobs:.0f} cycles/job "
+      f"(=> {m[28]/max(t['select_ms'],1e-9)/1e3:.0f} MHz counter)")
+rows = {19: "leader scanner: whole job", 16: "leader:   fetch + decode + row loop", 17: "leader:   lap guard (waiting for the supervisor)",
+        18: "leader:   argmins + publish + exchange wait", 21: "leader: stopped (command wait + reload)",
+        22: "supervisor: records -> task (incl. slot wait)", 23: "supervisor:   waiting for a free task slot", 26: "supervisor: stop handling"}
+for k, v in rows.items():
+    print(f"  {v:50s} {m[k]/jobs:10.0f} cyc/job")
+print(f"  leader jobs {m[20]:.0f}; supervisor: consumed {m[24]:.0f}, empty polls {m[27]:.0f}, stops {m[25]:.0f}, flushes {m[29]:.0f}")
+if m[15]:
+    print(f"  tester 0: {m[15]:.0f} tasks, dep wait {m[13]/m[15]:.0f} cyc/task, verdict wait {m[14]/m[15]:.0f} cyc/task")
