@@ -794,7 +794,9 @@ bool GpuNodeSelectionAlgo::AppendResourceInNodeV3Wire(const PdJobInScheduler& jo
   }
   auto li = I.last_index.find(&job);
   auto ni = I.node_idx.find(craned_id);
-  if (li == I.last_index.end() || ni == I.node_idx.end() || li->second >= S.jobs || S.start[li->second] == 0) return false;
+  if (li == I.last_index.end() || ni == I.node_idx.end() || li->second >= S.jobs || S.start[li->second] == 0 ||
+      S.reason[li->second] != CNS_REASON_NONE)   // only a job that starts now is dispatched
+    return false;
   const size_t j = li->second;
   std::string t1, t2, t3, t4;
   for (uint64_t q = S.off[j]; q < S.off[j + 1]; ++q)
