@@ -1,6 +1,6 @@
 #!/bin/bash
 # k_wide with the same-XCD exchange: parity, full-run digests, then the FAR variant and the cycle breakdown
-out=gpurun_out/w7; mkdir -p $out
+out=gpurun_out/w9; mkdir -p $out
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gpu_kat.py tests/test_gpu_parity.py tests/test_reservations.py -x -q -m gpu -k wide > $out/parity.log 2>&1
 echo "parity rc=$?" >> $out/parity.log

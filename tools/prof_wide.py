@@ -21,8 +21,8 @@ m = pr.mean(axis=0)
 print(f"{name} J={j.num_jobs} N={c.num_nodes} P={c.num_partitions} {e.last_kernel()}: {t['select_ms']:.1f} ms = "
       f"{1e3*t['select_ms']/jobs:.2f} us/job/partition; supervisor loop {m[28]/jobs:.0f} cycles/job "
       f"(=> {m[28]/max(t['select_ms'],1e-9)/1e3:.0f} MHz counter)")
-rows = {19: "leader scanner: whole job", 16: "leader:   preparation that was not speculative", 17: "leader:   lap guard (waiting for the supervisor)",
-        18: "leader:   publish + speculative preparation", 30: "leader:   exchange wait after it", 21: "leader: stopped (command wait + reload)",
+rows = {19: "leader scanner: whole job", 16: "leader:   (fetch + decode +) row loop", 17: "leader:   lap guard (waiting for the supervisor)",
+        18: "leader:   argmins + publish + exchange wait", 21: "leader: stopped (command wait + reload)",
         22: "supervisor: records -> task (incl. slot wait)", 23: "supervisor:   waiting for a free task slot", 26: "supervisor: stop handling"}
 for k, v in rows.items():
     print(f"  {v:50s} {m[k]/jobs:10.0f} cyc/job")
