@@ -7,14 +7,16 @@ src/CraneCtld/JobScheduler.cpp:6507-6836, bracket :1439-1447) over the synthetic
 with the job table and node snapshot already resident in HBM when the timed region starts.
 At N > 1 the queue is job-sharded by partition (rank r owns partitions p % N == r; partitions that share nodes
 stay together) and each step ends with one RCCL all-gather of the packed placement buffers; total work is fixed
-("strong").  A partition is ONE sequential chain on one workgroup, so with P = 8 partitions the curve is flat by
-construction: more GPUs do not add chains.
+("strong").  A partition is ONE sequential chain; k_wide spreads its per-job node scan over 8 more workgroups of the SAME
+XCD (exchange through that XCD's L2, ~0.4 us per job), so 8 partitions occupy 72 of 256 CUs and run concurrently on one
+GPU: more GPUs do not add chains and the curve is flat by construction (an exchange over xGMI would cost more per job
+than the whole chain does now).
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_pipe; k_select when CNS_SELECT_KERNEL=legacy) with the ALGORITHMIC
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_wide; k_pipe / k_select when CNS_SELECT_KERNEL=pipe / legacy) with the ALGORITHMIC
 bytes of SURVEY.md §8(d) (N_p*S_node + S_job + S_out per decision) over its HIP-event duration;
 `cpu_baseline` times the CPU oracle (a port of the reference algorithm; the reference itself cannot
 be built offline) on ONE WHOLE PARTITION of the same queue (partitions never interact), single pinned
@@ -208,7 +210,8 @@ def main():
                                    f"{cluster.num_partitions} disjoint partitions, CPU+mem+GRES(gpu/npu), FIFO, "
                                    f"seed 0x43524E45^{synth.CONFIGS[args.config]['idx']}",
                        "jobs": jobs.num_jobs, "nodes": cluster.num_nodes, "partitions": cluster.num_partitions,
-                       "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else "single GPU, one workgroup per partition",
+                       "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else
+                                   ("single GPU, 1 + 8 workgroups per partition (k_wide)" if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
                        "selection_kernel": kernel,
                        "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),
                                          "resource": int((r == 2).sum())},
@@ -219,8 +222,9 @@ def main():
                          "kernel": kernel, "algorithmic_bytes_per_launch": tm["algorithmic_bytes"],
                          "avg_launch_ms": avg_sel_ms,
                          "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); the node "
-                                 "tile is register-resident, so HBM traffic is ~1 % of this: the kernel is bound by the VALU "
-                                 "issue rate of the one CU a partition's sequential chain runs on (DESIGN.md 5), not by HBM"},
+                                 "tile is register-resident, so HBM traffic is ~1 % of this: the kernel is bound by the latency "
+                                 "of a partition's sequential chain (scan -> cross-CU exchange -> decision -> row update, "
+                                 "DESIGN.md 4c/5i), not by HBM"},
         }
         if incl is not None:
             line["incl_h2d_d2h"] = incl
