@@ -348,3 +348,104 @@ class Placements:
                 i = int(ne[0])
                 return (k, i, a[k][i].item(), b[k][i].item(), f"{len(ne)} mismatches")
         return None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# include/crane_gpu/preempt.h
+# ---------------------------------------------------------------------------------------------------------
+REASON_PREEMPTED = 7
+PREEMPT_REF_PENDING = 0x80000000
+
+
+class CnsPreemptSoa(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("num_qos", C.c_uint32), ("qos_preempt_offsets", C.c_void_p),
+                ("qos_preempt", C.c_void_p), ("pd_job_id", C.c_void_p), ("pd_qos", C.c_void_p),
+                ("pd_qos_priority", C.c_void_p), ("pd_priority", C.c_void_p), ("rn_job_id", C.c_void_p),
+                ("rn_qos", C.c_void_p), ("rn_qos_priority", C.c_void_p), ("rn_start_sec", C.c_void_p),
+                ("num_preempting", C.c_uint32), ("reserved0", C.c_uint32), ("preempting_job_ids", C.c_void_p)]
+
+
+class CnsPreemptOut(C.Structure):
+    _fields_ = [("capacity", C.c_uint64), ("offsets", C.c_void_p), ("preempted", C.c_void_p),
+                ("cancel_capacity", C.c_uint32), ("num_cancelled", C.c_uint32), ("cancelled_job_ids", C.c_void_p),
+                ("preempting_capacity", C.c_uint32), ("num_preempting", C.c_uint32), ("preempting_job_ids", C.c_void_p)]
+
+
+@dataclass
+class Preempt:
+    """Preemption inputs of one cycle (cns_preempt_soa): QoS preempt lists, the fields TryPreempt_ reads of the pending
+    and running jobs, and m_preempting_set_ as the previous cycle left it."""
+    qos_preempt: list                      # qos id -> list of qos ids it may preempt
+    pd_job_id: np.ndarray
+    pd_qos: np.ndarray
+    pd_qos_priority: np.ndarray
+    pd_priority: np.ndarray
+    rn_job_id: np.ndarray
+    rn_qos: np.ndarray
+    rn_qos_priority: np.ndarray
+    rn_start_sec: np.ndarray
+    preempting: np.ndarray = None
+    enabled: bool = True
+
+    def __post_init__(self):
+        self.pd_job_id = _arr(self.pd_job_id, np.uint32); n = len(self.pd_job_id)
+        self.pd_qos = _arr(self.pd_qos, np.uint32, n)
+        self.pd_qos_priority = _arr(self.pd_qos_priority, np.uint32, n)
+        self.pd_priority = _arr(self.pd_priority, np.float64, n)
+        self.rn_job_id = _arr(self.rn_job_id, np.uint32); r = len(self.rn_job_id)
+        self.rn_qos = _arr(self.rn_qos, np.uint32, r)
+        self.rn_qos_priority = _arr(self.rn_qos_priority, np.uint32, r)
+        self.rn_start_sec = _arr(self.rn_start_sec, np.int64, r)
+        self.preempting = _arr(self.preempting if self.preempting is not None else [], np.uint32)
+        off = [0]
+        flat = []
+        for lst in self.qos_preempt:
+            flat.extend(int(x) for x in lst)
+            off.append(len(flat))
+        self._off = np.asarray(off, np.uint32)
+        self._flat = np.asarray(flat if flat else [0], np.uint32)
+
+    def to_c(self) -> CnsPreemptSoa:
+        s = CnsPreemptSoa()
+        s.enabled, s.num_qos = int(self.enabled), len(self.qos_preempt)
+        s.qos_preempt_offsets, s.qos_preempt = _ptr(self._off), _ptr(self._flat)
+        for f in ("pd_job_id", "pd_qos", "pd_qos_priority", "pd_priority", "rn_job_id", "rn_qos", "rn_qos_priority", "rn_start_sec"):
+            setattr(s, f, _ptr(getattr(self, f)))
+        s.num_preempting, s.preempting_job_ids = len(self.preempting), _ptr(self.preempting if len(self.preempting) else np.zeros(1, np.uint32))
+        return s
+
+
+class PreemptOut:
+    """Caller-allocated preemption results (cns_preempt_out)."""
+
+    def __init__(self, num_jobs: int, num_running: int, capacity: int = 0):
+        self.num_jobs = num_jobs
+        cap = max(capacity or (num_jobs + num_running) * 4, 1)
+        self.capacity = cap
+        self.offsets = np.zeros(num_jobs + 1, np.uint64)
+        self.preempted = np.zeros(cap, np.uint32)
+        self.cancelled = np.zeros(max(num_running, 1), np.uint32)
+        self.preempting = np.zeros(max(2 * num_running, 1), np.uint32)
+        self._c = None
+
+    def to_c(self) -> CnsPreemptOut:
+        s = CnsPreemptOut()
+        s.capacity, s.offsets, s.preempted = self.capacity, _ptr(self.offsets), _ptr(self.preempted)
+        s.cancel_capacity, s.cancelled_job_ids = len(self.cancelled), _ptr(self.cancelled)
+        s.preempting_capacity, s.preempting_job_ids = len(self.preempting), _ptr(self.preempting)
+        self._c = s
+        return s
+
+    def lists(self):
+        """[(is_pending, index), ...] per pending job."""
+        out = []
+        for j in range(self.num_jobs):
+            refs = self.preempted[int(self.offsets[j]):int(self.offsets[j + 1])]
+            out.append([(bool(r & PREEMPT_REF_PENDING), int(r & 0x7FFFFFFF)) for r in refs])
+        return out
+
+    def cancelled_ids(self):
+        return [int(x) for x in self.cancelled[:self._c.num_cancelled]]
+
+    def preempting_ids(self):
+        return [int(x) for x in self.preempting[:self._c.num_preempting]]

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../include/crane_gpu/node_select.h"
+#include "../../include/crane_gpu/preempt.h"
 #include "../../include/crane_gpu/priority.h"
 #include "../../include/crane_gpu/run_limits.h"
 #include "../../include/crane_gpu/steps.h"
@@ -891,6 +892,25 @@ int cns_select(cns_handle* h, int64_t now, const cns_job_soa* jobs, cns_placemen
   if (int rc = cns_upload_jobs(h, jobs)) return rc;
   if (int rc = cns_run_resident(h, now)) return rc;
   return cns_download(h, out);
+}
+
+// include/crane_gpu/preempt.h.  TryPreempt_ (JobScheduler.cpp:6378-6505) releases resources inside a cycle, which every
+// selection kernel here excludes by construction (node state is monotone within a cycle: caches, predicted tiles, the
+// decoupled commit); the CPU checker restates it (tests/test_preempt.py), the device form is the next step.  Until then a
+// cycle with preemption enabled is REFUSED — never served by a fallback.
+int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* preempt,
+                       cns_placement_soa* out, cns_preempt_out* pout) {
+  if (preempt && preempt->enabled)
+    return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: preemption (PreemptType != NONE) is not implemented on the device; keep the CPU SchedulerAlgo for this configuration");
+  if (int rc = cns_select(h, now, jobs, out)) return rc;
+  if (pout) {
+    if (pout->offsets && jobs) for (uint64_t j = 0; j <= jobs->num_jobs; ++j) pout->offsets[j] = 0;
+    pout->num_cancelled = 0;
+    const uint32_t n = preempt ? std::min(preempt->num_preempting, pout->preempting_capacity) : 0u;   // the set passes through
+    for (uint32_t i = 0; i < n; ++i) pout->preempting_job_ids[i] = preempt->preempting_job_ids[i];
+    pout->num_preempting = n;
+  }
+  return CNS_OK;
 }
 
 int cns_device_results(cns_handle* h, void** dptr, uint64_t* bytes) {

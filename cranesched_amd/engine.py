@@ -33,6 +33,8 @@ PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
 # ... and include/crane_gpu/run_limits.h
 # ... and include/crane_gpu/steps.h
 STEPS_ABI_SYMBOLS = ("cns_schedule_steps",)
+# ... and include/crane_gpu/preempt.h
+PREEMPT_ABI_SYMBOLS = ("cns_select_preempt",)
 LIMITS_ABI_SYMBOLS = ("cns_set_run_limits", "cns_apply_run_limits", "cns_upload_limit_jobs", "cns_run_limits_resident",
                       "cns_download_limits", "cns_get_limit_timing", "cns_get_usage")
 

@@ -11,6 +11,7 @@
 #include "limits_oracle.hpp"
 #include "steps_oracle.hpp"
 #include "../include/crane_gpu/steps.h"
+#include "../include/crane_gpu/preempt.h"
 
 using namespace ora;
 
@@ -121,7 +122,13 @@ int ora_binop(const cns_gres_layout* gl, int algebra, int op, const ora_res* a, 
 // Returns an opaque run handle through *run_out (free with ora_free) for the debug getters.
 static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
                            const cns_resv_soa* resv, int64_t now, const cns_job_soa* jobs, cns_placement_soa* out,
-                           int algebra, void** run_out);
+                           int algebra, void** run_out, const cns_preempt_soa* pre = nullptr, cns_preempt_out* pout = nullptr);
+// ... with preemption (include/crane_gpu/preempt.h)
+int ora_select_preempt(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
+                       const cns_resv_soa* resv, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* pre,
+                       cns_placement_soa* out, cns_preempt_out* pout, int algebra, void** run_out) {
+  return ora_select_impl(cfg, nodes, running, resv, now, jobs, out, algebra, run_out, pre, pout);
+}
 int ora_select(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
                int64_t now, const cns_job_soa* jobs, cns_placement_soa* out, int algebra,
                void** run_out) {
@@ -135,7 +142,7 @@ int ora_select_resv(const cns_config* cfg, const cns_node_soa* nodes, const cns_
 }
 static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, const cns_running_soa* running,
                            const cns_resv_soa* resv, int64_t now, const cns_job_soa* jobs, cns_placement_soa* out,
-                           int algebra, void** run_out) {
+                           int algebra, void** run_out, const cns_preempt_soa* pre, cns_preempt_out* pout) {
   auto run = std::make_unique<OracleRun>();
   run->layout = layout_from(nodes->gres);
   u32 maxjobs = cfg && cfg->max_job_num_per_node ? cfg->max_job_num_per_node : 1000;
@@ -215,15 +222,37 @@ static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
     q.skip = jobs->skip ? jobs->skip[j] != 0 : false;
     if (jobs->reservation) q.reservation = jobs->reservation[j];
   }
+  PreemptCfg pcfg;
+  PreemptCfg* pc = nullptr;
+  if (pre) {  // include/crane_gpu/preempt.h
+    pc = &pcfg;
+    pcfg.enabled = pre->enabled != 0;
+    pcfg.qos_preempt.resize(pre->num_qos);
+    for (u32 q = 0; q < pre->num_qos; ++q)
+      for (u32 i = pre->qos_preempt_offsets[q]; i < pre->qos_preempt_offsets[q + 1]; ++i) pcfg.qos_preempt[q].push_back(pre->qos_preempt[i]);
+    for (u64 j = 0; j < jobs->num_jobs; ++j) {
+      pd[j].job_id = pre->pd_job_id ? pre->pd_job_id[j] : (u32)j;
+      pd[j].qos = pre->pd_qos ? pre->pd_qos[j] : 0;
+      pd[j].qos_priority = pre->pd_qos_priority ? pre->pd_qos_priority[j] : 0;
+      pd[j].priority = pre->pd_priority ? pre->pd_priority[j] : 0.0;
+    }
+    for (size_t r = 0; r < rn.size(); ++r) {
+      rn[r].job_id = pre->rn_job_id ? pre->rn_job_id[r] : (u32)r;
+      rn[r].qos = pre->rn_qos ? pre->rn_qos[r] : 0;
+      rn[r].qos_priority = pre->rn_qos_priority ? pre->rn_qos_priority[r] : 0;
+      rn[r].start_time = pre->rn_start_sec ? pre->rn_start_sec[r] : 0;
+    }
+    for (u32 i = 0; i < pre->num_preempting; ++i) pcfg.preempting_set.insert(pre->preempting_job_ids[i]);
+  }
 
   auto t0 = std::chrono::steady_clock::now();  // the reference's own bracket, JobScheduler.cpp:1439-1447
   if (algebra == 0) {
     run->mask = std::make_unique<SchedOracle<MaskAlgebra>>(MaskAlgebra(&run->layout), maxjobs, window);
-    run->mask->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch, rv);
+    run->mask->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch, rv, pc);
     run->jobs_ordered = run->mask->jobs_ordered();
   } else {
     run->lit = std::make_unique<SchedOracle<LitAlgebra>>(LitAlgebra(&run->layout), maxjobs, window);
-    run->lit->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch, rv);
+    run->lit->NodeSelect(now, total, sched, run->part_nodes, rn, pd, batch, rv, pc);
     run->jobs_ordered = run->lit->jobs_ordered();
   }
   run->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -231,6 +260,21 @@ static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
   if (out) {
     if (run->mask) emit(*run->mask, pd, out);
     else emit(*run->lit, pd, out);
+  }
+  if (pre && pout) {
+    u64 off = 0;
+    for (size_t j = 0; j < pd.size(); ++j) {
+      pout->offsets[j] = off;
+      for (const auto& [is_pd, idx] : pd[j].preempted_jobs) {
+        if (off >= pout->capacity) return -7;
+        pout->preempted[off++] = is_pd ? (idx | CNS_PREEMPT_REF_PENDING) : idx;
+      }
+    }
+    pout->offsets[pd.size()] = off;
+    pout->num_cancelled = 0;
+    for (u32 id : pcfg.cancelled) { if (pout->num_cancelled >= pout->cancel_capacity) return -7; pout->cancelled_job_ids[pout->num_cancelled++] = id; }
+    pout->num_preempting = 0;
+    for (u32 id : pcfg.preempting_set) { if (pout->num_preempting >= pout->preempting_capacity) return -7; pout->preempting_job_ids[pout->num_preempting++] = id; }
   }
   if (run_out) *run_out = run.release();
   return 0;

@@ -39,6 +39,7 @@ def build(force: bool = False) -> str:
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "node_select.h"))
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "run_limits.h"))
     srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "steps.h"))
+    srcs.append(os.path.join(_HERE, "..", "include", "crane_gpu", "preempt.h"))
     stale = force or not os.path.exists(path) or any(
         os.path.exists(s) and os.path.getmtime(s) > os.path.getmtime(path) for s in srcs)
     if stale:
@@ -129,7 +130,8 @@ class OracleRun:
 
 def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running | None = None,
            algebra: int = MASK, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0,
-           max_time_window_sec: int = 0, reservations: abi.Reservations | None = None) -> OracleRun:
+           max_time_window_sec: int = 0, reservations: abi.Reservations | None = None,
+           preempt: "abi.Preempt | None" = None) -> OracleRun:
     cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, 0, scheduled_batch_size, max_job_num_per_node, 0,
                         max_time_window_sec)
     out = abi.Placements(jobs.num_jobs, jobs.total_places())
@@ -137,6 +139,17 @@ def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running 
     cr = running.to_c() if running is not None else None
     cv = reservations.to_c() if reservations is not None else None
     h = C.c_void_p()
+    if preempt is not None:   # include/crane_gpu/preempt.h
+        pout = abi.PreemptOut(jobs.num_jobs, len(running.end_sec) if running is not None else 0)
+        cp, cpo = preempt.to_c(), pout.to_c()
+        rc = lib().ora_select_preempt(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
+                                      C.byref(cv) if cv is not None else None, C.c_int64(now), C.byref(cj), C.byref(cp),
+                                      C.byref(co), C.byref(cpo), algebra, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"ora_select_preempt failed: {rc}")
+        run = OracleRun(h, out, cluster)
+        run.preempt_out = pout
+        return run
     rc = lib().ora_select_resv(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
                                C.byref(cv) if cv is not None else None,
                                C.c_int64(now), C.byref(cj), C.byref(co), algebra, C.byref(h))

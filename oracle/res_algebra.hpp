@@ -109,6 +109,8 @@ struct MaskAlgebra {
   Res from_mask(const MaskRes& m) const { return m; }
   MaskRes to_mask(const Res& r) const { return r; }
   void set_zero(Res& r) const { r = Res{}; }
+  // ResourceInNodeV3::IsZero, PublicHeader.cpp:798-801 (memory_sw is not modelled on this path)
+  bool is_zero(const Res& r) const { return r.cpu == 0 && (r.clo | r.chi) == 0 && r.mem == 0 && r.gres == 0; }
 
   // ResourceView::GetFeasibleResourceInNode, PublicHeader.cpp:519-599
   bool feasible(const ReqView& q, const Res& a, Res* out) const {
@@ -254,6 +256,7 @@ struct LitAlgebra {
     r.mem = 0;
     r.gres.clear();
   }
+  bool is_zero(const Res& r) const { return r.cpu == 0 && r.cores.empty() && r.mem == 0 && r.gres.empty(); }
 
   // ResourceView::GetFeasibleResourceInNode, PublicHeader.cpp:519-599
   bool feasible(const ReqView& q, const Res& avail, Res* out) const {

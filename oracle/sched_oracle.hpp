@@ -15,10 +15,15 @@
 // inherited, with two canonicalisations: nodes are dense ints (cost ties
 // break on the node index instead of a NodeState* address) and per-job node lists are
 // reported sorted by node index (the reference's order comes from unordered_map iteration).
-// Out of this slice, as in SURVEY.md §8: reservations, preemption, licenses.
+//   LocalScheduler::TryPreempt_               src/CraneCtld/JobScheduler.cpp:6378-6505
+//   PreemptSegTree                            src/CraneCtld/JobScheduler.h:867-980
+//   UpdateNodeSelectorWith{Scheduled,Preempted}Job   src/CraneCtld/JobScheduler.h:630-670
+// Out of this slice, as in SURVEY.md §8: licenses.
 // Compile with -ffp-contract=off: the fp64 cost must not be FMA-contracted.
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <functional>
 #include <list>
 #include <map>
@@ -30,6 +35,7 @@
 #include <vector>
 
 #include "res_algebra.hpp"
+#include "../include/crane_gpu/preempt.h"
 
 namespace ora {
 
@@ -45,16 +51,31 @@ struct PdJob {  // PdJobInScheduler, JobScheduler.h:92-170 (fields used on this 
   std::set<u32> included_nodes, excluded_nodes;
   bool skip = false;
   u32 reservation = CNS_RESV_NONE;  // job->reservation (empty = CNS_RESV_NONE)
+  // preemption (JobScheduler.h:113-134): job id, qos (dense id), qos_priority, priority
+  u32 job_id = 0, qos = 0, qos_priority = 0;
+  double priority = 0.0;
   // results
   i64 start_time = 0, end_time = 0;
   int reason = CNS_REASON_NONE;
   std::map<u32, MaskRes> allocated_res;          // ResourceV3 (node -> ResourceInNodeV3)
   std::map<u32, u32> craned_id_to_task_num;
   std::vector<u32> craned_ids;
+  std::vector<std::pair<bool, u32>> preempted_jobs;  // (is_pending, index): std::variant<PdJobInScheduler*, RnJobInScheduler*>
 };
 
 struct RnAlloc { u32 node; MaskRes res; };
-struct RnJob { i64 end_time; std::vector<RnAlloc> allocs; u32 reservation = CNS_RESV_NONE; };
+struct RnJob {
+  i64 end_time; std::vector<RnAlloc> allocs; u32 reservation = CNS_RESV_NONE;
+  u32 job_id = 0, qos = 0, qos_priority = 0;   // JobScheduler.h:56-70
+  i64 start_time = 0;
+};
+// g_config.Preempt + what NodeSelect reads of the QoS table and keeps across cycles (JobScheduler.cpp:6522-6559, h:984)
+struct PreemptCfg {
+  bool enabled = false;                          // PreemptType != PREEMPT_NONE (PREEMPT_QOS is the only other mode)
+  std::vector<std::vector<u32>> qos_preempt;     // qos id -> the qos ids it may preempt (Qos::preempt)
+  std::set<u32> preempting_set;                  // m_preempting_set_: running job ids being preempted (in / out)
+  std::vector<u32> cancelled;                    // out: EnqueuePreemptCancel, in call order
+};
 // ResvMeta (start_time, end_time, res_total per node) as read at JobScheduler.cpp:6627-6679
 struct Resv { i64 start_time, end_time; std::vector<RnAlloc> allocs; };
 
@@ -73,6 +94,9 @@ class SchedOracle {
     std::vector<AllocatedRes> allocated_res;
     std::vector<ReservedRes> reserved_res;  // future reservations, JobScheduler.h:288
     TimeAvailResMap time_avail_res_map;
+    // JobScheduler.h:293-296: qos -> jobs holding resources on the node.  (is_pending, index) stands for the variant of
+    // pointers; the reference's flat_hash_set order is unspecified, here it is (pending first, ascending index).
+    std::map<u32, std::set<std::pair<bool, u32>>> qos_job_map;
   };
 
   SchedOracle(const A& alg, u32 max_job_num_per_node, i64 max_time_window)
@@ -104,10 +128,14 @@ class SchedOracle {
     A_.set_zero(ns.time_avail_res_map[end]);
   }
 
-  // -- NodeState::UpdateResourceInNode, JobScheduler.h:340-459 (allocate only) ---------
-  void UpdateResourceInNode(NodeState& ns, i64 start_time, i64 end_time, const Res& res) {
+  // -- NodeState::UpdateResourceInNode, JobScheduler.h:340-459 ----------------------------
+  void UpdateResourceInNode(NodeState& ns, i64 start_time, i64 end_time, const Res& res, bool is_release = false) {
     auto& m = ns.time_avail_res_map;
     bool ok;
+    auto apply = [&](Res& slot) {
+      if (is_release) A_.add(slot, res);
+      else { assert(A_.le(res, slot)); A_.sub(slot, res); }
+    };
     auto job_duration_begin_it = m.upper_bound(start_time);
     if (job_duration_begin_it == m.end()) {
       --job_duration_begin_it;
@@ -115,13 +143,11 @@ class SchedOracle {
       std::tie(inserted_it, ok) = m.emplace(end_time, job_duration_begin_it->second);
       assert(ok);
       if (job_duration_begin_it->first == start_time) {  // Case #1
-        assert(A_.le(res, job_duration_begin_it->second));
-        A_.sub(job_duration_begin_it->second, res);
+        apply(job_duration_begin_it->second);
       } else {  // Case #2
         std::tie(inserted_it, ok) = m.emplace(start_time, job_duration_begin_it->second);
         assert(ok);
-        assert(A_.le(res, inserted_it->second));
-        A_.sub(inserted_it->second, res);
+        apply(inserted_it->second);
       }
     } else {
       --job_duration_begin_it;
@@ -132,29 +158,26 @@ class SchedOracle {
         job_duration_begin_it = inserted_it;
       }
       auto job_duration_end_it = std::prev(m.upper_bound(end_time));
-      for (auto it = job_duration_begin_it; it != job_duration_end_it; it++) {
-        assert(A_.le(res, it->second));
-        A_.sub(it->second, res);
-      }
+      for (auto it = job_duration_begin_it; it != job_duration_end_it; it++) apply(it->second);
       if (job_duration_end_it->first != end_time) {
         typename TimeAvailResMap::iterator inserted_it;
         std::tie(inserted_it, ok) = m.emplace(end_time, job_duration_end_it->second);
         assert(ok);
-        assert(A_.le(res, job_duration_end_it->second));
-        A_.sub(job_duration_end_it->second, res);
+        apply(job_duration_end_it->second);
       }
     }
   }
 
   // -- MinCpuTimeRatioFirst::UpdateCost, JobScheduler.h:43-54 --------------------------
   static void UpdateCost(double& cost, i64 start_time, i64 end_time, i64 res_cpu_raw,
-                         i64 total_cpu_raw) {
+                         i64 total_cpu_raw, bool is_release = false) {
     // static_cast<double>(cpu_t) == double(raw) / 256.0 (fpm)
     double a = static_cast<double>(res_cpu_raw) / 256.0;
     double t = static_cast<double>(total_cpu_raw) / 256.0;
     double ratio = a / t;
     double delta = static_cast<double>(end_time - start_time) * ratio;
-    cost += delta;
+    if (is_release) cost -= delta;
+    else cost += delta;
   }
 
   // -- NodeSelector, JobScheduler.h:492-595 --------------------------------------------
@@ -185,6 +208,245 @@ class SchedOracle {
       ls.sel.m_cost_node_info_set_.erase({info.cost, node});
       UpdateCost(info.cost, start_time, end_time, mres.cpu, cpu_of(info.node_state->res_total));
       ls.sel.m_cost_node_info_set_.emplace(info.cost, node);
+    }
+  }
+
+  void ReleaseResourceIfPresent(LocalScheduler& ls, i64 start_time, i64 end_time,
+                                const std::map<u32, MaskRes>& res) {  // :577-587
+    for (const auto& [node, mres] : res) {
+      auto it = ls.sel.m_node_info_map_.find(node);
+      if (it == ls.sel.m_node_info_map_.end()) continue;
+      auto& info = it->second;
+      Res r = A_.from_mask(mres);
+      UpdateResourceInNode(*info.node_state, start_time, end_time, r, /*is_release=*/true);
+      ls.sel.m_cost_node_info_set_.erase({info.cost, node});
+      UpdateCost(info.cost, start_time, end_time, mres.cpu, cpu_of(info.node_state->res_total), /*is_release=*/true);
+      ls.sel.m_cost_node_info_set_.emplace(info.cost, node);
+    }
+  }
+
+  // -- PreemptSegTree, JobScheduler.h:867-980 --------------------------------------------------
+  // Times are absl::Time there; `mid = st + (ed - st) / 2` halves an absl::Duration, whose resolution is a quarter of a
+  // nanosecond, truncating.  Here: ticks of 1/4 ns RELATIVE to `now` (the arithmetic is translation-invariant and
+  // absolute ticks would overflow int64 in 2042).
+  static constexpr i64 kTicksPerSecond = 4000000000ll;
+  class PreemptSegTree {
+    struct Node {
+      i64 st, ed;
+      Node* ls;
+      Node* rs;
+      bool satisfied;
+      Res res;
+      Res add_tag;
+      Res sub_tag;
+    };
+    void add_res_(Node* node, const Res& res) {
+      A_->add(node->res, res);
+      node->satisfied = A_->le(m_target_res_, node->res);
+      if (node->ls) A_->add(node->add_tag, res);
+    }
+    void sub_res_(Node* node, const Res& res) {
+      A_->sub(node->res, res);
+      node->satisfied = A_->le(m_target_res_, node->res);
+      if (node->ls) A_->add(node->sub_tag, res);
+    }
+    Node* make(i64 st, i64 ed, bool satisfied, const Res* res) {
+      Node* n = new Node{st, ed, nullptr, nullptr, satisfied, Res{}, Res{}, Res{}};
+      A_->set_zero(n->res); A_->set_zero(n->add_tag); A_->set_zero(n->sub_tag);
+      if (res) n->res = *res;
+      return n;
+    }
+    void push_down_(Node* node) {
+      if (node->ls == nullptr) {
+        i64 mid = node->st + (node->ed - node->st) / 2;
+        node->ls = make(node->st, mid, node->satisfied, &node->res);
+        node->rs = make(mid, node->ed, node->satisfied, &node->res);
+        return;
+      }
+      if (!A_->is_zero(node->add_tag)) {
+        add_res_(node->ls, node->add_tag);
+        add_res_(node->rs, node->add_tag);
+        A_->set_zero(node->add_tag);
+      }
+      if (!A_->is_zero(node->sub_tag)) {
+        sub_res_(node->ls, node->sub_tag);
+        sub_res_(node->rs, node->sub_tag);
+        A_->set_zero(node->sub_tag);
+      }
+    }
+    void push_up_(Node* node) { node->satisfied = node->ls->satisfied && node->rs->satisfied; }
+    void add_(Node* node, i64 st, i64 ed, const Res& res) {
+      if (node->ed <= st || ed <= node->st) return;
+      if (st <= node->st && node->ed <= ed) { add_res_(node, res); return; }
+      push_down_(node);
+      add_(node->ls, st, ed, res);
+      add_(node->rs, st, ed, res);
+      push_up_(node);
+    }
+    void sub_(Node* node, i64 st, i64 ed, const Res& res) {
+      if (node->ed <= st || ed <= node->st) return;
+      if (st <= node->st && node->ed <= ed) { sub_res_(node, res); return; }
+      push_down_(node);
+      sub_(node->ls, st, ed, res);
+      sub_(node->rs, st, ed, res);
+      push_up_(node);
+    }
+    void destroy_(Node* node) {
+      if (node == nullptr) return;
+      destroy_(node->ls);
+      destroy_(node->rs);
+      delete node;
+    }
+    const A* A_;
+    Res m_target_res_;
+    Node* m_root_;
+
+   public:
+    PreemptSegTree(const A* alg, i64 st, i64 ed, const Res& target_res) : A_(alg), m_target_res_(target_res) {
+      m_root_ = make(st, ed, false, nullptr);
+    }
+    ~PreemptSegTree() { destroy_(m_root_); }
+    PreemptSegTree(const PreemptSegTree&) = delete;
+    PreemptSegTree& operator=(const PreemptSegTree&) = delete;
+    PreemptSegTree(PreemptSegTree&& o) noexcept : A_(o.A_), m_target_res_(o.m_target_res_), m_root_(o.m_root_) { o.m_root_ = nullptr; }
+    void Add(i64 st, i64 ed, const Res& res) { add_(m_root_, st, ed, res); }
+    void Sub(i64 st, i64 ed, const Res& res) { sub_(m_root_, st, ed, res); }
+    bool IsSatisfied() const { return m_root_->satisfied; }
+    u64 NodeCount() const { return count_(m_root_); }
+   private:
+    static u64 count_(const Node* n) { return n ? 1 + count_(n->ls) + count_(n->rs) : 0; }
+  };
+
+  // -- LocalScheduler::TryPreempt_, JobScheduler.cpp:6378-6505 ----------------------------------
+  using JobRef = std::pair<bool, u32>;   // (is_pending, index)
+  bool TryPreempt_(i64 now, PdJob* job, const std::vector<NodeState*>& nodes_to_sched) {
+    if (job->qos >= pc_->qos_preempt.size() || pc_->qos_preempt[job->qos].empty()) return false;  // :6384-6385
+    const auto& plist = pc_->qos_preempt[job->qos];
+    std::set<JobRef> preemptable_set;  // :6387-6396
+    for (const auto* node : nodes_to_sched)
+      for (u32 qos : plist) {
+        auto it = node->qos_job_map.find(qos);
+        if (it != node->qos_job_map.end()) preemptable_set.insert(it->second.begin(), it->second.end());
+      }
+    if (preemptable_set.empty()) return false;
+    std::vector<JobRef> ordered(preemptable_set.begin(), preemptable_set.end());  // :6399-6432
+    auto is_preempting = [&](const JobRef& v) { return !v.first && pc_->preempting_set.count((*rn_)[v.second].job_id) != 0; };
+    // The reference sorts a hash set's iteration order with an unstable sort: the order of candidates that compare
+    // equal is unspecified there.  Canonical here: stable, on top of (pending first, ascending index).
+    std::stable_sort(ordered.begin(), ordered.end(), [&](const JobRef& a, const JobRef& b) {
+      bool ca = is_preempting(a), cb = is_preempting(b);
+      if (ca != cb) return ca;
+      bool pa = a.first, pb = b.first;
+      if (pa != pb) return pa;
+      if (pa) {
+        const PdJob& x = (*pd_)[a.second]; const PdJob& y = (*pd_)[b.second];
+        if (x.qos_priority != y.qos_priority) return x.qos_priority < y.qos_priority;
+        return x.priority < y.priority;
+      } else {
+        const RnJob& x = (*rn_)[a.second]; const RnJob& y = (*rn_)[b.second];
+        if (x.qos_priority != y.qos_priority) return x.qos_priority < y.qos_priority;
+        return x.start_time > y.start_time;
+      }
+    });
+    // absl::InfiniteFuture() (the last key of every time map) and anything beyond ~36 years stay "after everything"
+    auto ticks = [&](i64 t) -> i64 {
+      const i64 d = t - now;
+      if (t == kInfiniteFuture || d > (INT64_MAX / 8) / kTicksPerSecond) return INT64_MAX / 4;
+      if (d < -((INT64_MAX / 8) / kTicksPerSecond)) return -(INT64_MAX / 4);
+      return d * kTicksPerSecond;
+    };
+    const i64 seg_start = 0, seg_end = ticks(now + job->time_limit);  // :6434-6435
+    std::vector<PreemptSegTree> seg_trees;
+    seg_trees.reserve(nodes_to_sched.size());
+    std::map<u32, size_t> node_index;
+    for (size_t i = 0; i < nodes_to_sched.size(); ++i) {  // :6441-6461
+      auto* node = nodes_to_sched[i];
+      node_index[node->idx] = i;
+      auto alloc_it = job->allocated_res.find(node->idx);
+      assert(alloc_it != job->allocated_res.end());
+      seg_trees.emplace_back(&A_, seg_start, seg_end, A_.from_mask(alloc_it->second));
+      auto& tree = seg_trees.back();
+      const auto& tmap = node->time_avail_res_map;
+      for (auto it = tmap.begin(); it != tmap.end();) {
+        i64 st = ticks(it->first);
+        auto nxt = std::next(it);
+        i64 ed = (nxt == tmap.end() ? seg_end : ticks(nxt->first));
+        tree.Add(st, ed, it->second);
+        if (ed >= seg_end) break;
+        it = nxt;
+      }
+    }
+    auto apply_to_trees = [&](const JobRef& pre, bool add) {  // :6463-6477
+      const i64 st = ticks(pre.first ? (*pd_)[pre.second].start_time : (*rn_)[pre.second].start_time);
+      const i64 ed = ticks(pre.first ? (*pd_)[pre.second].end_time : (*rn_)[pre.second].end_time);
+      auto one = [&](u32 cid, const MaskRes& res) {
+        auto ni = node_index.find(cid);
+        if (ni == node_index.end()) return;
+        if (add) seg_trees[ni->second].Add(st, ed, A_.from_mask(res));
+        else seg_trees[ni->second].Sub(st, ed, A_.from_mask(res));
+      };
+      if (pre.first) for (const auto& [cid, res] : (*pd_)[pre.second].allocated_res) one(cid, res);
+      else for (const auto& al : rn_alloc_map(pre.second)) one(al.first, al.second);
+    };
+    auto all_satisfied = [&]() {
+      for (const auto& t : seg_trees)
+        if (!t.IsSatisfied()) return false;
+      return true;
+    };
+    if (getenv("ORA_DEBUG_PREEMPT")) {
+      fprintf(stderr, "TryPreempt job %u qos %u: %zu candidates:", job->job_id, job->qos, ordered.size());
+      for (auto& o : ordered) fprintf(stderr, " (%s %u)", o.first ? "pd" : "rn", o.second);
+      fprintf(stderr, "  sat0:");
+      for (auto& t : seg_trees) fprintf(stderr, " %d", (int)t.IsSatisfied());
+      fprintf(stderr, "\n");
+    }
+    int preempt_idx = -1;
+    for (size_t i = 0; !all_satisfied() && i < ordered.size(); ++i) {  // :6484-6488
+      apply_to_trees(ordered[i], /*add=*/true);
+      preempt_idx = static_cast<int>(i);
+    }
+    if (!all_satisfied()) return false;
+    // (:6490: ordered[preempt_idx] with preempt_idx == -1 when the trees are satisfied before anything was added is
+    // undefined behaviour in the reference; it cannot happen: the job would have started now in GetNodesAndTrySchedule_
+    // ... unless the allocation against res_total fits the window minimum where get_max_tasks' greedy split did not.
+    // The oracle then preempts nobody.)
+    if (preempt_idx >= 0) job->preempted_jobs.push_back(ordered[preempt_idx]);
+    for (int i = preempt_idx - 1; i >= 0; --i) {  // :6491-6497
+      apply_to_trees(ordered[i], /*add=*/false);
+      if (!all_satisfied()) {
+        apply_to_trees(ordered[i], /*add=*/true);
+        job->preempted_jobs.push_back(ordered[i]);
+      }
+    }
+    seg_tree_nodes_ = 0;
+    for (const auto& t : seg_trees) seg_tree_nodes_ += t.NodeCount();
+    job->craned_ids.clear();  // :6499-6503
+    for (const auto* node : nodes_to_sched) job->craned_ids.emplace_back(node->idx);
+    job->start_time = now;
+    return true;
+  }
+
+  // -- LocalScheduler::UpdateNodeSelectorWithPreemptedJob, JobScheduler.h:645-670 -----------------
+  void UpdateNodeSelectorWithPreemptedJob(LocalScheduler& ls, i64 now, const JobRef& pre) {
+    if (!pre.first) {
+      RnJob& rn = (*rn_)[pre.second];
+      std::map<u32, MaskRes> res = rn_alloc_map(pre.second);
+      ReleaseResourceIfPresent(ls, now, rn.end_time, res);
+      for (const auto& [cid, _] : res) {
+        auto it = ls.sel.m_node_info_map_.find(cid);
+        if (it == ls.sel.m_node_info_map_.end()) continue;
+        it->second.node_state->qos_job_map[rn.qos].erase(pre);
+      }
+    } else {
+      PdJob& pd = (*pd_)[pre.second];
+      ReleaseResourceIfPresent(ls, pd.start_time, pd.end_time, pd.allocated_res);
+      if (pd.reason == CNS_REASON_NONE) {  // is_scheduled()
+        for (u32 cid : pd.craned_ids) {
+          auto it = ls.sel.m_node_info_map_.find(cid);
+          if (it == ls.sel.m_node_info_map_.end()) continue;
+          it->second.node_state->qos_job_map[pd.qos].erase(pre);
+        }
+      }
     }
   }
 
@@ -446,11 +708,12 @@ class SchedOracle {
     return false;
   }
 
-  // -- LocalScheduler::CalculateRunningNodesAndStartTime_, cpp:6127-6145 (no preemption) -
+  // -- LocalScheduler::CalculateRunningNodesAndStartTime_, cpp:6127-6145 ------------------------
   bool CalculateRunningNodesAndStartTime_(LocalScheduler& ls, i64 now, PdJob* job) {
     std::vector<NodeState*> nodes_to_sched;
     if (GetNodesAndTrySchedule_(ls, now, job, &nodes_to_sched)) return true;
     if (nodes_to_sched.size() < job->node_num) return false;
+    if (pc_ && pc_->enabled && TryPreempt_(now, job, nodes_to_sched)) return true;  // :6140-6143
     return Backfill_(now, job, nodes_to_sched);
   }
 
@@ -460,8 +723,19 @@ class SchedOracle {
                   const std::vector<uint8_t>& schedulable,
                   const std::vector<std::vector<u32>>& part_nodes, std::vector<RnJob>& running_jobs,
                   std::vector<PdJob>& pending_jobs, u64 scheduled_batch_size,
-                  const std::vector<Resv>& resvs = {}) {
+                  const std::vector<Resv>& resvs = {}, PreemptCfg* preempt = nullptr) {
     for (auto& rn : running_jobs) rn.end_time = std::max(rn.end_time, now + 1);  // :6513-6514
+    pc_ = preempt; pd_ = &pending_jobs; rn_ = &running_jobs;
+    if (pc_) {  // :6545-6559: running jobs that are being preempted end "now"; ids that left the running set are dropped
+      std::map<u32, RnJob*> rn_job_id_map;
+      for (auto& rn : running_jobs) rn_job_id_map.emplace(rn.job_id, &rn);
+      for (auto it = pc_->preempting_set.begin(); it != pc_->preempting_set.end();) {
+        auto rn_it = rn_job_id_map.find(*it);
+        if (rn_it == rn_job_id_map.end()) it = pc_->preempting_set.erase(it);
+        else { rn_it->second->end_time = now + 1; ++it; }
+      }
+      pc_->cancelled.clear();
+    }
     // :6524-6530 reservations that have pending jobs (before ordering / batch limit)
     std::vector<char> resv_has_pd(resvs.size(), 0);
     for (const auto& job : pending_jobs)
@@ -508,17 +782,23 @@ class SchedOracle {
             node_state_[al.node]->reserved_res.push_back({rv.start_time, rv.end_time, A_.from_mask(al.res)});
       }
     }
-    for (const auto& job : running_jobs) {  // :6681-6709
+    for (u32 ri = 0; ri < running_jobs.size(); ++ri) {  // :6681-6709
+      const auto& job = running_jobs[ri];
       if (job.reservation == CNS_RESV_NONE) {
         for (const auto& al : job.allocs)
-          if (al.node < node_state_.size() && node_state_[al.node])
+          if (al.node < node_state_.size() && node_state_[al.node]) {
             node_state_[al.node]->allocated_res.push_back({job.end_time, A_.from_mask(al.res)});
+            node_state_[al.node]->qos_job_map[job.qos].emplace(false, ri);  // :6688
+          }
       } else {
         if (job.reservation >= resvs.size() || !resv_live_[job.reservation]) continue;  // "not found" (:6693-6700)
         auto& m = resv_node_state_[job.reservation];
         for (const auto& al : job.allocs) {
           auto it = m.find(al.node);
-          if (it != m.end()) it->second->allocated_res.push_back({job.end_time, A_.from_mask(al.res)});
+          if (it != m.end()) {
+            it->second->allocated_res.push_back({job.end_time, A_.from_mask(al.res)});
+            it->second->qos_job_map[job.qos].emplace(false, ri);  // :6705
+          }
         }
       }
     }
@@ -571,7 +851,19 @@ class SchedOracle {
         job->craned_ids.clear();
       } else {
         job->end_time = job->start_time + job->time_limit;  // :6772
-        AllocateResource(scheduler, job->start_time, job->end_time, job->allocated_res);  // :6795
+        for (const auto& pre : job->preempted_jobs) {  // :6779-6792
+          UpdateNodeSelectorWithPreemptedJob(scheduler, now, pre);
+          if (pre.first) { pending_jobs[pre.second].reason = CNS_REASON_PREEMPTED; continue; }
+          const u32 rid = running_jobs[pre.second].job_id;
+          if (!pc_->preempting_set.insert(rid).second) continue;
+          pc_->cancelled.push_back(rid);   // EnqueuePreemptCancel (:6793)
+        }
+        AllocateResource(scheduler, job->start_time, job->end_time, job->allocated_res);  // :6795 (h:630-643)
+        if (job->reason == CNS_REASON_NONE)   // is_scheduled(): the reason of a later start is only set below
+          for (u32 nid : job->craned_ids) {
+            auto nit = scheduler.sel.m_node_info_map_.find(nid);
+            nit->second.node_state->qos_job_map[job->qos].emplace(true, (u32)i);
+          }
         if (job->start_time != now) {  // :6797-6833
           if (job->reservation == CNS_RESV_NONE) {
             for (u32 nid : job->craned_ids)
@@ -610,8 +902,21 @@ class SchedOracle {
   double ResvCostOf(u32 v, u32 node) const { return resv_scheduler_[v].sel.m_node_info_map_.at(node).cost; }
   const A& alg() const { return A_; }
   u64 jobs_ordered() const { return jobs_ordered_; }
+  u64 last_seg_tree_nodes() const { return seg_tree_nodes_; }
 
  private:
+  std::map<u32, MaskRes> rn_alloc_map(u32 ri) const {  // RnJobInScheduler::allocated_res.EachNodeResMap()
+    std::map<u32, MaskRes> m;
+    for (const auto& al : (*rn_)[ri].allocs) {
+      MaskRes& d = m[al.node];
+      d.cpu += al.res.cpu; d.mem += al.res.mem; d.clo |= al.res.clo; d.chi |= al.res.chi; d.gres |= al.res.gres;
+    }
+    return m;
+  }
+  PreemptCfg* pc_ = nullptr;
+  std::vector<PdJob>* pd_ = nullptr;
+  std::vector<RnJob>* rn_ = nullptr;
+  u64 seg_tree_nodes_ = 0;
   i64 cpu_of(const MaskRes& r) const { return r.cpu; }
   i64 cpu_of(const LitRes& r) const { return r.cpu; }
   static void add_alloc(PdJob* job, u32 nid, const MaskRes& r) {

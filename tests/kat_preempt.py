@@ -1,0 +1,108 @@
+"""Hand-derived known-answer scenarios for preemption inside the node-selection cycle
+(LocalScheduler::TryPreempt_, JobScheduler.cpp:6378-6505; PreemptSegTree, JobScheduler.h:867-980;
+UpdateNodeSelectorWithPreemptedJob / ...WithScheduledJob, JobScheduler.h:630-670; NodeSelect :6545-6559,6779-6795).
+
+The reference ships no test of this path, so every expectation was derived by hand from the cited lines (the
+derivations are in the comments) and frozen; tests/test_preempt.py checks the CPU oracle (both algebras) and the
+independent Python restatement (tests/select_pyref.py) against them.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from cranesched_amd import abi
+from tests import kat
+
+GIB, NOW = kat.GIB, kat.NOW
+INF = np.iinfo(np.int64).max
+
+
+def running(specs):
+    """specs: dicts with end, allocs = [(node, cores_mask, mem_gib)] (cpu = popcount of the mask)."""
+    off, node, cpu, mem, lo = [0], [], [], [], []
+    for s in specs:
+        for (n, mask, m) in s["allocs"]:
+            node.append(n); cpu.append(256 * bin(mask).count("1")); mem.append(m * GIB); lo.append(mask)
+        off.append(len(node))
+    z = np.zeros(len(node), np.uint64)
+    return abi.Running(np.array([s["end"] for s in specs], np.int64), np.array(off, np.uint32), np.array(node, np.uint32),
+                       np.array(cpu, np.int64), np.array(mem, np.uint64), np.array(lo, np.uint64), z, z.copy())
+
+
+def preempt(qos_preempt, pd, rn, preempting=()):
+    """pd: [(job_id, qos, qos_priority, priority)], rn: [(job_id, qos, qos_priority, start)]."""
+    return abi.Preempt(qos_preempt, [p[0] for p in pd], [p[1] for p in pd], [p[2] for p in pd], [p[3] for p in pd],
+                       [r[0] for r in rn], [r[1] for r in rn], [r[2] for r in rn], [r[3] for r in rn],
+                       preempting=list(preempting))
+
+
+# Each scenario: (name, cluster, jobs, running, preempt, expect); expect maps a job index to
+#   (reason, start, [(node, ntasks, cpu_raw, core_lo, gres)]) plus
+#   "preempted": {job: [(is_pending, index)]}, "cancelled": [job ids], "preempting": [job ids], "costs", "timeline".
+def scenarios():
+    out = []
+    Q = [[], [0]]   # qos 1 ("high") may preempt qos 0 ("low")
+
+    # P1. One node, 2 cores, 8 GiB.  R0 (id 50, qos 0) holds both cores until 1500: the map is {1000: (0 cpu, 6 GiB),
+    #     1500: total}, cost (1500-1000) * 2/2 = 500.  P0 (qos 1, 2 cpus, L 100) cannot start now (:6274); its allocation
+    #     against res_total is cores {0,1} (:6345-6367).  TryPreempt_: candidates = qos_job_map[0] = {R0}; the tree over
+    #     [now, now+100) holds (0 cpu, 6 GiB) -> not satisfied; + R0 (2 cpus, 2 GiB over [900, 1500)) -> (512, 8 GiB) ->
+    #     satisfied, preempt_idx 0.  Release over [now, 1500) (h:651): entry 1000 += R0, cost 500 - 500 = 0; R0 enters
+    #     m_preempting_set_ and is cancelled (:6787-6793); allocation over [1000, 1100): entry 1100 inserted as a copy,
+    #     entry 1000 -= (2 cpus, 1 GiB) (h:438-457, case #4 with an insertion at the end); cost 0 + 100 * 2/2.
+    c = kat.cluster([2], [8])
+    j = kat.jobs([dict(cpu=2, L=100)])
+    r = running([dict(end=1500, allocs=[(0, 0x3, 2)])])
+    out.append(("preempt_running_job", c, j, r, preempt(Q, [(1, 1, 10, 1.0)], [(50, 0, 1, 900)]), {
+        0: (0, NOW, [(0, 1, 512, 0x3, 0)]),
+        "preempted": {0: [(False, 0)]}, "cancelled": [50], "preempting": [50], "costs": [100.0],
+        "timeline": {0: [(NOW, 0, 0x0), (1100, 512, 0x3), (1500, 512, 0x3), (INF, 0, 0)]}}))
+
+    # P2. Minimal set and order.  4 cores; R0 (id 10, qos_priority 1, start 800, core 0), R1 (id 11, 1, start 900, core 1),
+    #     R2 (id 12, qos_priority 2, start 950, cores 2-3), all qos 0, all until 2000: cost 250 + 250 + 500 = 1000.
+    #     Order (:6401-6432): lower qos_priority first, then the LATER start first: [R1, R0, R2].  P0 wants 2 cpus.
+    #     Forward pass: + R1 -> 1 cpu, + R0 -> 2 cpus: satisfied, preempt_idx = 1 -> [R0]; backward: - R1 -> 1 cpu, not
+    #     satisfied -> + R1 again, pushed: preempted_jobs = [R0, R1]; R2 keeps running.  Releases in that order:
+    #     cost 1000 - 250 - 250 = 500, entry 1000 = (2 cpus, cores {0,1}, 15 GiB); allocation [1000, 1100):
+    #     cost + 100 * 2/4 = 550; cancel order = push order.
+    c = kat.cluster([4], [16])
+    j = kat.jobs([dict(cpu=2, L=100)])
+    r = running([dict(end=2000, allocs=[(0, 0x1, 1)]), dict(end=2000, allocs=[(0, 0x2, 1)]), dict(end=2000, allocs=[(0, 0xC, 1)])])
+    out.append(("minimal_set_and_order", c, j, r,
+                preempt(Q, [(1, 1, 10, 1.0)], [(10, 0, 1, 800), (11, 0, 1, 900), (12, 0, 2, 950)]), {
+        0: (0, NOW, [(0, 1, 512, 0x3, 0)]),
+        "preempted": {0: [(False, 0), (False, 1)]}, "cancelled": [10, 11], "preempting": [10, 11], "costs": [550.0],
+        "timeline": {0: [(NOW, 0, 0x0), (1100, 512, 0x3), (2000, 1024, 0xF), (INF, 0, 0)]}}))
+
+    # P3. A pending job placed earlier in the SAME cycle is preempted (:6781-6784).  2 cores, 16 GiB, nothing running.
+    #     P0 (qos 0, 2 cpus, L 100) starts now: map {1000: (0, 15 GiB), 1100: total}, cost 100, qos_job_map[0] = {P0}
+    #     (h:636-642, its reason is still empty).  P1 (qos 1, 2 cpus, L 50): tree over [now, now+50) = (0 cpu) ->
+    #     + P0 over [1000, 1100) -> satisfied.  Release over [P0.start, P0.end): entry 1000 back to total, cost 0;
+    #     P0.reason = "Preempted", its start and placement stay as they were; P1 over [1000, 1050): cost 50.
+    c = kat.cluster([2], [16])
+    j = kat.jobs([dict(cpu=2, L=100), dict(cpu=2, L=50)])
+    out.append(("pending_job_preempted_in_cycle", c, j, None,
+                preempt(Q, [(1, 0, 1, 5.0), (2, 1, 10, 1.0)], []), {
+        0: (abi.REASON_PREEMPTED, NOW, [(0, 1, 512, 0x3, 0)]), 1: (0, NOW, [(0, 1, 512, 0x3, 0)]),
+        "preempted": {0: [], 1: [(True, 0)]}, "cancelled": [], "preempting": [], "costs": [50.0],
+        "timeline": {0: [(NOW, 0, 0x0), (1050, 512, 0x3), (1100, 512, 0x3), (INF, 0, 0)]}}))
+
+    # P4. Nothing to preempt: the running job's qos (2) is not on P0's list -> TryPreempt_ returns false at :6397,
+    #     Backfill_ places P0 at 1500; its allocation (2 cpus) does not fit res_avail (0 cpus) -> "Resource" (:6809-6817).
+    c = kat.cluster([2], [8])
+    j = kat.jobs([dict(cpu=2, L=100)])
+    r = running([dict(end=1500, allocs=[(0, 0x3, 2)])])
+    out.append(("nothing_preemptable", c, j, r, preempt([[], [0], []], [(1, 1, 10, 1.0)], [(50, 2, 1, 900)]), {
+        0: (2, 1500, [(0, 1, 512, 0x3, 0)]),
+        "preempted": {0: []}, "cancelled": [], "preempting": [], "costs": [600.0]}))
+
+    # P5. m_preempting_set_ across cycles (:6545-6559): R0 (id 50) was preempted in an earlier cycle and still runs ->
+    #     its end_time becomes now + 1, cost (1001 - 1000) * 1 = 1; id 77 no longer runs -> dropped from the set.
+    #     P0 (qos 0: no preempt list) backfills at 1001; "Resource" as in P4; cost 1 + 100.
+    c = kat.cluster([2], [8])
+    j = kat.jobs([dict(cpu=2, L=100)])
+    r = running([dict(end=1500, allocs=[(0, 0x3, 2)])])
+    out.append(("preempting_set_carried_over", c, j, r, preempt(Q, [(1, 0, 1, 1.0)], [(50, 0, 1, 900)], preempting=[50, 77]), {
+        0: (2, 1001, [(0, 1, 512, 0x3, 0)]),
+        "preempted": {0: []}, "cancelled": [], "preempting": [50], "costs": [101.0]}))
+    return out

@@ -192,6 +192,20 @@ class Node:
         else:
             self.tmap.append([end, Res()])
 
+    def release(self, start, end, res: Res):   # UpdateResourceInNode(..., is_release = true), JobScheduler.h:340-459
+        ts = [e[0] for e in self.tmap]
+        ib = max(i for i, t in enumerate(ts) if t <= start)
+        if ts[ib] != start:
+            self.tmap.insert(ib + 1, [start, self.tmap[ib][1].copy()])
+            ib += 1
+        ts = [e[0] for e in self.tmap]
+        ie = max(i for i, t in enumerate(ts) if t <= end)
+        if ts[ie] != end:
+            self.tmap.insert(ie + 1, [end, self.tmap[ie][1].copy()])   # the copy is taken BEFORE the addition below
+            ie += 1
+        for i in range(ib, ie):
+            res_add(self.tmap[i][1], res)
+
     def commit(self, start, end, res: Res):   # UpdateResourceInNode (allocate), JobScheduler.h:340-459
         ts = [e[0] for e in self.tmap]
         ib = max(i for i, t in enumerate(ts) if t <= start)
@@ -377,3 +391,227 @@ class Cycle:
             if any(not res_le(alloc, self.nodes[i].avail0) for i, _, alloc in picks):
                 reason = 2
         return reason, start, sorted(picks, key=lambda x: x[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Preemption: TryPreempt_ (JobScheduler.cpp:6378-6505), PreemptSegTree (JobScheduler.h:867-980), the bookkeeping of
+# NodeSelect around it (:6545-6559, :6779-6795; JobScheduler.h:630-670).  Written from those lines; shares nothing with
+# oracle/sched_oracle.hpp.  Canonicalisation: candidates that the reference's comparator leaves unordered (it sorts the
+# iteration order of a hash set) are taken pending-first, then by ascending index.
+# ---------------------------------------------------------------------------------------------------------------------
+TICKS = 4_000_000_000   # absl::Duration resolves a quarter of a nanosecond; `(ed - st) / 2` truncates there
+
+
+def res_is_zero(r: Res) -> bool:   # ResourceInNodeV3::IsZero, PublicHeader.cpp:798-801
+    return r.cpu == 0 and r.mem == 0 and not r.cores and not any(r.gres.values())
+
+
+class SegTree:
+    """A lazily split segment tree over [st, ed): every node carries a resource, a `satisfied` flag and two pending tags."""
+
+    def __init__(self, st, ed, target: Res):
+        self.target = target
+        self.root = self._node(st, ed, False, Res())
+
+    @staticmethod
+    def _node(st, ed, sat, res):
+        return {"st": st, "ed": ed, "ls": None, "rs": None, "sat": sat, "res": res, "add": Res(), "sub": Res()}
+
+    def _plus(self, n, r):      # add_res_: the flag is recomputed from THIS node's resource, whatever its children hold
+        res_add(n["res"], r)
+        n["sat"] = res_le(self.target, n["res"])
+        if n["ls"] is not None:
+            res_add(n["add"], r)
+
+    def _minus(self, n, r):     # sub_res_
+        res_sub(n["res"], r)
+        n["sat"] = res_le(self.target, n["res"])
+        if n["ls"] is not None:
+            res_add(n["sub"], r)
+
+    def _down(self, n):         # push_down_: the first visit splits the node, later visits hand the tags on
+        if n["ls"] is None:
+            mid = n["st"] + (n["ed"] - n["st"]) // 2
+            n["ls"] = self._node(n["st"], mid, n["sat"], n["res"].copy())
+            n["rs"] = self._node(mid, n["ed"], n["sat"], n["res"].copy())
+            return
+        if not res_is_zero(n["add"]):
+            self._plus(n["ls"], n["add"]); self._plus(n["rs"], n["add"])
+            n["add"] = Res()
+        if not res_is_zero(n["sub"]):
+            self._minus(n["ls"], n["sub"]); self._minus(n["rs"], n["sub"])
+            n["sub"] = Res()
+
+    def _walk(self, n, st, ed, r, plus):
+        if n["ed"] <= st or ed <= n["st"]:
+            return
+        if st <= n["st"] and n["ed"] <= ed:
+            (self._plus if plus else self._minus)(n, r)
+            return
+        self._down(n)
+        self._walk(n["ls"], st, ed, r, plus)
+        self._walk(n["rs"], st, ed, r, plus)
+        n["sat"] = n["ls"]["sat"] and n["rs"]["sat"]      # push_up_
+
+    def add(self, st, ed, r):
+        self._walk(self.root, st, ed, r, True)
+
+    def sub(self, st, ed, r):
+        self._walk(self.root, st, ed, r, False)
+
+    @property
+    def satisfied(self):
+        return self.root["sat"]
+
+
+class PreemptCycle(Cycle):
+    """Cycle + preemption.  Jobs are referred to as ("pd", index) / ("rn", index)."""
+
+    def __init__(self, *a, qos_preempt=(), preempting=(), **kw):
+        super().__init__(*a, **kw)
+        self.qos_preempt = [list(x) for x in qos_preempt]
+        self.preempting = set(preempting)       # m_preempting_set_ (job ids)
+        self.cancelled = []
+        self.rn = []                            # dicts: id, qos, qprio, start, end, allocs {node: Res}
+        self.pd = {}                            # index -> dict: qos, qprio, prio, start, end, allocs, reason, nodes
+        self.node_jobs = {}                     # node -> {qos: set(ref)}     (NodeState::qos_job_map)
+
+    def add_running_job(self, job_id, qos, qprio, start, end, allocs):
+        end = max(end, self.now + 1)                                             # :6513-6514
+        self.rn.append(dict(id=job_id, qos=qos, qprio=qprio, start=start, end=end, allocs=allocs))
+
+    def start(self):
+        ids = {r["id"] for r in self.rn}
+        self.preempting &= ids                                                   # :6550-6558
+        for r in self.rn:
+            if r["id"] in self.preempting:
+                r["end"] = self.now + 1
+        for x, r in enumerate(self.rn):                                          # :6681-6690
+            merged = {}
+            for node, res in r["allocs"]:
+                if node in merged:
+                    res_add(merged[node], res)
+                else:
+                    merged[node] = res.copy()
+                if node in self.nodes:
+                    self.nodes[node].allocated.append((r["end"], res))
+                    self.node_jobs.setdefault(node, {}).setdefault(r["qos"], set()).add(("rn", x))
+            r["allocs"] = merged
+        super().start()
+
+    def try_preempt(self, job, jinfo, picks):
+        """picks: the (node, ntasks, alloc) list of the res_total branch, in nodes_to_sched order.  -> list of refs or None."""
+        plist = self.qos_preempt[jinfo["qos"]] if jinfo["qos"] < len(self.qos_preempt) else []
+        if not plist:
+            return None
+        cand = set()
+        for i, _, _ in picks:
+            for q in plist:
+                cand |= self.node_jobs.get(i, {}).get(q, set())
+        if not cand:
+            return None
+
+        def key(ref):
+            kind, x = ref
+            if kind == "rn":
+                r = self.rn[x]
+                return (0 if r["id"] in self.preempting else 1, 1, r["qprio"], -r["start"], x)
+            d = self.pd[x]
+            return (1, 0, d["qprio"], d["prio"], x)
+        order = sorted(cand, key=key)
+        tk = lambda t: (t - self.now) * TICKS
+        seg_end = tk(self.now + job["L"])
+        trees = {}
+        for i, _, alloc in picks:
+            tr = SegTree(0, seg_end, alloc)
+            tm = self.nodes[i].tmap
+            for x, (t, r) in enumerate(tm):
+                ed = tk(tm[x + 1][0]) if x + 1 < len(tm) else seg_end
+                tr.add(tk(t), ed, r)
+                if ed >= seg_end:
+                    break
+            trees[i] = tr
+
+        def span(ref):
+            d = self.rn[ref[1]] if ref[0] == "rn" else self.pd[ref[1]]
+            return tk(d["start"]), tk(d["end"]), d["allocs"]
+
+        def apply(ref, plus):
+            st, ed, allocs = span(ref)
+            for node, res in allocs.items():
+                if node in trees:
+                    (trees[node].add if plus else trees[node].sub)(st, ed, res)
+        ok = lambda: all(t.satisfied for t in trees.values())
+        last = -1
+        for x, ref in enumerate(order):
+            if ok():
+                break
+            apply(ref, True)
+            last = x
+        if not ok():
+            return None
+        chosen = [order[last]] if last >= 0 else []
+        for x in range(last - 1, -1, -1):
+            apply(order[x], False)
+            if not ok():
+                apply(order[x], True)
+                chosen.append(order[x])
+        return chosen
+
+    def run_job_p(self, idx, job, jinfo):
+        """-> (reason, start, picks ascending node, preempted refs)."""
+        self.pd[idx] = dict(qos=jinfo["qos"], qprio=jinfo["qprio"], prio=jinfo["prio"], start=0, end=0, allocs={}, reason=None, nodes=[])
+        r = self.try_schedule(job)
+        if r is None:
+            self.pd[idx]["reason"] = 2
+            return 2, 0, [], []
+        kind, picks = r
+        pre = []
+        if kind == "now":
+            start = self.now
+        else:
+            chosen = self.try_preempt(job, jinfo, picks)                          # :6140-6143
+            if chosen is not None:
+                start, pre = self.now, chosen
+            else:
+                start = self.earliest_start(job, picks)
+                if start is None:
+                    self.pd[idx]["reason"] = 2
+                    return 2, 0, [], []
+        end = start + job["L"]
+        p = job["part"]
+        me = self.pd[idx]
+        me.update(start=start, end=end, allocs={i: a for i, _, a in picks}, nodes=[i for i, _, _ in picks])
+        for ref in pre:                                                           # :6779-6792, JobScheduler.h:645-670
+            d = self.rn[ref[1]] if ref[0] == "rn" else self.pd[ref[1]]
+            st = self.now if ref[0] == "rn" else d["start"]
+            for node, res in d["allocs"].items():
+                if node in self.cost[p]:
+                    nd = self.nodes[node]
+                    nd.release(st, d["end"], res)
+                    self.cost[p][node] -= float(d["end"] - st) * ((float(res.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
+            if ref[0] == "rn":
+                for node in d["allocs"]:
+                    if node in self.cost[p]:
+                        self.node_jobs.get(node, {}).get(d["qos"], set()).discard(ref)
+                if d["id"] not in self.preempting:
+                    self.preempting.add(d["id"])
+                    self.cancelled.append(d["id"])
+            else:
+                if d["reason"] == 0:                                              # is_scheduled() at that moment
+                    for node in d["nodes"]:
+                        if node in self.cost[p]:
+                            self.node_jobs.get(node, {}).get(d["qos"], set()).discard(ref)
+                d["reason"] = 7                                                   # "Preempted"
+        for i, t, alloc in picks:                                                 # :6795
+            nd = self.nodes[i]
+            nd.commit(start, end, alloc)
+            self.cost[p][i] += float(end - start) * ((float(alloc.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
+            self.node_jobs.setdefault(i, {}).setdefault(jinfo["qos"], set()).add(("pd", idx))   # reason still empty (h:636-642)
+        reason = 0
+        if start != self.now:
+            reason = 1
+            if any(not res_le(alloc, self.nodes[i].avail0) for i, _, alloc in picks):
+                reason = 2
+        me["reason"] = reason
+        return reason, start, sorted(picks, key=lambda x: x[0]), pre

@@ -39,7 +39,12 @@ def test_header_symbols_exported(built):
     assert set(snames) == set(engine.STEPS_ABI_SYMBOLS)
     for n in snames:
         assert hasattr(lib, n), f"{n} declared in steps.h but not exported"
-    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "priority.h", "run_limits.h", "steps.h"]
+    # ... and preempt.h (preemption inside the cycle, SURVEY 8f-4: declared, refused on the device while enabled)
+    qnames = header_functions("preempt.h")
+    assert set(qnames) == set(engine.PREEMPT_ABI_SYMBOLS)
+    for n in qnames:
+        assert hasattr(lib, n), f"{n} declared in preempt.h but not exported"
+    assert sorted(os.listdir(os.path.join(ROOT, "include", "crane_gpu"))) == ["node_select.h", "preempt.h", "priority.h", "run_limits.h", "steps.h"]
 
 
 def test_no_gpu_means_loud_failure(built):

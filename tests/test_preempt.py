@@ -1,0 +1,161 @@
+"""Preemption inside the cycle: the CPU oracle's restatement of TryPreempt_ / PreemptSegTree against
+hand-derived scenarios (tests/kat_preempt.py), both resource algebras."""
+import numpy as np
+import pytest
+
+from cranesched_amd import abi
+from tests import kat_preempt
+
+
+def check(run, jobs, cluster, expect, name):
+    pl = run.placements
+    for j, e in expect.items():
+        if not isinstance(j, int):
+            continue
+        reason, start, recs = e
+        assert int(pl.reason[j]) == reason, (name, j, "reason", int(pl.reason[j]))
+        assert int(pl.start_sec[j]) == start, (name, j, "start", int(pl.start_sec[j]))
+        o = int(pl.place_offsets[j])
+        got = [(int(pl.node_idx[o + i]), int(pl.ntasks[o + i]), int(pl.cpu_raw[o + i]), int(pl.core_lo[o + i]), int(pl.gres[o + i]))
+               for i in range(int(pl.place_offsets[j + 1]) - o) if int(pl.node_idx[o + i]) != abi.NODE_NONE]
+        assert got == recs, (name, j, got)
+    po = run.preempt_out
+    lists = po.lists()
+    for j, want in expect["preempted"].items():
+        assert lists[j] == want, (name, j, lists[j])
+    assert po.cancelled_ids() == expect["cancelled"], (name, po.cancelled_ids())
+    assert po.preempting_ids() == expect["preempting"], (name, po.preempting_ids())
+    if "costs" in expect:
+        assert np.array_equal(run.costs(), np.asarray(expect["costs"], np.float64)), (name, run.costs())
+    for node, tl in expect.get("timeline", {}).items():
+        m = run.timeline(node)
+        got = [(int(t), int(c), int(lo)) for t, c, lo in zip(m["t"], m["cpu_raw"], m["core_lo"])]
+        assert got == tl, (name, node, got)
+
+
+@pytest.mark.parametrize("algebra", [0, 1])
+@pytest.mark.parametrize("scn", kat_preempt.scenarios(), ids=lambda s: s[0])
+def test_oracle_preempt_known_answers(built, scn, algebra):
+    from oracle import pyoracle
+    name, cluster, jobs, running, pre, expect = scn
+    run = pyoracle.select(cluster, jobs, kat_preempt.NOW, running=running, algebra=algebra, preempt=pre)
+    check(run, jobs, cluster, expect, name)
+
+
+def test_disabled_preemption_is_the_plain_cycle(built):
+    """PreemptType == NONE: the same inputs go through Backfill_ (JobScheduler.cpp:6140)."""
+    from oracle import pyoracle
+    name, cluster, jobs, running, pre, _ = kat_preempt.scenarios()[0]
+    pre.enabled = False
+    a = pyoracle.select(cluster, jobs, kat_preempt.NOW, running=running, preempt=pre)
+    b = pyoracle.select(cluster, jobs, kat_preempt.NOW, running=running)
+    assert a.placements.diff(b.placements) is None
+    assert int(a.placements.start_sec[0]) == 1500 and a.preempt_out.lists() == [[]]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The C++ oracle against the independent Python restatement (tests/select_pyref.py: PreemptCycle, SegTree)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_pyref_preempt(c, j, now, run, pre, max_job_num_per_node=0, max_time_window_sec=0):
+    from tests import select_pyref as pr
+    from tests.test_select_pyref import _res
+    lay = c.gres
+    N = c.num_nodes
+    chi = c.core_hi if c.core_hi is not None else np.zeros(N, np.uint64)
+    gs = c.gres_slots if c.gres_slots is not None else np.zeros(N, np.uint64)
+    totals = [_res(lay, c.cpu_total_raw[n], c.mem_total[n], c.core_lo[n], chi[n], gs[n]) for n in range(N)]
+    parts = [list(map(int, c.part_nodes[c.part_offsets[p]:c.part_offsets[p + 1]])) for p in range(c.num_partitions)]
+    types_of = lambda name: [g for g in range(len(lay.class_name)) if lay.class_name[g] == name]
+    cyc = pr.PreemptCycle(now, totals, parts, schedulable=None if c.schedulable is None else list(c.schedulable), types_of=types_of,
+                          max_jobs_per_node=max_job_num_per_node or pr.MAX_JOBS_PER_NODE, max_window=max_time_window_sec or pr.MAX_WINDOW,
+                          qos_preempt=pre.qos_preempt if pre.enabled else [], preempting=[int(x) for x in pre.preempting])
+    if run is not None:
+        ahi = run.alloc_core_hi if run.alloc_core_hi is not None else np.zeros(len(run.alloc_node), np.uint64)
+        ag = run.alloc_gres if run.alloc_gres is not None else np.zeros(len(run.alloc_node), np.uint64)
+        for r in range(len(run.end_sec)):
+            al = [(int(run.alloc_node[a]), _res(lay, run.alloc_cpu_raw[a], run.alloc_mem[a], run.alloc_core_lo[a], ahi[a], ag[a]))
+                  for a in range(int(run.alloc_offsets[r]), int(run.alloc_offsets[r + 1]))]
+            cyc.add_running_job(int(pre.rn_job_id[r]), int(pre.rn_qos[r]), int(pre.rn_qos_priority[r]), int(pre.rn_start_sec[r]),
+                                int(run.end_sec[r]), al)
+    cyc.start()
+    out, lists = [], []
+    for i in range(j.num_jobs):
+        if j.skip is not None and j.skip[i]:
+            out.append([abi.REASON_SKIPPED, 0, []]); lists.append([])
+            continue
+        if j.partition[i] >= c.num_partitions:
+            out.append([abi.REASON_PARTITION_NOT_FOUND, 0, []]); lists.append([])
+            continue
+        gtot = {a: int(v) for a, v in enumerate(j.gres_total[i]) if v} if j.gres_total is not None else {}
+        gspec = {(lay.class_name[g], g): int(v) for g, v in enumerate(j.gres_spec[i]) if v} if j.gres_spec is not None else {}
+        node_view = pr.Req(int(j.node_cpu_raw[i]) if j.node_cpu_raw is not None else 0, int(j.node_mem[i]), gtot, gspec)
+        job = dict(part=int(j.partition[i]), L=int(j.time_limit_sec[i]), k=int(j.node_num[i]), ntasks=int(j.ntasks[i]),
+                   tmin=int(j.ntasks_per_node_min[i]), tmax=int(j.ntasks_per_node_max[i]), tcpu=int(j.task_cpu_raw[i]),
+                   tmem=int(j.task_mem[i]), node_view=node_view, exclusive=bool(j.exclusive[i]) if j.exclusive is not None else False,
+                   incl=set(map(int, j.incl_nodes[int(j.incl_offsets[i]):int(j.incl_offsets[i + 1])])) if j.incl_offsets is not None else set(),
+                   excl=set(map(int, j.excl_nodes[int(j.excl_offsets[i]):int(j.excl_offsets[i + 1])])) if j.excl_offsets is not None else set())
+        job["min_view"] = pr.compose(node_view, job["tcpu"], job["tmem"], job["tmin"])
+        jinfo = dict(qos=int(pre.pd_qos[i]), qprio=int(pre.pd_qos_priority[i]), prio=float(pre.pd_priority[i]))
+        reason, start, picks, refs = cyc.run_job_p(i, job, jinfo)
+        out.append([reason, start, picks])
+        lists.append([(kind == "pd", x) for kind, x in refs])
+    for i in range(j.num_jobs):          # a job preempted later in the cycle carries "Preempted"
+        if i in cyc.pd and cyc.pd[i]["reason"] == 7:
+            out[i][0] = 7
+    return cyc, [tuple(o) for o in out], lists
+
+
+def compare_preempt(tag, c, j, ref, cyc, out, lists):
+    from tests.test_select_pyref import compare
+    compare(tag, c, j, ref, cyc, out)
+    po = ref.preempt_out
+    assert po.lists() == lists, f"{tag}: preempted lists {po.lists()} (oracle) vs {lists} (python)"
+    assert po.cancelled_ids() == cyc.cancelled, f"{tag}: cancelled {po.cancelled_ids()} vs {cyc.cancelled}"
+    assert po.preempting_ids() == sorted(cyc.preempting), f"{tag}: preempting set"
+    for n in range(c.num_nodes):         # final time maps, entry by entry
+        if n not in cyc.nodes:
+            continue
+        m = ref.timeline(n)
+        got = [(int(t), int(cpu), int(mem)) for t, cpu, mem in zip(m["t"], m["cpu_raw"], m["mem"])]
+        want = [(t, r.cpu, r.mem) for t, r in cyc.nodes[n].tmap]
+        assert got == want, f"{tag}: time map of node {n}: {got} (oracle) vs {want} (python)"
+
+
+@pytest.mark.parametrize("scn", kat_preempt.scenarios(), ids=lambda s: s[0])
+def test_python_restatement_on_hand_derived_preempt_scenarios(built, scn):
+    from oracle import pyoracle
+    name, c, j, r, pre, expect = scn
+    cyc, out, lists = run_pyref_preempt(c, j, kat_preempt.NOW, r, pre)
+    ref = pyoracle.select(c, j, kat_preempt.NOW, running=r, preempt=pre)
+    compare_preempt(name, c, j, ref, cyc, out, lists)
+
+
+def random_preempt_case(seed, N=10, J=60, P=1, running=14, nq=3):
+    """A loaded little cluster with three QoS levels (2 may preempt 1 and 0, 1 may preempt 0), distinct (qos_priority,
+    start) / (qos_priority, priority) keys so that the reference's comparator leaves nothing unordered."""
+    from tests import helpers
+    c, j, now, run = helpers.random_case(seed, N=N, J=J, P=P, running=running)
+    rng = np.random.default_rng(seed * 7919 + 13)
+    R = len(run.end_sec)
+    rn_qos = rng.integers(0, nq, R)
+    pd_qos = rng.integers(0, nq, j.num_jobs)
+    qprio = np.array([10, 20, 30])
+    rn_start = now - 1 - rng.permutation(R) * 7            # all different
+    pd_prio = rng.permutation(j.num_jobs).astype(np.float64) + 0.5
+    preempting = [int(1000 + r) for r in range(R) if rng.random() < 0.15] + [4242]
+    pre = abi.Preempt([[], [0], [1, 0]][:nq], np.arange(j.num_jobs) + 1, pd_qos, qprio[pd_qos], pd_prio,
+                      1000 + np.arange(R), rn_qos, qprio[rn_qos], rn_start, preempting=preempting)
+    return c, j, now, run, pre
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_python_restatement_on_random_preempt_cases(built, seed):
+    from oracle import pyoracle
+    c, j, now, run, pre = random_preempt_case(500 + seed, N=6 + seed % 7, J=50 + seed % 40, P=1 + seed % 2, running=10 + seed % 11)
+    cyc, out, lists = run_pyref_preempt(c, j, now, run, pre)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    compare_preempt(f"random preempt {seed}", c, j, ref, cyc, out, lists)
+    if seed == 0:
+        # the generator must actually exercise the path
+        tot = sum(len(x) for s in range(500, 520) for x in pyoracle.select(*random_preempt_case(s)[:3], running=random_preempt_case(s)[3], preempt=random_preempt_case(s)[4]).preempt_out.lists())
+        assert tot > 20, f"only {tot} preemptions in 20 random cases"
