@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <set>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -108,6 +109,13 @@ struct cns_engine {
   // run-limit admission (limits_host.inc)
   DevBuf d_lim[29], d_limpar[17];
   DevBuf d_step[13];  // step scheduler (steps_host.inc)
+  // preemption (include/crane_gpu/preempt.h): what cns_set_running kept of the running set, and the cycle's tables
+  u32 R = 0;                                    // running jobs of the last cns_set_running
+  std::vector<u32> ent_job, ent_slot;           // slot-grouped allocation entry d -> running job, slot
+  std::vector<i64> ent_end;                     // ... -> end time as handed in
+  bool pre_active = false;                      // the next run is a cycle with preemption (general path of k_select only)
+  PreParams pre_params{};
+  DevBuf d_pre[24];
   bool lim_have_tables = false, lim_have_jobs = false, lim_have_run = false;
   bool lim_has_upl = false, lim_has_apl = false, lim_has_sel = false, lim_has_skip = false;
   u32 lim_U = 0, lim_UA = 0, lim_A = 0, lim_Q = 0, lim_Pn = 0, lim_base[5] = {0, 0, 0, 0, 0};
@@ -209,6 +217,9 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.fault = h->d_fault.as<u32>();
   K.prof = h->d_prof.as<u64>();
   K.wide_ctl = h->d_wide.as<char>();
+  K.general_only = h->pre_active ? 1u : 0u;
+  K.pad_go = 0;
+  K.pre = h->pre_active ? h->pre_params : PreParams{};
   K.gres = h->gres;
   if (h->shared) {
     K.slot_block = h->d_slot_block.as<u32>(); K.sib_off = h->d_sib_off.as<u32>(); K.sib = h->d_sib.as<u32>();
@@ -412,6 +423,7 @@ void cns_destroy(cns_handle* h) {
   for (DevBuf& b : h->d_raw) b.release();
   for (DevBuf& b : h->d_limpar) b.release();
   for (DevBuf& b : h->d_step) b.release();
+  for (DevBuf& b : h->d_pre) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -629,6 +641,8 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
     }
     rn_end.resize(rn_off[S]);
     rn_res.resize(rn_off[S]);
+    h->ent_job.assign(rn_off[S], 0);
+    h->ent_slot.assign(rn_off[S], 0);
     std::vector<u32> cur(rn_off.begin(), rn_off.end() - 1);
     for (u32 j = 0; j < rn->num_jobs; ++j)  // stable: per slot, input order (cost accumulation order)
       for (u32 a = rn->alloc_offsets[j]; a < rn->alloc_offsets[j + 1]; ++a) {
@@ -642,9 +656,14 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
           u32 d = cur[q]++;
           rn_end[d] = rn->end_sec[j];
           rn_res[d] = r;
+          h->ent_job[d] = j;
+          h->ent_slot[d] = q;
         }
       }
   }
+  if (!(rn && rn->num_jobs)) { h->ent_job.clear(); h->ent_slot.clear(); }
+  h->R = rn ? rn->num_jobs : 0;
+  h->ent_end = rn_end;
   if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
   if (rn_end.empty()) { rn_end.push_back(0); rn_res.push_back(Res{0, 0, 0, 0, 0}); }
   if (int rc = upload(h, h->d_rn_end, rn_end)) return rc;
@@ -819,12 +838,12 @@ int cns_run_resident(cns_handle* h, int64_t now) {
     launch_select<CNS_ONLY_NPL>(h, K);
 #else
     bool launched = false;
-    if (use_wide_kernel(h)) {
+    if (!h->pre_active && use_wide_kernel(h)) {
 #define CNS_TRY_WWIDTH(w) if (!launched && np <= kWLanes * (w)) { if (launch_wide<w>(h, K)) return fail(h, CNS_ERR_HIP, "k_wide: control block allocation / upload failed"); launched = true; h->last_kernel = "k_wide<" #w ">"; }
       CNS_WNPL_LIST(CNS_TRY_WWIDTH)
 #undef CNS_TRY_WWIDTH
     }
-    if (!launched && use_pipe_kernel(h)) {
+    if (!launched && !h->pre_active && use_pipe_kernel(h)) {
 #define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; h->last_kernel = "k_pipe<" #w ">"; }
       CNS_PNPL_LIST(CNS_TRY_PWIDTH)
 #undef CNS_TRY_PWIDTH
@@ -894,21 +913,157 @@ int cns_select(cns_handle* h, int64_t now, const cns_job_soa* jobs, cns_placemen
   return cns_download(h, out);
 }
 
-// include/crane_gpu/preempt.h.  TryPreempt_ (JobScheduler.cpp:6378-6505) releases resources inside a cycle, which every
-// selection kernel here excludes by construction (node state is monotone within a cycle: caches, predicted tiles, the
-// decoupled commit); the CPU checker restates it (tests/test_preempt.py), the device form is the next step.  Until then a
-// cycle with preemption enabled is REFUSED — never served by a fallback.
-int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* preempt,
+// include/crane_gpu/preempt.h.  TryPreempt_ (JobScheduler.cpp:6378-6505) releases resources inside a cycle, which the
+// pipelined kernels exclude by construction (node state monotone within a cycle: caches, predicted tiles, decoupled
+// commits).  A cycle with preemption enabled therefore runs k_select with every job on its general path
+// (KParams::general_only) and the device form of TryPreempt_ / PreemptSegTree between the res_total selection and the
+// backfill (csrc/preempt_dev.inc).  Not combined yet with reservations or partitions that share nodes: refused.
+int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* pre,
                        cns_placement_soa* out, cns_preempt_out* pout) {
-  if (preempt && preempt->enabled)
-    return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: preemption (PreemptType != NONE) is not implemented on the device; keep the CPU SchedulerAlgo for this configuration");
-  if (int rc = cns_select(h, now, jobs, out)) return rc;
-  if (pout) {
-    if (pout->offsets && jobs) for (uint64_t j = 0; j <= jobs->num_jobs; ++j) pout->offsets[j] = 0;
-    pout->num_cancelled = 0;
-    const uint32_t n = preempt ? std::min(preempt->num_preempting, pout->preempting_capacity) : 0u;   // the set passes through
-    for (uint32_t i = 0; i < n; ++i) pout->preempting_job_ids[i] = preempt->preempting_job_ids[i];
-    pout->num_preempting = n;
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null handle");
+  if (!pre || !pre->enabled) {
+    if (int rc = cns_select(h, now, jobs, out)) return rc;
+    if (pout) {
+      if (pout->offsets && jobs) for (uint64_t j = 0; j <= jobs->num_jobs; ++j) pout->offsets[j] = 0;
+      pout->num_cancelled = 0;
+      const uint32_t n = pre ? std::min(pre->num_preempting, pout->preempting_capacity) : 0u;   // the set passes through
+      for (uint32_t i = 0; i < n; ++i) pout->preempting_job_ids[i] = pre->preempting_job_ids[i];
+      pout->num_preempting = n;
+    }
+    return CNS_OK;
+  }
+  if (!jobs || !out || !pout) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null argument");
+  if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_select_preempt before cns_set_nodes");
+  if (h->shared || h->V) return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: preemption together with reservations or partitions that share nodes is not implemented");
+  const u64 J = jobs->num_jobs;
+  const u32 R = h->R;
+  if (J && (!pre->pd_qos || !pre->pd_qos_priority || !pre->pd_priority)) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: missing pending-job array");
+  if (R && (!pre->rn_job_id || !pre->rn_qos || !pre->rn_qos_priority || !pre->rn_start_sec)) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: missing running-job array");
+  if (!pout->offsets || !pout->preempted || !pout->cancelled_job_ids || !pout->preempting_job_ids) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: missing output array");
+  HIPCHK(h, hipSetDevice(h->device));
+  if (int rc = cns_upload_jobs(h, jobs)) return rc;
+  const u32 A = (u32)h->ent_job.size();
+  // m_preempting_set_: ids that no longer run are dropped, the others end at now + 1 (JobScheduler.cpp:6545-6559)
+  std::map<u32, u32> id_to_rn;
+  for (u32 r = 0; r < R; ++r) id_to_rn.emplace(pre->rn_job_id[r], r);
+  std::vector<uint8_t> rj_pre(std::max<u32>(R, 1), 0);
+  std::vector<u32> set_in;
+  for (u32 i = 0; i < pre->num_preempting; ++i) {
+    auto it = id_to_rn.find(pre->preempting_job_ids[i]);
+    if (it == id_to_rn.end()) continue;
+    rj_pre[it->second] = 1;
+    set_in.push_back(pre->preempting_job_ids[i]);
+  }
+  std::vector<i64> ent_end = h->ent_end, rj_end(std::max<u32>(R, 1), 0), rj_start(std::max<u32>(R, 1), 0);
+  std::vector<u32> rj_qos(std::max<u32>(R, 1), 0), rj_qprio(std::max<u32>(R, 1), 0), rj_off(R + 1, 0), rj_ent(std::max<u32>(A, 1), 0);
+  for (u32 d = 0; d < A; ++d) rj_off[h->ent_job[d] + 1]++;
+  for (u32 r = 0; r < R; ++r) rj_off[r + 1] += rj_off[r];
+  {
+    std::vector<u32> cur(rj_off.begin(), rj_off.end() - 1);
+    for (u32 d = 0; d < A; ++d) rj_ent[cur[h->ent_job[d]]++] = d;
+  }
+  for (u32 r = 0; r < R; ++r) { rj_qos[r] = pre->rn_qos[r]; rj_qprio[r] = pre->rn_qos_priority[r]; rj_start[r] = pre->rn_start_sec[r]; }
+  std::vector<char> have_end(std::max<u32>(R, 1), 0);
+  for (u32 d = 0; d < A; ++d) {
+    const u32 r = h->ent_job[d];
+    if (rj_pre[r]) ent_end[d] = now + 1;
+    rj_end[r] = std::max<i64>(ent_end[d], now + 1);   // :6513-6514
+    have_end[r] = 1;
+  }
+  bool patched = false;
+  for (u32 r = 0; r < R; ++r) patched = patched || rj_pre[r];
+  if (patched) { if (int rc = upload(h, h->d_rn_end, ent_end)) return rc; }
+  // qos preempt lists, pending-job fields (by queue index)
+  std::vector<u32> qp_off(pre->num_qos + 1, 0), qp;
+  for (u32 q = 0; q < pre->num_qos; ++q) {
+    for (u32 i = pre->qos_preempt_offsets[q]; i < pre->qos_preempt_offsets[q + 1]; ++i) qp.push_back(pre->qos_preempt[i]);
+    qp_off[q + 1] = (u32)qp.size();
+  }
+  if (qp.empty()) qp.push_back(0);
+  std::vector<u32> pj_qos(std::max<u64>(J, 1), 0), pj_qprio(std::max<u64>(J, 1), 0);
+  std::vector<double> pj_prio(std::max<u64>(J, 1), 0.0);
+  for (u64 j = 0; j < J; ++j) { pj_qos[j] = pre->pd_qos[j]; pj_qprio[j] = pre->pd_qos_priority[j]; pj_prio[j] = pre->pd_priority[j]; }
+  const u64 places = std::max<u64>(h->places, 1);
+  const u32 pool_nodes = 1u << 16, cand_cap = 4096;
+  const u32 out_cap = (u32)std::min<u64>(4 * (J + R) + 64, 1u << 28);
+  enum { B_QPOFF, B_QP, B_PJQOS, B_PJQP, B_PJPRIO, B_PJREC0, B_PJK, B_PJEND, B_RNJOB, B_ENTSLOT, B_ENTGONE, B_RJQOS, B_RJQP,
+         B_RJSTART, B_RJEND, B_RJPRE, B_RJOFF, B_RJENT, B_HEAD, B_RECNEXT, B_RECORIG, B_RECSLOT, B_RECGONE, B_MISC };
+  DevBuf* B = h->d_pre;
+  if (int rc = upload(h, B[B_QPOFF], qp_off)) return rc;
+  if (int rc = upload(h, B[B_QP], qp)) return rc;
+  if (int rc = upload(h, B[B_PJQOS], pj_qos)) return rc;
+  if (int rc = upload(h, B[B_PJQP], pj_qprio)) return rc;
+  if (int rc = upload(h, B[B_PJPRIO], pj_prio)) return rc;
+  HIPCHK(h, B[B_PJREC0].ensure(std::max<u64>(J, 1) * 4)); HIPCHK(h, B[B_PJK].ensure(std::max<u64>(J, 1) * 4)); HIPCHK(h, B[B_PJEND].ensure(std::max<u64>(J, 1) * 8));
+  { std::vector<u32> ej = h->ent_job, es = h->ent_slot; if (ej.empty()) { ej.push_back(0); es.push_back(0); }
+    if (int rc = upload(h, B[B_RNJOB], ej)) return rc; if (int rc = upload(h, B[B_ENTSLOT], es)) return rc; }
+  HIPCHK(h, B[B_ENTGONE].ensure(std::max<u32>(A, 1))); HIPCHK(h, hipMemsetAsync(B[B_ENTGONE].p, 0, std::max<u32>(A, 1), h->stream));
+  if (int rc = upload(h, B[B_RJQOS], rj_qos)) return rc;
+  if (int rc = upload(h, B[B_RJQP], rj_qprio)) return rc;
+  if (int rc = upload(h, B[B_RJSTART], rj_start)) return rc;
+  if (int rc = upload(h, B[B_RJEND], rj_end)) return rc;
+  if (int rc = upload(h, B[B_RJPRE], rj_pre)) return rc;
+  if (int rc = upload(h, B[B_RJOFF], rj_off)) return rc;
+  if (int rc = upload(h, B[B_RJENT], rj_ent)) return rc;
+  HIPCHK(h, B[B_HEAD].ensure((size_t)std::max<u32>(h->S, 1) * 4)); HIPCHK(h, hipMemsetAsync(B[B_HEAD].p, 0xFF, (size_t)std::max<u32>(h->S, 1) * 4, h->stream));
+  HIPCHK(h, B[B_RECNEXT].ensure(places * 4)); HIPCHK(h, B[B_RECORIG].ensure(places * 4)); HIPCHK(h, B[B_RECSLOT].ensure(places * 4));
+  HIPCHK(h, B[B_RECGONE].ensure(places)); HIPCHK(h, hipMemsetAsync(B[B_RECGONE].p, 0, places, h->stream));
+  // one block for: segment-tree pools | candidate lists | chosen lists | output counter | output pairs
+  const size_t pool_b = (size_t)h->P * pool_nodes * sizeof(PreNode), cand_b = (size_t)h->P * cand_cap * 4;
+  const size_t off_cand = align16(pool_b), off_chosen = off_cand + align16(cand_b), off_cnt = off_chosen + align16(cand_b), off_out = off_cnt + 16;
+  HIPCHK(h, B[B_MISC].ensure(off_out + (size_t)out_cap * 8));
+  char* misc = B[B_MISC].as<char>();
+  HIPCHK(h, hipMemsetAsync(misc + off_cnt, 0, 16, h->stream));
+  PreParams& Q = h->pre_params;
+  Q = PreParams{};
+  Q.enabled = 1; Q.num_qos = pre->num_qos;
+  Q.qp_off = B[B_QPOFF].as<u32>(); Q.qp = B[B_QP].as<u32>();
+  Q.pj_qos = B[B_PJQOS].as<u32>(); Q.pj_qprio = B[B_PJQP].as<u32>(); Q.pj_prio = B[B_PJPRIO].as<double>();
+  Q.pj_rec0 = B[B_PJREC0].as<u32>(); Q.pj_k = B[B_PJK].as<u32>(); Q.pj_end = B[B_PJEND].as<i64>();
+  Q.rn_job = B[B_RNJOB].as<u32>(); Q.ent_slot = B[B_ENTSLOT].as<u32>(); Q.ent_gone = B[B_ENTGONE].as<uint8_t>();
+  Q.rj_qos = B[B_RJQOS].as<u32>(); Q.rj_qprio = B[B_RJQP].as<u32>(); Q.rj_start = B[B_RJSTART].as<i64>(); Q.rj_end = B[B_RJEND].as<i64>();
+  Q.rj_preempting = B[B_RJPRE].as<uint8_t>(); Q.rj_off = B[B_RJOFF].as<u32>(); Q.rj_ent = B[B_RJENT].as<u32>();
+  Q.slot_head = B[B_HEAD].as<u32>(); Q.rec_next = B[B_RECNEXT].as<u32>(); Q.rec_orig = B[B_RECORIG].as<u32>();
+  Q.rec_slot = B[B_RECSLOT].as<u32>(); Q.rec_gone = B[B_RECGONE].as<uint8_t>();
+  Q.pool = misc; Q.pool_nodes = pool_nodes; Q.cand_cap = cand_cap;
+  Q.cand = (u32*)(misc + off_cand); Q.chosen = (u32*)(misc + off_chosen);
+  Q.out_cnt = (u32*)(misc + off_cnt); Q.out = (u32*)(misc + off_out); Q.out_cap = out_cap;
+  h->pre_active = true;
+  int rc = cns_run_resident(h, now);
+  h->pre_active = false;
+  if (patched) { if (int rc2 = upload(h, h->d_rn_end, h->ent_end)) return rc2; HIPCHK(h, hipStreamSynchronize(h->stream)); }
+  if (rc) return rc;
+  if (int rc3 = cns_download(h, out)) return rc3;
+  // ---- the preempted lists: (pending job, reference) pairs in push_back order per job -> CSR by job ------------------
+  u32 cnt = 0;
+  HIPCHK(h, hipMemcpy(&cnt, misc + off_cnt, 4, hipMemcpyDeviceToHost));
+  if (cnt > out_cap) return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: more preemptions than the result buffer holds");
+  std::vector<u32> pairs((size_t)cnt * 2 + 2);
+  if (cnt) HIPCHK(h, hipMemcpy(pairs.data(), misc + off_out, (size_t)cnt * 8, hipMemcpyDeviceToHost));
+  if (cnt > pout->capacity) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: cns_preempt_out::capacity too small");
+  for (u64 j = 0; j <= J; ++j) pout->offsets[j] = 0;
+  for (u32 i = 0; i < cnt; ++i) pout->offsets[pairs[2 * i] + 1]++;
+  for (u64 j = 0; j < J; ++j) pout->offsets[j + 1] += pout->offsets[j];
+  {
+    std::vector<u64> cur(pout->offsets, pout->offsets + J);
+    for (u32 i = 0; i < cnt; ++i) pout->preempted[cur[pairs[2 * i]]++] = pairs[2 * i + 1];   // append order = push_back order within a job
+  }
+  // m_preempting_set_ / EnqueuePreemptCancel (:6786-6793), in queue order
+  std::set<u32> pset(set_in.begin(), set_in.end());
+  pout->num_cancelled = 0;
+  for (u64 j = 0; j < J; ++j)
+    for (u64 x = pout->offsets[j]; x < pout->offsets[j + 1]; ++x) {
+      const u32 ref = pout->preempted[x];
+      if (ref & CNS_PREEMPT_REF_PENDING) continue;
+      const u32 id = pre->rn_job_id[ref];
+      if (!pset.insert(id).second) continue;
+      if (pout->num_cancelled >= pout->cancel_capacity) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: cancel_capacity too small");
+      pout->cancelled_job_ids[pout->num_cancelled++] = id;
+    }
+  pout->num_preempting = 0;
+  for (u32 id : pset) {
+    if (pout->num_preempting >= pout->preempting_capacity) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: preempting_capacity too small");
+    pout->preempting_job_ids[pout->num_preempting++] = id;
   }
   return CNS_OK;
 }

@@ -79,6 +79,48 @@ struct UpdRec {  // what the owning scanner lane must refresh after a commit
 
 enum JobFlags : u32 { kJfExclusive = 1, kJfIncl = 2, kJfExcl = 4, kJfGres = 8 };
 
+// Preemption tables (include/crane_gpu/preempt.h; null / 0 unless the cycle runs with preemption enabled, which forces
+// k_select's general path: TryPreempt_ RELEASES resources, the one thing every fast path excludes).
+struct PreNode {   // PreemptSegTree::Node, JobScheduler.h:869-877; children are pool indices (0 = none: index 0 is never a child)
+  i64 st, ed;
+  u32 ls, rs;
+  u32 sat, pad;
+  Res res, add_tag, sub_tag;
+};
+struct PreParams {
+  u32 enabled, num_qos;
+  const u32* qp_off;       // [num_qos + 1] Qos::preempt lists ...
+  const u32* qp;           // ... as qos ids
+  const u32* pj_qos;       // [J] by queue index (orig): qos id, qos_priority, priority of the pending job
+  const u32* pj_qprio;
+  const double* pj_prio;
+  u32* pj_rec0;            // [J] first placement record of a job placed in this cycle (written at its commit) ...
+  u32* pj_k;               // ... and how many
+  i64* pj_end;             // ... and its end time (start is o_start[orig])
+  const u32* rn_job;       // [A] running allocation entry d (slot-grouped, as rn_end / rn_res) -> running job index
+  const u32* ent_slot;     // [A] ... -> its slot
+  uint8_t* ent_gone;       // [A] erased from the node's qos_job_map (JobScheduler.h:653-657)
+  const u32* rj_qos;       // [R] running job: qos id, qos_priority, start, end as the cycle sees it, in m_preempting_set_?
+  const u32* rj_qprio;
+  const i64* rj_start;
+  const i64* rj_end;
+  const uint8_t* rj_preempting;
+  const u32* rj_off;       // [R + 1] entries d of running job r ...
+  const u32* rj_ent;
+  u32* slot_head;          // [S] newest placement record of this cycle on slot q (kNone: none) ...
+  u32* rec_next;           // [places] ... linked through here
+  u32* rec_orig;           // [places] the pending job of a placement record
+  u32* rec_slot;           // [places] its slot
+  uint8_t* rec_gone;       // [places] erased from the node's qos_job_map
+  char* pool;              // segment-tree nodes, pool_nodes per partition
+  u32 pool_nodes, cand_cap;
+  u32* cand;               // [P * cand_cap] candidate references (bit 31: pending job), sorted in place
+  u32* chosen;             // [P * cand_cap] preempted_jobs of the job at hand
+  u32* out_cnt;            // [1] pairs appended so far
+  u32* out;                // [2 * out_cap] (pending job (orig), reference) in push_back order per job
+  u32 out_cap, pad0;
+};
+
 struct KParams {
   // ---- cluster -------------------------------------------------------------------------
   u32 num_nodes, num_parts, num_slots, num_types;
@@ -130,6 +172,8 @@ struct KParams {
   u32* fault;              // [4] != 0: an internal invariant failed (code, job, aux, aux)
   u64* prof;               // [P*32] cycle counters (only written by -DCNS_PROF builds)
   char* wide_ctl;          // [P] WideCtl blocks of k_wide (exchange rings + control words), zeroed before every launch
+  u32 general_only, pad_go; // != 0: every job through the general path of k_select (preemption enabled)
+  PreParams pre;
   GresDev gres;
   // ---- partitions that share nodes (null otherwise) ----------------------------------------------------------------
   const u32* slot_block;   // [S] slot whose NodeBlock holds the node's (shared) time map = the node's first slot

@@ -40,6 +40,13 @@ namespace cns {
 // small device helpers
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 cost_key(double c) { return (u64)__double_as_longlong(c); }
+// ... and an order-preserving key for costs of EITHER sign: a cycle with preemption releases cost (UpdateCost(...,
+// is_release)), a job preempted twice even below zero, where the raw bit pattern orders the wrong way round.
+// smode = ~0: signed mode; 0: the raw pattern (costs only grow from >= 0 in every other cycle).
+__device__ __forceinline__ u64 cost_key_m(double c, u64 smode) {
+  const u64 b = (u64)__double_as_longlong(c);
+  return b ^ (smode & ((u64)((i64)b >> 63) | 0x8000000000000000ull));
+}
 
 __device__ __forceinline__ u32 uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni32((u32)(v >> 32)) << 32) | uni32((u32)v); }
@@ -657,6 +664,7 @@ __device__ __forceinline__ u32 tl_commit_regs(const KParams& P, NodeHdr* hd, TlE
 
 // General form (any length): chunks are rewritten from the highest down so that the <= 2-slot shift
 // never overwrites an entry that has not been read yet.
+template <bool kRelease = false>   // kRelease: UpdateResourceInNode(..., is_release = true): += instead of -=
 __device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, i64 end, const Res& res, u32 lane, u32 job) {
   TlEntry* T = tl_of(hd);
   const u32 len = hd->len;
@@ -686,12 +694,12 @@ __device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, 
     if (act) e = T[i];
     u32 np = i + ((ins_s && i > ib) ? 1u : 0u) + ((ins_e && i > ie0) ? 1u : 0u);
     bool sub = act && e.t >= start && e.t < end;
-    if (sub) res_sub(e.r, res);
+    if (sub) { if (kRelease) res_add(e.r, res); else res_sub(e.r, res); }
     if (act && (np != i || sub)) T[np] = e;
   }
   const u32 nlen = len + (ins_s ? 1u : 0u) + (ins_e ? 1u : 0u);
   if (lane == 0) {
-    if (ins_s) { TlEntry s = eb; s.t = start; res_sub(s.r, res); T[ib + 1] = s; }
+    if (ins_s) { TlEntry s = eb; s.t = start; if (kRelease) res_add(s.r, res); else res_sub(s.r, res); T[ib + 1] = s; }
     if (ins_e) { TlEntry x = ee; x.t = end; T[ie0 + (ins_s ? 1u : 0u) + 1] = x; }
     hd->len = nlen;
   }
@@ -844,7 +852,14 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
     P.o_clo[o] = me.res.clo;
     P.o_chi[o] = me.res.chi;
     P.o_gres[o] = me.res.gres;
+    if (P.pre.enabled) {   // UpdateNodeSelectorWithScheduledJob (h:636-642): the job joins its nodes' qos_job_map
+      const u32 q = qbeg + slot_of_code_t<kS>(me.p);
+      P.pre.rec_orig[o] = orig; P.pre.rec_slot[o] = q; P.pre.rec_gone[o] = 0;
+      P.pre.rec_next[o] = P.pre.slot_head[q];   // (the k nodes are distinct: no two lanes touch one list)
+      P.pre.slot_head[q] = (u32)o;
+    }
   }
+  if (P.pre.enabled && lane == 0) { P.pre.pj_rec0[orig] = (u32)poff; P.pre.pj_k[orig] = J.k; P.pre.pj_end[orig] = end; }
 }
 
 // Single-node ending (node_num == 1) straight from the register-resident chunk: commit, cost, owner
@@ -987,6 +1002,8 @@ struct WorkerShared {
 #define PROF_ADDS(slot, a, b)
 #endif
 
+#include "preempt_dev.inc"
+
 // Out-of-line worker path for everything that is not "node_num == 1, ntasks == 1, shared node":
 // multi-node jobs, ntasks > node_num (priority_queue emulation) and exclusive jobs.  Enters after the
 // round-0 barrier with the A and T winners, leaves after the job's last barrier; returns the LDS
@@ -1007,7 +1024,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   }
   const u32 orig = J.orig;
   HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
-  UpdRec* const s_upd = (J.k <= (u32)kMaxUpd && !P.sib_off) ? sh.upd : P.g_upd + qbeg;  // long lists (and sibling slots of shared nodes) go through HBM
+  UpdRec* const s_upd = (J.k <= (u32)kMaxUpd && !P.sib_off && !P.general_only) ? sh.upd : P.g_upd + qbeg;  // long lists (sibling slots of shared nodes, releases of a preemption) go through HBM
   int* const s_nupd = sh.nupd;
 
   // ---- Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) -------------
@@ -1039,7 +1056,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     if (ok) {
       HeapEnt x;
       x.ntasks = ta; x.p = wcode; x.node = n; x.pad = 0;
-      x.cost = __longlong_as_double((long long)wc);
+      x.cost = P.cost[q];   // (= the scanners' value: every earlier commit is in; the key may be in signed form, cost_key_m)
       x.res = m;
       int nsum = hsum + ta, nsize = hsize + 1;
       if (lane == 0) {
@@ -1059,7 +1076,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
         code = 2;
       }
     }
-    if (J.k > (u32)kMaxUpd || P.sib_off) __threadfence_block();  // the owner updates went through HBM (g_upd)
+    if (J.k > (u32)kMaxUpd || P.sib_off || P.general_only) __threadfence_block();  // the owner updates went through HBM (g_upd)
     if (lane == 0) *sh.flag = code;
     wg_barrier();  // B2: verdict (and, on success, the owner updates) visible to the scanners
     if (code == 2) return par;
@@ -1082,7 +1099,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     NodeHdr* const hd = hdr_of(P, qbeg + slot_of_code_t<kS>(ccode));
     HeapEnt x;
     x.p = ccode; x.node = hd->node; x.pad = 0;
-    x.cost = __longlong_as_double((long long)cc);
+    x.cost = P.cost[qbeg + slot_of_code_t<kS>(ccode)];
     x.res = res_zero();
     if (!J.general) {
       x.ntasks = 1;
@@ -1123,10 +1140,46 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     }
     __threadfence_block();
     if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 3, orig, 0, 1); }
+    // TryPreempt_ before Backfill_ (JobScheduler.cpp:6140-6143), only in a cycle that was started with preemption
+    bool preempted = false;
+    if (P.pre.enabled) {
+      u32 pf = 0;
+      const int nch = pre_try<kS>(P, J, H, qbeg, sh.part, &pf);
+      if (pf && lane == 0) set_fault(P, pf, orig, J.k, 0);
+      if (nch >= 0) {
+        const u32 nn = P.part_off[sh.part + 1] - qbeg;
+        u32* const touched = P.bf_j + qbeg;   // (the backfill cursors are not needed on this branch)
+        const u32 nt = pre_release(P, J, qbeg, nn, sh.part, (u32)nch, touched);
+        for (u32 i = lane; i < J.k; i += 64) H[i].cost = P.cost[qbeg + slot_of_code_t<kS>(H[i].p)];   // the releases lowered costs
+        __threadfence_block();
+        commit_selection<kS>(P, J, H, qbeg, P.now, lane, s_upd, s_nupd);   // start_time = now (:6501), h:630-634
+        // the scanners' rows of the nodes that were released on (other than the job's own: their records are final)
+        u32 nup = (u32)*s_nupd;
+        for (u32 x = 0; x < nt; ++x) {
+          const u32 q = touched[x];
+          bool dup = false;
+          for (u32 i = 0; i < J.k; ++i) dup = dup || qbeg + slot_of_code_t<kS>(H[i].p) == q;
+          if (dup) continue;
+          NodeHdr* hd = hdr_of(P, q);
+          if (lane == 0) {
+            UpdRec u;
+            const u32 ps = q - qbeg;
+            u.p = ((ps / kS) << 10) | (ps % kS);
+            u.len = hd->len; u.cost = P.cost[q]; u.fcpu = P.f_cpu[q]; u.fmem = P.f_mem[q]; u.fcnt = P.f_cnt[q];
+            u.has_front = 1u; u.pad = 0;
+            s_upd[nup] = u;
+          }
+          ++nup;
+        }
+        if (lane == 0) { *s_nupd = (int)nup; P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
+        code = 2;
+        preempted = true;
+      }
+    }
     // EarliestStartSubsetSelector::CalcEarliestStartTime as a fixed point over the k nodes
     i64 t = P.now;
     bool found = false;
-    for (u32 iter = 0; iter < (1u << 22); ++iter) {
+    for (u32 iter = 0; iter < (1u << 22) && !preempted; ++iter) {
       i64 Tm = t;
       for (u32 i = 0; i < J.k; ++i) {
         const HeapEnt x = H[i];
@@ -1157,7 +1210,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     }
   }
   if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
-  if (J.k > (u32)kMaxUpd || P.sib_off) __threadfence_block();  // the owner updates went through HBM (g_upd)
+  if (J.k > (u32)kMaxUpd || P.sib_off || P.general_only) __threadfence_block();  // the owner updates went through HBM (g_upd)
   if (lane == 0) *sh.flag = code;
   wg_barrier();  // B3
   return par;
@@ -1632,7 +1685,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       PROF_T(p0);
       const FastJob F = make_fast_job(P, raw);
       const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
-      const bool shared_nodes = P.sib_off != nullptr;   // partitions that share nodes: everything through the general path
+      const bool shared_nodes = P.sib_off != nullptr || P.general_only;   // partitions that share nodes / a cycle with preemption: everything through the general path
       const bool fast = simple && F.k == 1 && F.tmin == 1 && !shared_nodes;
 
       if (!pre_valid) {
@@ -2029,12 +2082,13 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     };
 
     // argmin of (cost, code) over the lane's nodes whose bit is set in `mask`; ties keep the lower r
+    const u64 smode = P.general_only ? ~0ull : 0ull;   // signed cost keys in a cycle with preemption (cost_key_m)
     auto lane_argmin = [&](RM mask, u64& bc, u32& bp) {
       bc = ~0ull;
       u32 br = 0xFFu;
 #pragma unroll
       for (int r = 0; r < NPL; ++r) {
-        const u64 ck = cost_key(cost[r]);
+        const u64 ck = cost_key_m(cost[r], smode);
         const bool take = ((mask >> r) & 1u) & (ck < bc);
         bc = take ? ck : bc;
         br = take ? (u32)r : br;
@@ -2096,7 +2150,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               a = a & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
             }
           }
-          const u64 ck = cost_key(cost[r]);
+          const u64 ck = cost_key_m(cost[r], smode);
           const bool ta = a & (ck < ac);
           ac = ta ? ck : ac;
           ar = ta ? (u32)r : ar;
@@ -2225,7 +2279,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       ScanJob Jn = J;
       u64 typeok_n = typeok;
       const bool have_next = ji + 1 < jend;
-      const bool shared_nodes = P.sib_off != nullptr;
+      const bool shared_nodes = P.sib_off != nullptr || P.general_only;
       const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes;  // this job touches one node, a round-0 winner
       RM skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= kOne << (wcode >> 10);

@@ -203,6 +203,16 @@ class GpuNodeSelector:
         return out
 
     # split form: inputs resident in HBM before the timed region (bench.py)
+    def node_select_preempt(self, now: int, jobs: abi.Jobs, preempt: "abi.Preempt"):
+        """NodeSelect with preemption (include/crane_gpu/preempt.h): TryPreempt_ between the res_total selection and the
+        backfill; -> (Placements, PreemptOut).  The running set must have been handed in with set_running."""
+        out = abi.Placements(jobs.num_jobs, jobs.total_places())
+        pout = abi.PreemptOut(jobs.num_jobs, len(preempt.rn_job_id))
+        cj, co, cp, cpo = jobs.to_c(), out.to_c(), preempt.to_c(), pout.to_c()
+        self._check(self._L.cns_select_preempt(self._h, C.c_int64(now), C.byref(cj), C.byref(cp), C.byref(co), C.byref(cpo)))
+        self._jobs = jobs
+        return out, pout
+
     def upload_jobs(self, jobs: abi.Jobs):
         cj = jobs.to_c()
         self._check(self._L.cns_upload_jobs(self._h, C.byref(cj)))

@@ -159,3 +159,85 @@ def test_python_restatement_on_random_preempt_cases(built, seed):
         # the generator must actually exercise the path
         tot = sum(len(x) for s in range(500, 520) for x in pyoracle.select(*random_preempt_case(s)[:3], running=random_preempt_case(s)[3], preempt=random_preempt_case(s)[4]).preempt_out.lists())
         assert tot > 20, f"only {tot} preemptions in 20 random cases"
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The HIP engine (cns_select_preempt: k_select's general path + csrc/preempt_dev.inc) against the oracle
+# ---------------------------------------------------------------------------------------------------------------------
+def run_engine_preempt(c, j, now, run, pre, **cfg):
+    from cranesched_amd.engine import GpuNodeSelector
+    eng = GpuNodeSelector(device=0, **cfg)
+    eng.set_nodes(c)
+    eng.set_running(run)
+    pl, po = eng.node_select_preempt(now, j, pre)
+    return eng, pl, po
+
+
+def compare_engine(tag, c, j, ref, eng, pl, po):
+    d = pl.diff(ref.placements)
+    assert d is None, f"{tag}: engine placements differ from the oracle: {d}"
+    rpo = ref.preempt_out
+    assert po.lists() == rpo.lists(), f"{tag}: preempted lists {po.lists()} (engine) vs {rpo.lists()} (oracle)"
+    assert po.cancelled_ids() == rpo.cancelled_ids(), f"{tag}: cancelled {po.cancelled_ids()} vs {rpo.cancelled_ids()}"
+    assert po.preempting_ids() == rpo.preempting_ids(), f"{tag}: preempting set"
+    assert np.array_equal(eng.costs().view(np.uint64), ref.costs().view(np.uint64)), f"{tag}: fp64 costs differ"
+    for n in range(c.num_nodes):
+        a, b = eng.timeline(n), ref.timeline(n)
+        for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+            assert np.array_equal(a[f], b[f]), f"{tag}: time map of node {n}, field {f}: {a[f]} vs {b[f]}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scn", kat_preempt.scenarios(), ids=lambda s: s[0])
+def test_engine_preempt_known_answers(built, scn):
+    from oracle import pyoracle
+    name, c, j, r, pre, expect = scn
+    ref = pyoracle.select(c, j, kat_preempt.NOW, running=r, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, kat_preempt.NOW, r, pre)
+    try:
+        compare_engine(name, c, j, ref, eng, pl, po)
+        assert eng.last_kernel().startswith("k_select")
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_engine_preempt_random_cases(built, seed):
+    from oracle import pyoracle
+    c, j, now, run, pre = random_preempt_case(500 + seed, N=6 + seed % 7, J=50 + seed % 40, P=1 + seed % 2, running=10 + seed % 11)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        compare_engine(f"random preempt {seed}", c, j, ref, eng, pl, po)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(6))
+def test_engine_preempt_larger_cases(built, seed):
+    """More nodes, multi-partition, many running jobs: long candidate lists, deep trees, several releases per job."""
+    from oracle import pyoracle
+    c, j, now, run, pre = random_preempt_case(900 + seed, N=48 + 8 * seed, J=500, P=2, running=120)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        compare_engine(f"larger preempt {seed}", c, j, ref, eng, pl, po)
+        assert sum(len(x) for x in po.lists()) > 0
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_engine_preempt_disabled_is_the_plain_cycle(built):
+    from oracle import pyoracle
+    c, j, now, run, pre = random_preempt_case(777, N=12, J=80, P=1, running=16)
+    pre.enabled = False
+    pre.preempting = np.zeros(0, np.uint32)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        ref = pyoracle.select(c, j, now, running=run)
+        assert pl.diff(ref.placements) is None and po.lists() == [[] for _ in range(j.num_jobs)]
+    finally:
+        eng.close()
