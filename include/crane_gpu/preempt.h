@@ -13,9 +13,12 @@
  * QoS names are dense ids (the caller's string table); job references in the results are indices into the cycle's
  * pending queue (bit 31 set) or running table (bit 31 clear).
  *
- * STATUS: the CPU oracle (oracle/sched_oracle.hpp, TryPreempt_ + PreemptSegTree restated) takes these structs today;
- * cns_select_preempt exists and fails loudly with CNS_ERR_UNSUPPORTED while `enabled` is set — the device form is the
- * next step.  With `enabled == 0` it is cns_select.
+ * How it runs: a cycle with `enabled` set goes through k_select with every job on its general path and the device form
+ * of TryPreempt_ / PreemptSegTree between the res_total selection and the backfill (csrc/preempt_dev.inc; DESIGN.md
+ * 5j); bit-exact against the CPU oracle's restatement (tests/test_preempt.py).  Limits, refused with
+ * CNS_ERR_UNSUPPORTED: preemption together with reservations or with partitions that share nodes.  Candidates that
+ * the reference's comparator leaves unordered (it sorts the iteration order of a hash set) are taken in ascending
+ * index.  With `enabled == 0` the call is cns_select.
  */
 #ifndef CRANE_GPU_PREEMPT_H
 #define CRANE_GPU_PREEMPT_H
