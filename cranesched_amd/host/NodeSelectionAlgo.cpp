@@ -3,6 +3,7 @@
 // PdJobInScheduler exactly where the reference's NodeSelect leaves them
 // (src/CraneCtld/JobScheduler.cpp:6322-6331, :6772, :6768-6831; consumed at :1492-1600).
 #include "NodeSelectionAlgo.h"
+#include "../../include/crane_gpu/preempt.h"
 
 #include <algorithm>
 #include <chrono>
@@ -17,7 +18,7 @@
 namespace crane {
 
 namespace {
-const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", "", "Reservation Not Found"};
+const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", "", "Reservation Not Found", "Preempted"};
 }
 
 struct GpuNodeSelectionAlgo::Impl {
@@ -75,6 +76,21 @@ struct GpuNodeSelectionAlgo::Impl {
     return 0;
   }
   std::unordered_map<job_id_t, PackedAlloc> alloc_cache;
+  // preemption (include/crane_gpu/preempt.h)
+  bool preempt_enabled = false;
+  std::unordered_map<std::string, uint32_t> qos_id;                 // qos name -> dense id
+  std::vector<std::vector<uint32_t>> qos_preempt;                   // id -> ids it may preempt
+  std::set<job_id_t> preempting;                                    // m_preempting_set_
+  std::vector<job_id_t> cancelled;                                  // EnqueuePreemptCancel of the last cycle
+  std::vector<RnJobInScheduler*> r_src;                             // packed running job r -> the caller's object
+  uint32_t qos_of(const std::string& name) {
+    auto it = qos_id.find(name);
+    if (it != qos_id.end()) return it->second;
+    const uint32_t id = (uint32_t)qos_id.size();
+    qos_id.emplace(name, id);
+    qos_preempt.emplace_back();   // a qos the table does not know: nothing to preempt (cpp:6537-6539)
+    return id;
+  }
   uint64_t alloc_gen = 0;
   bool use_alloc_cache = true;
   std::vector<int64_t> r_end, r_cpu;
@@ -231,6 +247,7 @@ struct GpuNodeSelectionAlgo::Impl {
   // running jobs -> cns_running_soa arrays (JobScheduler.cpp:6681-6709); order = the caller's vector
   void pack_running(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
     r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
+    r_src.clear();
     r_off.assign(1, 0);
     ++alloc_gen;
     PackedAlloc scratch;
@@ -266,6 +283,7 @@ struct GpuNodeSelectionAlgo::Impl {
       pa->gen = alloc_gen;
       r_resv.push_back(rv);
       r_end.push_back(rn->end_time);
+      r_src.push_back(rn.get());
       for (const AllocRec& a : pa->recs) {
         r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
         r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g);
@@ -505,10 +523,20 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   const uint32_t N = (uint32_t)snap.craned_metas.size();
   I.node_name.clear(); I.node_mem_sw.clear(); I.node_idx.clear(); I.part_idx.clear();
   I.core_overflow = false;
+  I.preempt_enabled = snap.preempt_enabled;
+  I.qos_id.clear(); I.qos_preempt.clear();
   if (snap.preempt_enabled) {
-    status_ = CNS_ERR_UNSUPPORTED;
-    error_ = "preemption is enabled (PreemptType != NONE): TryPreempt_ / PreemptSegTree are not implemented by the GPU engine; keep the CPU SchedulerAlgo";
-    return;
+    if (!snap.reservations.empty()) {
+      status_ = CNS_ERR_UNSUPPORTED;
+      error_ = "preemption (PreemptType != NONE) together with reservations is not implemented by the GPU engine; keep the CPU SchedulerAlgo";
+      return;
+    }
+    for (const auto& [name, lst] : snap.qos_preempt) I.qos_of(name);
+    for (const auto& [name, lst] : snap.qos_preempt) {
+      std::vector<uint32_t> ids;
+      for (const auto& p : lst) ids.push_back(I.qos_of(p));
+      I.qos_preempt[I.qos_id.at(name)] = ids;
+    }
   }
   I.classes.clear(); I.name_id.clear(); I.class_slot_bit.clear(); I.class_bit_slot.clear();
   // GRES classes: every (name,type) seen in any res_total; bits per class = union of its slot paths
@@ -752,8 +780,50 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   out.core_lo = S.lo.data(); out.core_hi = S.hi.data(); out.gres = S.g.data();
   I.last_index.clear();
   I.last_ord.clear();
-  st = cns_select(I.h, now, &js, &out);
-  if (st != 0) return fail_all(st, cns_last_error(I.h));
+  I.cancelled.clear();
+  for (PdJobInScheduler* p : ord) p->preempted_jobs.clear();
+  if (!I.preempt_enabled) {
+    st = cns_select(I.h, now, &js, &out);
+    if (st != 0) return fail_all(st, cns_last_error(I.h));
+  } else {
+    // ---- the cycle with preemption (include/crane_gpu/preempt.h): qos ids, the fields TryPreempt_ reads, the set ------
+    if (I.r_src.size() != I.r_end.size())
+      return fail_all(CNS_ERR_STATE, "preemption needs the running jobs themselves: call NodeSelect(now, running_jobs, pending_jobs)");
+    const uint32_t R = (uint32_t)I.r_src.size();
+    std::vector<uint32_t> pj_id(J + 1), pj_qos(J + 1), pj_qp(J + 1), rj_id(R + 1), rj_qos(R + 1), rj_qp(R + 1), pset;
+    std::vector<double> pj_prio(J + 1);
+    std::vector<int64_t> rj_start(R + 1);
+    for (size_t j = 0; j < J; ++j) { pj_id[j] = ord[j]->job_id; pj_qos[j] = I.qos_of(ord[j]->qos); pj_qp[j] = ord[j]->qos_priority; pj_prio[j] = ord[j]->priority; }
+    for (uint32_t r = 0; r < R; ++r) { rj_id[r] = I.r_src[r]->job_id; rj_qos[r] = I.qos_of(I.r_src[r]->qos); rj_qp[r] = I.r_src[r]->qos_priority; rj_start[r] = I.r_src[r]->start_time; }
+    for (job_id_t id : I.preempting) pset.push_back(id);
+    std::vector<uint32_t> qoff(I.qos_preempt.size() + 1, 0), qflat;
+    for (size_t q = 0; q < I.qos_preempt.size(); ++q) { for (uint32_t x : I.qos_preempt[q]) qflat.push_back(x); qoff[q + 1] = (uint32_t)qflat.size(); }
+    if (qflat.empty()) qflat.push_back(0);
+    if (pset.empty()) pset.push_back(0);
+    cns_preempt_soa ps{};
+    ps.enabled = 1; ps.num_qos = (uint32_t)I.qos_preempt.size();
+    ps.qos_preempt_offsets = qoff.data(); ps.qos_preempt = qflat.data();
+    ps.pd_job_id = pj_id.data(); ps.pd_qos = pj_qos.data(); ps.pd_qos_priority = pj_qp.data(); ps.pd_priority = pj_prio.data();
+    ps.rn_job_id = rj_id.data(); ps.rn_qos = rj_qos.data(); ps.rn_qos_priority = rj_qp.data(); ps.rn_start_sec = rj_start.data();
+    ps.num_preempting = (uint32_t)I.preempting.size(); ps.preempting_job_ids = pset.data();
+    std::vector<uint64_t> po_off(J + 1, 0);
+    std::vector<uint32_t> po_refs(4 * (J + R) + 64), po_cancel(R + 1), po_set(R + I.preempting.size() + 1);
+    cns_preempt_out po{};
+    po.capacity = po_refs.size(); po.offsets = po_off.data(); po.preempted = po_refs.data();
+    po.cancel_capacity = (uint32_t)po_cancel.size(); po.cancelled_job_ids = po_cancel.data();
+    po.preempting_capacity = (uint32_t)po_set.size(); po.preempting_job_ids = po_set.data();
+    st = cns_select_preempt(I.h, now, &js, &ps, &out, &po);
+    if (st != 0) return fail_all(st, cns_last_error(I.h));
+    for (size_t j = 0; j < J; ++j)
+      for (uint64_t x = po_off[j]; x < po_off[j + 1]; ++x) {
+        const uint32_t ref = po_refs[x];
+        if (ref & CNS_PREEMPT_REF_PENDING) ord[j]->preempted_jobs.emplace_back(ord[ref & 0x7FFFFFFFu]);
+        else ord[j]->preempted_jobs.emplace_back(I.r_src[ref]);
+      }
+    I.cancelled.assign(po_cancel.begin(), po_cancel.begin() + po.num_cancelled);
+    I.preempting.clear();
+    for (uint32_t i = 0; i < po.num_preempting; ++i) I.preempting.insert(po_set[i]);
+  }
   I.last_ord.assign(ord.begin(), ord.end());
   S.jobs = J;
   status_ = 0;
@@ -765,6 +835,8 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
 // Placement -> wire
 // ---------------------------------------------------------------------------------------------------------
 const std::vector<const PdJobInScheduler*>& GpuNodeSelectionAlgo::LastOrder() const { return impl_->last_ord; }
+const std::vector<job_id_t>& GpuNodeSelectionAlgo::LastPreemptCancel() const { return impl_->cancelled; }
+const std::set<job_id_t>& GpuNodeSelectionAlgo::PreemptingSet() const { return impl_->preempting; }
 
 size_t GpuNodeSelectionAlgo::EmitStartedResourcesWire(WireBatch* out) const {
   const Impl& I = *impl_;

@@ -25,6 +25,7 @@
 #include <string>
 #include <unordered_map>
 #include <unordered_set>
+#include <variant>
 #include <vector>
 
 struct cns_engine;
@@ -77,6 +78,7 @@ using ResourceV3 = std::unordered_map<CranedId, ResourceInNodeV3>;  // EachNodeR
 
 struct RnJobInScheduler {  // JobScheduler.h:57-90
   job_id_t job_id{0};
+  std::string qos;                    // h:68: read by TryPreempt_ through NodeState::qos_job_map
   PartitionId partition_id;
   std::string reservation;
   TimeSec start_time{0};
@@ -89,6 +91,9 @@ struct RnJobInScheduler {  // JobScheduler.h:57-90
   uint32_t node_num{0};               // uninitialised in the reference (h:70,76-89); here: allocated_res.size() when 0
   ResourceView allocated_res_view;    // cpu_count + memory_bytes of the whole allocation
 };
+
+struct PdJobInScheduler;
+using PreemptedJob = std::variant<PdJobInScheduler*, RnJobInScheduler*>;   // JobScheduler.h:124-126
 
 struct PdJobInScheduler {  // JobScheduler.h:92-170
   job_id_t job_id{0};
@@ -111,6 +116,7 @@ struct PdJobInScheduler {  // JobScheduler.h:92-170
   ResourceV3 allocated_res;
   std::vector<CranedId> craned_ids;
   std::string reason;
+  std::vector<PreemptedJob> preempted_jobs;   // result of TryPreempt_ (JobScheduler.cpp:6490-6496), push_back order
   bool is_scheduled() const { return reason.empty(); }
   // licenses (JobScheduler.h:141-146; LicenseManager::CheckLicenseCountSufficient, LicenseManager.cpp:167-221)
   std::vector<std::pair<std::string, uint32_t>> req_licenses;   // (license id, count), request order
@@ -150,10 +156,13 @@ struct ClusterSnapshot {
   std::vector<CranedMeta> craned_metas;                                   // dense order = canonical tie-break order
   std::vector<std::pair<PartitionId, std::vector<CranedId>>> partitions;  // PartitionMeta::craned_ids
   std::vector<ResvMeta> reservations;                                     // g_meta_container->GetResvMetaMapPtr(); vector order = canonical order
-  // g_config.PreemptType != NONE: NodeSelect would call LocalScheduler::TryPreempt_ (JobScheduler.cpp:6140-6143), which
-  // the engine does not implement.  SetClusterSnapshot then refuses the snapshot (status() = CNS_ERR_UNSUPPORTED) so that
+  // g_config.Preempt.PreemptType != NONE (PREEMPT_QOS): NodeSelect calls LocalScheduler::TryPreempt_ (JobScheduler.cpp:
+  // 6140-6143) with the preempt lists of the QoS table (cpp:6532-6543: Qos::preempt of every pending job's qos).  Served by
+  // cns_select_preempt (include/crane_gpu/preempt.h) through NodeSelect(now, running_jobs, pending_jobs); a snapshot that
+  // combines it with reservations or with partitions that share nodes is refused (status() = CNS_ERR_UNSUPPORTED) so that
   // the integrator keeps the CPU SchedulerAlgo instead of getting "GpuEngineError" on every job of every cycle.
   bool preempt_enabled{false};
+  std::unordered_map<std::string, std::vector<std::string>> qos_preempt;   // qos name -> Qos::preempt
 };
 
 // ---- what the commit loop's run-limit admission reads (JobScheduler.cpp:1557-1573) -----------------------------
@@ -376,6 +385,12 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
                            std::string* wire, ResourceInNodeV3* obj) const;
   // ... and the emission of PendingCycleForBench's synthetic placements (ms per call)
   double EmitWireForBench(size_t* records, size_t* bytes);
+
+  // ---- preemption (only when the snapshot had preempt_enabled) -------------------------------------------------------
+  // m_preempting_set_ (JobScheduler.h:984) lives in the adapter across cycles; the running jobs newly put into it by the
+  // last cycle are what the reference hands to EnqueuePreemptCancel (JobScheduler.cpp:6793), in that order.
+  const std::vector<job_id_t>& LastPreemptCancel() const;
+  const std::set<job_id_t>& PreemptingSet() const;
 
   bool Ok() const { return status_ == 0; }
   int LastStatus() const { return status_; }

@@ -274,10 +274,14 @@ int main(int argc, char** argv) {
     ClusterSnapshot snap;
     snap.craned_metas = {node("cn0", 4, 16), node("cn1", 4, 16)};
     snap.partitions = {{"CPU", {"cn0", "cn1"}}};
-    snap.preempt_enabled = true;
+    snap.preempt_enabled = true;           // preemption together with a reservation: not served
+    ResvMeta rv; rv.name = "r0"; rv.start_time = 2000; rv.end_time = 3000;
+    rv.res_total["cn0"].cpu_set.cpu_count = cpu_t(1);
+    snap.reservations.push_back(rv);
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() == -4 /* CNS_ERR_UNSUPPORTED */ && algo.LastError().find("preemption") != std::string::npos);
     snap.preempt_enabled = false;
+    snap.reservations.clear();
     snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: id >= 128
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);
@@ -604,6 +608,50 @@ int main(int argc, char** argv) {
       CHECK(!algo.AppendResourceInNodeV3Wire(*pd[1], want0, &one));   // backfilled for later: nothing to dispatch
       CHECK(algo.AppendJobToDWire(*pd[0], 1000, "j", want0, &jtd) && jtd.size() > one.size());
     }
+  }
+  if (!no_gpu) {
+    // ---- preemption through the adapter (tests/kat_preempt.py, scenarios P1 and P3: derivations there) -------------------
+    GpuNodeSelectionAlgo algo(0);
+    ClusterSnapshot snap;
+    snap.craned_metas = {node("cn0", 2, 8)};
+    snap.partitions = {{"CPU", {"cn0"}}};
+    snap.preempt_enabled = true;
+    snap.qos_preempt = {{"high", {"low"}}, {"low", {}}};
+    algo.SetClusterSnapshot(snap);
+    CHECK(algo.Ok());
+    std::vector<std::unique_ptr<RnJobInScheduler>> rn;
+    auto r0 = std::make_unique<RnJobInScheduler>();
+    r0->job_id = 50; r0->partition_id = "CPU"; r0->qos = "low"; r0->qos_priority = 1; r0->start_time = 900; r0->end_time = 1500;
+    r0->allocated_res["cn0"].cpu_set.cpu_count = cpu_t(2);
+    r0->allocated_res["cn0"].cpu_set.core_ids = {0, 1};
+    r0->allocated_res["cn0"].memory_bytes = 2ull << 30;
+    rn.push_back(std::move(r0));
+    std::vector<std::unique_ptr<PdJobInScheduler>> pd;
+    pd.push_back(job(1, 2, 100));
+    pd[0]->qos = "high"; pd[0]->qos_priority = 10; pd[0]->priority = 1.0;
+    algo.NodeSelect(now, rn, pd);
+    CHECK(algo.Ok());
+    CHECK(pd[0]->is_scheduled() && pd[0]->start_time == now && pd[0]->craned_ids == std::vector<CranedId>{"cn0"});
+    CHECK(pd[0]->preempted_jobs.size() == 1 && std::holds_alternative<RnJobInScheduler*>(pd[0]->preempted_jobs[0]) &&
+          std::get<RnJobInScheduler*>(pd[0]->preempted_jobs[0]) == rn[0].get());
+    CHECK(algo.LastPreemptCancel() == std::vector<job_id_t>{50} && algo.PreemptingSet() == std::set<job_id_t>{50});
+    // the next cycle: job 50 still runs -> it ends at now + 1 (cpp:6553-6556) and is not cancelled a second time
+    pd.clear();
+    pd.push_back(job(2, 2, 100));
+    pd[0]->qos = "low"; pd[0]->qos_priority = 1;
+    algo.NodeSelect(now, rn, pd);
+    CHECK(algo.Ok() && pd[0]->start_time == now + 1 && pd[0]->preempted_jobs.empty() && algo.LastPreemptCancel().empty());
+    CHECK(algo.PreemptingSet() == std::set<job_id_t>{50});
+    // a pending job placed earlier in the same cycle is preempted: reason "Preempted"
+    rn.clear();
+    pd.clear();
+    pd.push_back(job(3, 2, 100)); pd[0]->qos = "low"; pd[0]->qos_priority = 1; pd[0]->priority = 5.0;
+    pd.push_back(job(4, 2, 50)); pd[1]->qos = "high"; pd[1]->qos_priority = 10; pd[1]->priority = 1.0;
+    algo.NodeSelect(now, rn, pd);
+    CHECK(algo.Ok() && pd[0]->reason == "Preempted" && pd[1]->is_scheduled() && pd[1]->start_time == now);
+    CHECK(pd[1]->preempted_jobs.size() == 1 && std::holds_alternative<PdJobInScheduler*>(pd[1]->preempted_jobs[0]) &&
+          std::get<PdJobInScheduler*>(pd[1]->preempted_jobs[0]) == pd[0].get());
+    CHECK(algo.PreemptingSet().empty());   // job 50 no longer runs: dropped from the set (cpp:6551-6553)
   }
   printf("%s\n", g_fail ? "FAIL" : "ok");
   return g_fail != 0;
