@@ -21,7 +21,7 @@ for n in ("p1","p2","p3"):
     agg = collections.defaultdict(float)
     for row in csv.DictReader(open(fs[0])):
         k = row.get("Kernel_Name","")
-        if "k_pipe" in k or "k_select" in k:
+        if "k_pipe" in k or "k_select" in k or "k_wide" in k:
             agg[(k[:40], row["Counter_Name"])] += float(row["Counter_Value"])
     for (k,c),v in sorted(agg.items()): print(n, k, c, v)
 PY
