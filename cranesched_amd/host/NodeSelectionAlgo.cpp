@@ -1019,6 +1019,13 @@ void GpuNodeSelectionAlgo::CheckAndMallocMetaResource(AccountMetaSnapshot& meta,
       if (u.class_count[c]) m.resource.gres_map[I.classes[c].first].specified[I.classes[c].second] = u.class_count[c];
     return m;
   };
+  // the admission changes resource, jobs_count and wall_time of an entry; submit_jobs_count (AccountMetaContainer.h:33) is
+  // submit-time bookkeeping and stays what the caller handed in
+  auto put_usage = [&](MetaResource& dst, const cns_usage& u) {
+    const uint32_t keep = dst.submit_jobs_count;
+    dst = from_usage(u);
+    dst.submit_jobs_count = keep;
+  };
 
   // ---- limits ----
   std::vector<cns_qos_limits> qos(Q);
@@ -1127,12 +1134,15 @@ void GpuNodeSelectionAlgo::CheckAndMallocMetaResource(AccountMetaSnapshot& meta,
     else if (ait == acct_ix.end()) err = "InvalidAccount";                            // :193-199,958-963
     else if (qit == qos_ix.end()) err = "InvalidQOS";                                 // :201-202
     else if (!meta.user_meta.count(p.username)) err = "UserMetaNotFound";            // :895-899
-    else if (!meta.qos_meta.count(p.qos)) err = "QosMetaNotFound";                    // :909-913
-    else if (xit == ua_ix.end()) err = "UserAccountMismatch";                         // :920-928
-    else if (pit == I.part_idx.end()) err = "Partition Not Found";
-    if (!err)
+    if (!err && uit != user_ix.end() && ait != acct_ix.end() && qit != qos_ix.end()) {
+      // CheckRunLimits_ looks things up in this order (AccountMetaContainer.cpp:895-928): user meta, every account of the
+      // chain, qos meta, then the user's account list — the first miss names the reason
       for (std::string a = p.account; !a.empty(); a = meta.account_parent.count(a) ? meta.account_parent.at(a) : std::string())
         if (!meta.account_meta.count(a)) { err = "AccountMetaNotFound"; break; }     // :901-907
+      if (!err && !meta.qos_meta.count(p.qos)) err = "QosMetaNotFound";               // :909-913
+      if (!err && xit == ua_ix.end()) err = "UserAccountMismatch";                    // :920-928
+      if (!err && pit == I.part_idx.end()) err = "Partition Not Found";
+    }
     if (err) { skip[i] = 1; results[i] = err; continue; }
     user[i] = uit->second; ua[i] = xit->second; acct[i] = ait->second; qosv[i] = qit->second; part[i] = pit->second;
   }
@@ -1151,19 +1161,19 @@ void GpuNodeSelectionAlgo::CheckAndMallocMetaResource(AccountMetaSnapshot& meta,
   if (st != 0) { status_ = st; error_ = cns_last_error(I.h); return; }
   for (const auto& [uname, uix] : user_ix) {
     for (const auto& [qname, qix] : qos_ix)
-      if (uqe[(size_t)uix * Q + qix]) meta.user_meta[uname].qos_to_resource_map[qname] = from_usage(uq[(size_t)uix * Q + qix]);
+      if (uqe[(size_t)uix * Q + qix]) put_usage(meta.user_meta[uname].qos_to_resource_map[qname], uq[(size_t)uix * Q + qix]);
   }
   for (const auto& [key, x] : ua_ix)
     for (uint32_t pp = 0; pp < Pn; ++pp)
-      if (upe[(size_t)x * Pn + pp]) meta.user_meta[key.first].account_to_partition_to_resource_map[key.second][part_name[pp]] = from_usage(up[(size_t)x * Pn + pp]);
+      if (upe[(size_t)x * Pn + pp]) put_usage(meta.user_meta[key.first].account_to_partition_to_resource_map[key.second][part_name[pp]], up[(size_t)x * Pn + pp]);
   for (const auto& [aname, aix] : acct_ix) {
     for (const auto& [qname, qix] : qos_ix)
-      if (aqe[(size_t)aix * Q + qix]) meta.account_meta[aname].qos_to_resource_map[qname] = from_usage(aq[(size_t)aix * Q + qix]);
+      if (aqe[(size_t)aix * Q + qix]) put_usage(meta.account_meta[aname].qos_to_resource_map[qname], aq[(size_t)aix * Q + qix]);
     for (uint32_t pp = 0; pp < Pn; ++pp)
-      if (ape[(size_t)aix * Pn + pp]) meta.account_meta[aname].partition_to_resource_map[part_name[pp]] = from_usage(ap[(size_t)aix * Pn + pp]);
+      if (ape[(size_t)aix * Pn + pp]) put_usage(meta.account_meta[aname].partition_to_resource_map[part_name[pp]], ap[(size_t)aix * Pn + pp]);
   }
   for (const auto& [qname, qix] : qos_ix)
-    if (meta.qos_meta.count(qname)) meta.qos_meta[qname] = from_usage(qu[qix]);
+    if (meta.qos_meta.count(qname)) put_usage(meta.qos_meta[qname], qu[qix]);
   status_ = 0;
   error_.clear();
 }

@@ -185,6 +185,7 @@ struct PartitionResourceLimit {  // AccountDefs.h:163-175
 struct MetaResource {  // AccountMetaContainer.h:30-35
   ResourceView resource;
   uint32_t jobs_count{0};
+  uint32_t submit_jobs_count{0};   // counted at submit time (h:33); the run-limit admission neither reads nor changes it
   int64_t wall_time{0};
 };
 struct MetaResourceStat {  // AccountMetaContainer.h:62-80
