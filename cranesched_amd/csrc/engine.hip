@@ -917,7 +917,8 @@ int cns_select(cns_handle* h, int64_t now, const cns_job_soa* jobs, cns_placemen
 // pipelined kernels exclude by construction (node state monotone within a cycle: caches, predicted tiles, decoupled
 // commits).  A cycle with preemption enabled therefore runs k_select with every job on its general path
 // (KParams::general_only) and the device form of TryPreempt_ / PreemptSegTree between the res_total selection and the
-// backfill (csrc/preempt_dev.inc).  Not combined yet with reservations or partitions that share nodes: refused.
+// backfill (csrc/preempt_dev.inc).  Reservations are served (their virtual nodes carry their own job lists, cpp:6705);
+// not combined yet with partitions that share nodes: refused.
 int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* pre,
                        cns_placement_soa* out, cns_preempt_out* pout) {
   if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null handle");
@@ -934,7 +935,7 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   }
   if (!jobs || !out || !pout) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null argument");
   if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_select_preempt before cns_set_nodes");
-  if (h->shared || h->V) return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: preemption together with reservations or partitions that share nodes is not implemented");
+  if (h->shared) return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: preemption together with partitions that share nodes is not implemented");
   const u64 J = jobs->num_jobs;
   const u32 R = h->R;
   if (J && (!pre->pd_qos || !pre->pd_qos_priority || !pre->pd_priority)) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: missing pending-job array");

@@ -274,14 +274,12 @@ int main(int argc, char** argv) {
     ClusterSnapshot snap;
     snap.craned_metas = {node("cn0", 4, 16), node("cn1", 4, 16)};
     snap.partitions = {{"CPU", {"cn0", "cn1"}}};
-    snap.preempt_enabled = true;           // preemption together with a reservation: not served
-    ResvMeta rv; rv.name = "r0"; rv.start_time = 2000; rv.end_time = 3000;
-    rv.res_total["cn0"].cpu_set.cpu_count = cpu_t(1);
-    snap.reservations.push_back(rv);
+    snap.preempt_enabled = true;           // preemption together with partitions that share a node: not served
+    snap.partitions.push_back({"ALL", {"cn0", "cn1"}});
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() == -4 /* CNS_ERR_UNSUPPORTED */ && algo.LastError().find("preemption") != std::string::npos);
     snap.preempt_enabled = false;
-    snap.reservations.clear();
+    snap.partitions.pop_back();
     snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: id >= 128
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);

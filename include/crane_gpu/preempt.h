@@ -16,7 +16,7 @@
  * How it runs: a cycle with `enabled` set goes through k_select with every job on its general path and the device form
  * of TryPreempt_ / PreemptSegTree between the res_total selection and the backfill (csrc/preempt_dev.inc; DESIGN.md
  * 5j); bit-exact against the CPU oracle's restatement (tests/test_preempt.py).  Limits, refused with
- * CNS_ERR_UNSUPPORTED: preemption together with reservations or with partitions that share nodes.  Candidates that
+ * CNS_ERR_UNSUPPORTED: preemption together with partitions that share nodes (reservations are served).  Candidates that
  * the reference's comparator leaves unordered (it sorts the iteration order of a hash set) are taken in ascending
  * index.  With `enabled == 0` the call is cns_select.
  */

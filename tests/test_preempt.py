@@ -164,10 +164,12 @@ def test_python_restatement_on_random_preempt_cases(built, seed):
 # ---------------------------------------------------------------------------------------------------------------------
 # The HIP engine (cns_select_preempt: k_select's general path + csrc/preempt_dev.inc) against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
-def run_engine_preempt(c, j, now, run, pre, **cfg):
+def run_engine_preempt(c, j, now, run, pre, resv=None, **cfg):
     from cranesched_amd.engine import GpuNodeSelector
     eng = GpuNodeSelector(device=0, **cfg)
     eng.set_nodes(c)
+    if resv is not None:
+        eng.set_reservations(resv)
     eng.set_running(run)
     pl, po = eng.node_select_preempt(now, j, pre)
     return eng, pl, po
@@ -239,5 +241,51 @@ def test_engine_preempt_disabled_is_the_plain_cycle(built):
     try:
         ref = pyoracle.select(c, j, now, running=run)
         assert pl.diff(ref.placements) is None and po.lists() == [[] for _ in range(j.num_jobs)]
+    finally:
+        eng.close()
+
+
+def resv_preempt_case(seed):
+    """Reservations (active / future / expired, jobs inside them, running jobs inside them) AND preemption."""
+    from tests.test_reservations import random_resv_case
+    c, j, now, run, rv = random_resv_case(seed, N=24, J=260, V=6)
+    rng = np.random.default_rng(seed * 104729 + 7)
+    R = len(run.end_sec)
+    rn_qos = rng.integers(0, 3, R)
+    pd_qos = rng.integers(0, 3, j.num_jobs)
+    qprio = np.array([10, 20, 30])
+    pre = abi.Preempt([[], [0], [1, 0]], np.arange(j.num_jobs) + 1, pd_qos, qprio[pd_qos], rng.permutation(j.num_jobs).astype(np.float64) + 0.5,
+                      1000 + np.arange(R), rn_qos, qprio[rn_qos], now - 1 - rng.permutation(R) * 7,
+                      preempting=[int(1000 + r) for r in range(R) if rng.random() < 0.1])
+    return c, j, now, run, rv, pre
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_oracle_preempt_with_reservations_lit_vs_mask(built, seed):
+    from oracle import pyoracle
+    c, j, now, run, rv, pre = resv_preempt_case(seed)
+    a = pyoracle.select(c, j, now, running=run, reservations=rv, preempt=pre, algebra=0)
+    b = pyoracle.select(c, j, now, running=run, reservations=rv, preempt=pre, algebra=1)
+    assert a.placements.diff(b.placements) is None and a.preempt_out.lists() == b.preempt_out.lists()
+    assert a.preempt_out.cancelled_ids() == b.preempt_out.cancelled_ids()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_engine_preempt_with_reservations(built, seed):
+    from oracle import pyoracle
+    c, j, now, run, rv, pre = resv_preempt_case(seed)
+    ref = pyoracle.select(c, j, now, running=run, reservations=rv, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre, resv=rv)
+    try:
+        d = pl.diff(ref.placements)
+        assert d is None, f"engine placements differ from the oracle: {d}"
+        assert po.lists() == ref.preempt_out.lists() and po.cancelled_ids() == ref.preempt_out.cancelled_ids()
+        assert po.preempting_ids() == ref.preempt_out.preempting_ids()
+        assert np.array_equal(eng.costs().view(np.uint64), ref.costs().view(np.uint64))
+        for n in range(c.num_nodes):
+            a, b = eng.timeline(n), ref.timeline(n)
+            for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+                assert np.array_equal(a[f], b[f]), f"time map of node {n}, field {f}"
     finally:
         eng.close()
