@@ -974,6 +974,28 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   bool patched = false;
   for (u32 r = 0; r < R; ++r) patched = patched || rj_pre[r];
   if (patched) { if (int rc = upload(h, h->d_rn_end, ent_end)) return rc; }
+  // No pending job's qos may preempt anything: TryPreempt_ returns at :6385 for every job, so the cycle is the plain one
+  // (with the preempting jobs ending at now + 1) and runs on the pipelined kernels.
+  bool any_list = false;
+  for (u64 j = 0; j < J && !any_list; ++j) {
+    const u32 q = pre->pd_qos[j];
+    any_list = q < pre->num_qos && pre->qos_preempt_offsets[q + 1] > pre->qos_preempt_offsets[q];
+  }
+  if (!any_list) {
+    int rc = cns_run_resident(h, now);
+    if (patched) { if (int rc2 = upload(h, h->d_rn_end, h->ent_end)) return rc2; HIPCHK(h, hipStreamSynchronize(h->stream)); }
+    if (rc) return rc;
+    if (int rc3 = cns_download(h, out)) return rc3;
+    for (u64 j = 0; j <= J; ++j) pout->offsets[j] = 0;
+    pout->num_cancelled = 0;
+    pout->num_preempting = 0;
+    std::set<u32> keep(set_in.begin(), set_in.end());
+    for (u32 id : keep) {
+      if (pout->num_preempting >= pout->preempting_capacity) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: preempting_capacity too small");
+      pout->preempting_job_ids[pout->num_preempting++] = id;
+    }
+    return CNS_OK;
+  }
   // qos preempt lists, pending-job fields (by queue index)
   std::vector<u32> qp_off(pre->num_qos + 1, 0), qp;
   for (u32 q = 0; q < pre->num_qos; ++q) {

@@ -198,7 +198,8 @@ def test_engine_preempt_known_answers(built, scn):
     eng, pl, po = run_engine_preempt(c, j, kat_preempt.NOW, r, pre)
     try:
         compare_engine(name, c, j, ref, eng, pl, po)
-        assert eng.last_kernel().startswith("k_select")
+        has_list = any(len(pre.qos_preempt[int(q)]) for q in pre.pd_qos)
+        assert eng.last_kernel().startswith("k_select") == has_list   # (no list anywhere: the plain cycle on the fast kernels)
     finally:
         eng.close()
 
@@ -287,5 +288,26 @@ def test_engine_preempt_with_reservations(built, seed):
             a, b = eng.timeline(n), ref.timeline(n)
             for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
                 assert np.array_equal(a[f], b[f]), f"time map of node {n}, field {f}"
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_engine_preempt_enabled_without_lists_runs_the_fast_kernels(built):
+    """PreemptType == QOS but no pending job's qos may preempt anything: TryPreempt_ returns at :6385 every time, the cycle
+    is the plain one except for the preempting set (jobs in it end at now + 1) — and it runs on k_wide / k_pipe."""
+    from oracle import pyoracle
+    c, j, now, run, pre = random_preempt_case(555, N=12, J=120, P=2, running=18)
+    pre = abi.Preempt([[], [], []], pre.pd_job_id, pre.pd_qos, pre.pd_qos_priority, pre.pd_priority, pre.rn_job_id, pre.rn_qos,
+                      pre.rn_qos_priority, pre.rn_start_sec, preempting=[1001, 1003, 4242])
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        compare_engine("no lists", c, j, ref, eng, pl, po)
+        assert not eng.last_kernel().startswith("k_select"), eng.last_kernel()
+        # ... and the patched end times do not leak into the next plain cycle
+        pl2 = eng.node_select(now, j)
+        ref2 = pyoracle.select(c, j, now, running=run)
+        assert pl2.diff(ref2.placements) is None
     finally:
         eng.close()
