@@ -935,7 +935,6 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   }
   if (!jobs || !out || !pout) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null argument");
   if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_select_preempt before cns_set_nodes");
-  if (h->shared) return fail(h, CNS_ERR_UNSUPPORTED, "cns_select_preempt: preemption together with partitions that share nodes is not implemented");
   const u64 J = jobs->num_jobs;
   const u32 R = h->R;
   if (J && (!pre->pd_qos || !pre->pd_qos_priority || !pre->pd_priority)) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: missing pending-job array");

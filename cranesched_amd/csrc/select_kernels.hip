@@ -855,8 +855,9 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
     if (P.pre.enabled) {   // UpdateNodeSelectorWithScheduledJob (h:636-642): the job joins its nodes' qos_job_map
       const u32 q = qbeg + slot_of_code_t<kS>(me.p);
       P.pre.rec_orig[o] = orig; P.pre.rec_slot[o] = q; P.pre.rec_gone[o] = 0;
-      P.pre.rec_next[o] = P.pre.slot_head[q];   // (the k nodes are distinct: no two lanes touch one list)
-      P.pre.slot_head[q] = (u32)o;
+      const u32 hq = P.slot_block ? P.slot_block[q] : q;   // the list is the NODE's (one NodeState per craned)
+      P.pre.rec_next[o] = P.pre.slot_head[hq];   // (the k nodes are distinct: no two lanes touch one list)
+      P.pre.slot_head[hq] = (u32)o;
     }
   }
   if (P.pre.enabled && lane == 0) { P.pre.pj_rec0[orig] = (u32)poff; P.pre.pj_k[orig] = J.k; P.pre.pj_end[orig] = end; }
@@ -1170,6 +1171,18 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
             s_upd[nup] = u;
           }
           ++nup;
+          if (P.sib_off)   // the released node's slots in the other partitions of the group (new length / front summary, own cost kept)
+            for (u32 a = P.sib_off[q]; a < P.sib_off[q + 1]; ++a) {
+              if (lane == 0) {
+                UpdRec us;
+                const u32 ps = P.sib[a] - qbeg;
+                us.p = ((ps / kS) << 10) | (ps % kS);
+                us.len = hd->len; us.cost = 0.0; us.fcpu = P.f_cpu[q]; us.fmem = P.f_mem[q]; us.fcnt = P.f_cnt[q];
+                us.has_front = 3u; us.pad = 0;
+                s_upd[nup] = us;
+              }
+              ++nup;
+            }
         }
         if (lane == 0) { *s_nupd = (int)nup; P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
         code = 2;

@@ -526,14 +526,6 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   I.preempt_enabled = snap.preempt_enabled;
   I.qos_id.clear(); I.qos_preempt.clear();
   if (snap.preempt_enabled) {
-    std::unordered_set<std::string> seen_nodes;
-    for (const auto& [pname, ids] : snap.partitions)
-      for (const auto& id : ids)
-        if (!seen_nodes.insert(id).second) {
-          status_ = CNS_ERR_UNSUPPORTED;
-          error_ = "preemption (PreemptType != NONE) together with partitions that share nodes is not implemented by the GPU engine; keep the CPU SchedulerAlgo";
-          return;
-        }
     for (const auto& [name, lst] : snap.qos_preempt) I.qos_of(name);
     for (const auto& [name, lst] : snap.qos_preempt) {
       std::vector<uint32_t> ids;

@@ -274,10 +274,10 @@ int main(int argc, char** argv) {
     ClusterSnapshot snap;
     snap.craned_metas = {node("cn0", 4, 16), node("cn1", 4, 16)};
     snap.partitions = {{"CPU", {"cn0", "cn1"}}};
-    snap.preempt_enabled = true;           // preemption together with partitions that share a node: not served
+    snap.preempt_enabled = true;           // preemption together with partitions that share a node is served
     snap.partitions.push_back({"ALL", {"cn0", "cn1"}});
     algo.SetClusterSnapshot(snap);
-    CHECK(algo.LastStatus() == -4 /* CNS_ERR_UNSUPPORTED */ && algo.LastError().find("preemption") != std::string::npos);
+    CHECK(algo.LastStatus() != -4 /* CNS_ERR_UNSUPPORTED */ && algo.LastError().find("preemption") == std::string::npos);
     snap.preempt_enabled = false;
     snap.partitions.pop_back();
     snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: id >= 128
@@ -650,6 +650,38 @@ int main(int argc, char** argv) {
     CHECK(pd[1]->preempted_jobs.size() == 1 && std::holds_alternative<PdJobInScheduler*>(pd[1]->preempted_jobs[0]) &&
           std::get<PdJobInScheduler*>(pd[1]->preempted_jobs[0]) == pd[0].get());
     CHECK(algo.PreemptingSet().empty());   // job 50 no longer runs: dropped from the set (cpp:6551-6553)
+  }
+  if (!no_gpu) {
+    // ---- preemption + partitions that share a node (tests/kat_preempt.py, scenario P6): the release lowers the cost of
+    // cn0 in SUB's selector only, so ALL still walks cn1 first ---------------------------------------------------------
+    GpuNodeSelectionAlgo algo(0);
+    ClusterSnapshot snap;
+    snap.craned_metas = {node("cn0", 2, 8), node("cn1", 2, 8)};
+    snap.partitions = {{"ALL", {"cn0", "cn1"}}, {"SUB", {"cn0"}}};
+    snap.preempt_enabled = true;
+    snap.qos_preempt = {{"high", {"low"}}, {"low", {}}};
+    algo.SetClusterSnapshot(snap);
+    CHECK(algo.Ok());
+    std::vector<std::unique_ptr<RnJobInScheduler>> rn;
+    for (int i = 0; i < 2; ++i) {
+      auto r = std::make_unique<RnJobInScheduler>();
+      const std::string cn = i ? "cn1" : "cn0";
+      r->job_id = 50 + i; r->partition_id = "ALL"; r->qos = "low"; r->qos_priority = 1; r->start_time = 900 + 50 * i; r->end_time = i ? 1300 : 1500;
+      r->allocated_res[cn].cpu_set.cpu_count = cpu_t(2);
+      r->allocated_res[cn].cpu_set.core_ids = {0, 1};
+      r->allocated_res[cn].memory_bytes = 2ull << 30;
+      rn.push_back(std::move(r));
+    }
+    std::vector<std::unique_ptr<PdJobInScheduler>> pd;
+    pd.push_back(job(1, 2, 100)); pd[0]->partition_id = "SUB"; pd[0]->qos = "high"; pd[0]->qos_priority = 10; pd[0]->priority = 1.0;
+    pd.push_back(job(2, 2, 100)); pd[1]->partition_id = "ALL"; pd[1]->qos = "low"; pd[1]->qos_priority = 1; pd[1]->priority = 1.0;
+    algo.NodeSelect(now, rn, pd);
+    CHECK(algo.Ok());
+    CHECK(pd[0]->is_scheduled() && pd[0]->start_time == now && pd[0]->craned_ids == std::vector<CranedId>{"cn0"});
+    CHECK(pd[0]->preempted_jobs.size() == 1 && std::holds_alternative<RnJobInScheduler*>(pd[0]->preempted_jobs[0]) &&
+          std::get<RnJobInScheduler*>(pd[0]->preempted_jobs[0]) == rn[0].get());
+    CHECK(pd[1]->start_time == 1300 && pd[1]->craned_ids == std::vector<CranedId>{"cn1"} && pd[1]->reason == "Resource");
+    CHECK(algo.LastPreemptCancel() == std::vector<job_id_t>{50} && algo.PreemptingSet() == std::set<job_id_t>{50});
   }
   printf("%s\n", g_fail ? "FAIL" : "ok");
   return g_fail != 0;

@@ -15,8 +15,8 @@
  *
  * How it runs: a cycle with `enabled` set goes through k_select with every job on its general path and the device form
  * of TryPreempt_ / PreemptSegTree between the res_total selection and the backfill (csrc/preempt_dev.inc; DESIGN.md
- * 5j); bit-exact against the CPU oracle's restatement (tests/test_preempt.py).  Limits, refused with
- * CNS_ERR_UNSUPPORTED: preemption together with partitions that share nodes (reservations are served).  Candidates that
+ * 5j); bit-exact against the CPU oracle's restatement (tests/test_preempt.py).  Partitions that share nodes
+ * and reservations are served together with it.  Candidates that
  * the reference's comparator leaves unordered (it sorts the iteration order of a hash set) are taken in ascending
  * index.  With `enabled == 0` the call is cns_select.
  */

@@ -105,4 +105,22 @@ def scenarios():
     out.append(("preempting_set_carried_over", c, j, r, preempt(Q, [(1, 0, 1, 1.0)], [(50, 0, 1, 900)], preempting=[50, 77]), {
         0: (2, 1001, [(0, 1, 512, 0x3, 0)]),
         "preempted": {0: []}, "cancelled": [], "preempting": [50], "costs": [101.0]}))
+
+    # P6. Partitions that share a node.  ALL = {cn0, cn1}, SUB = {cn0}; one NodeState per craned (cpp:6585-6615), one cost
+    #     per partition selector (h:498-516).  R0 (id 50) holds cn0 until 1500, R1 (id 51) holds cn1 until 1300, both
+    #     qos 0: costs ALL = (500, 300), SUB = (500).  P0 (SUB, qos 1, 2 cpus, L 100): candidates = cn0's qos_job_map[0] =
+    #     {R0} (entered by the prologue, :6688, whichever partition R0 ran in) -> preempted as in P1.  The release goes
+    #     through SUB's selector (h:577-587): cn0's shared map gets R0 back, SUB's cost of cn0 500 - 500 + 100 = 100,
+    #     ALL's cost of cn0 stays 500.  P1 (ALL, qos 0: no list) therefore still walks cn1 (300) before cn0 (500): the
+    #     res_total selection is cn1, Backfill_ starts it at 1300 ("Resource": cn1 had 0 cpus in res_avail) — had the
+    #     release lowered ALL's cost of cn0 as well, cn0 would come first and P1 would start at 1100.
+    c = kat.cluster([2, 2], [8, 8], parts=[[0, 1], [0]])
+    j = kat.jobs([dict(cpu=2, L=100, part=1), dict(cpu=2, L=100, part=0)])
+    r = running([dict(end=1500, allocs=[(0, 0x3, 2)]), dict(end=1300, allocs=[(1, 0x3, 2)])])
+    out.append(("shared_node_release_is_per_partition", c, j, r,
+                preempt(Q, [(1, 1, 10, 1.0), (2, 0, 1, 1.0)], [(50, 0, 1, 900), (51, 0, 1, 950)]), {
+        0: (0, NOW, [(0, 1, 512, 0x3, 0)]), 1: (2, 1300, [(1, 1, 512, 0x3, 0)]),
+        "preempted": {0: [(False, 0)], 1: []}, "cancelled": [50], "preempting": [50], "costs": [500.0, 400.0, 100.0],
+        "timeline": {0: [(NOW, 0, 0x0), (1100, 512, 0x3), (1500, 512, 0x3), (INF, 0, 0)],
+                     1: [(NOW, 0, 0x0), (1300, 0, 0x0), (1400, 512, 0x3), (INF, 0, 0)]}}))
     return out

@@ -183,7 +183,11 @@ def compare_engine(tag, c, j, ref, eng, pl, po):
     assert po.cancelled_ids() == rpo.cancelled_ids(), f"{tag}: cancelled {po.cancelled_ids()} vs {rpo.cancelled_ids()}"
     assert po.preempting_ids() == rpo.preempting_ids(), f"{tag}: preempting set"
     assert np.array_equal(eng.costs().view(np.uint64), ref.costs().view(np.uint64)), f"{tag}: fp64 costs differ"
+    in_part = np.zeros(c.num_nodes, bool)
+    in_part[np.asarray(c.part_nodes, np.int64)] = True
     for n in range(c.num_nodes):
+        if not in_part[n]:   # a node in no partition has no NodeState at all (JobScheduler.cpp:6584-6606)
+            continue
         a, b = eng.timeline(n), ref.timeline(n)
         for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
             assert np.array_equal(a[f], b[f]), f"{tag}: time map of node {n}, field {f}: {a[f]} vs {b[f]}"
@@ -309,5 +313,59 @@ def test_engine_preempt_enabled_without_lists_runs_the_fast_kernels(built):
         pl2 = eng.node_select(now, j)
         ref2 = pyoracle.select(c, j, now, running=run)
         assert pl2.diff(ref2.placements) is None
+    finally:
+        eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Preemption with partitions that share nodes: the candidate lists are the NODE's (one NodeState per craned,
+# JobScheduler.cpp:6585-6615), a release acts on the nodes of the preempting job's own partition only (h:577-587) and
+# lowers that partition's cost of the node alone (h:498-516)
+# ---------------------------------------------------------------------------------------------------------------------
+def overlap_preempt_case(seed, N=24, J=120, layout="all+subsets", nq=3):
+    from tests.test_overlap import overlap_case
+    c, j, now, run = overlap_case(seed, N=N, J=J, layout=layout)
+    rng = np.random.default_rng(seed * 7919 + 17)
+    R = len(run.end_sec)
+    rn_qos = rng.integers(0, nq, R)
+    pd_qos = rng.integers(0, nq, j.num_jobs)
+    qprio = np.array([10, 20, 30])
+    rn_start = now - 1 - rng.permutation(R) * 7
+    pd_prio = rng.permutation(j.num_jobs).astype(np.float64) + 0.5
+    preempting = [int(1000 + r) for r in range(R) if rng.random() < 0.15] + [4242]
+    pre = abi.Preempt([[], [0], [1, 0]][:nq], np.arange(j.num_jobs) + 1, pd_qos, qprio[pd_qos], pd_prio,
+                      1000 + np.arange(R), rn_qos, qprio[rn_qos], rn_start, preempting=preempting)
+    return c, j, now, run, pre
+
+
+OVERLAP_CASES = [(s, lay) for s in range(6) for lay in ("all+subsets", "chain", "random")]
+
+
+@pytest.mark.parametrize("seed,lay", OVERLAP_CASES)
+def test_python_restatement_on_preemption_with_shared_nodes(built, seed, lay):
+    from oracle import pyoracle
+    c, j, now, run, pre = overlap_preempt_case(seed, layout=lay)
+    cyc, out, lists = run_pyref_preempt(c, j, now, run, pre)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    compare_preempt(f"overlap preempt {seed} {lay}", c, j, ref, cyc, out, lists)
+    lit = pyoracle.select(c, j, now, running=run, preempt=pre, algebra=pyoracle.LITERAL)
+    assert ref.placements.diff(lit.placements) is None and ref.preempt_out.lists() == lit.preempt_out.lists()
+    if (seed, lay) == (0, "all+subsets"):
+        tot = sum(len(x) for s, l in OVERLAP_CASES
+                  for x in pyoracle.select(*overlap_preempt_case(s, layout=l)[:3], running=overlap_preempt_case(s, layout=l)[3],
+                                           preempt=overlap_preempt_case(s, layout=l)[4]).preempt_out.lists())
+        assert tot > 60, f"only {tot} preemptions over the shared-node cases"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,lay", OVERLAP_CASES + [(s, lay) for s in (20, 21) for lay in ("all+subsets", "chain", "random")])
+def test_engine_preempt_with_shared_nodes(built, seed, lay):
+    from oracle import pyoracle
+    big = seed >= 20
+    c, j, now, run, pre = overlap_preempt_case(seed, N=64 if big else 24, J=500 if big else 120, layout=lay)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        compare_engine(f"overlap preempt {seed} {lay}", c, j, ref, eng, pl, po)
     finally:
         eng.close()
