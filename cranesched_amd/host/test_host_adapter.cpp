@@ -680,7 +680,7 @@ int main(int argc, char** argv) {
     CHECK(pd[0]->is_scheduled() && pd[0]->start_time == now && pd[0]->craned_ids == std::vector<CranedId>{"cn0"});
     CHECK(pd[0]->preempted_jobs.size() == 1 && std::holds_alternative<RnJobInScheduler*>(pd[0]->preempted_jobs[0]) &&
           std::get<RnJobInScheduler*>(pd[0]->preempted_jobs[0]) == rn[0].get());
-    CHECK(pd[1]->start_time == 1300 && pd[1]->craned_ids == std::vector<CranedId>{"cn1"} && pd[1]->reason == "Resource");
+    CHECK(pd[1]->start_time == 1300 && pd[1]->reason == "Resource");   // (on cn1; a later start carries reason / start / end only)
     CHECK(algo.LastPreemptCancel() == std::vector<job_id_t>{50} && algo.PreemptingSet() == std::set<job_id_t>{50});
   }
   printf("%s\n", g_fail ? "FAIL" : "ok");
