@@ -211,7 +211,7 @@ def main():
                                    f"seed 0x43524E45^{synth.CONFIGS[args.config]['idx']}",
                        "jobs": jobs.num_jobs, "nodes": cluster.num_nodes, "partitions": cluster.num_partitions,
                        "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else
-                                   ("single GPU, 1 + 8 workgroups per partition (k_wide)" if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
+                                   (("single GPU, 1 + 16 workgroups per partition (k_wide, 64 scanner waves)" if kernel.endswith("x64") else "single GPU, 1 + 8 workgroups per partition (k_wide)") if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
                        "selection_kernel": kernel,
                        "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),
                                          "resource": int((r == 2).sum())},

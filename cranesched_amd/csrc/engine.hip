@@ -235,13 +235,16 @@ template <int NPL>
 void launch_pipe(cns_engine* h, const KParams& K) {
   hipLaunchKernelGGL((k_pipe<NPL>), dim3(h->P), dim3(kPBlock), 0, h->stream, K, h->d_params.as<KParams>());
 }
-// k_wide: 1 + 8 workgroups per partition; the workgroups of a partition share blockIdx % 8 (= the XCD, observed).  A pad of
-// dynamic LDS keeps it at one workgroup per CU (one scanner wave per SIMD is the point of the kernel).
-template <int NPL>
-int launch_wide(cns_engine* h, const KParams& K) {
+// k_wide: 1 + 8 (or 1 + 16) workgroups per partition; the workgroups of a partition share blockIdx % 8 (= the XCD, observed).
+// A pad of dynamic LDS keeps it at one workgroup per CU (one scanner wave per SIMD is the point of the kernel).
+template <class W>
+int launch_wide(cns_engine* h, const KParams& K, u32 np, std::string* name) {
+  const char* kname = "";
+  const void* fn = W::pick(np, &kname);
+  if (!fn) return 2;
   const unsigned groups = (h->P + 7u) / 8u;
-  const unsigned grid = 8u * groups * (unsigned)kWGroup;
-  const size_t need = (size_t)h->P * sizeof(WideCtl);
+  const unsigned grid = 8u * groups * W::group;
+  const size_t need = (size_t)h->P * W::ctl_bytes;
   if (h->d_wide.ensure(need) != hipSuccess) return 1;
   if (hipMemsetAsync(h->d_wide.p, 0, need, h->stream) != hipSuccess) return 1;
   KParams K2 = K;
@@ -249,11 +252,14 @@ int launch_wide(cns_engine* h, const KParams& K) {
   if (hipMemcpyAsync(&h->d_params.as<KParams>()->wide_ctl, &K2.wide_ctl, sizeof(char*), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
   size_t dyn = 0;
   hipFuncAttributes fa;
-  if (hipFuncGetAttributes(&fa, (const void*)k_wide<NPL>) == hipSuccess && fa.sharedSizeBytes < 84u * 1024u) {
+  if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes < 84u * 1024u) {
     dyn = 84u * 1024u - fa.sharedSizeBytes;
-    if (hipFuncSetAttribute((const void*)k_wide<NPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { dyn = 0; (void)hipGetLastError(); }
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { dyn = 0; (void)hipGetLastError(); }
   }
-  hipLaunchKernelGGL((k_wide<NPL>), dim3(grid), dim3(kWBlock), dyn, h->stream, K2, h->d_params.as<KParams>());
+  const KParams* dparams = h->d_params.as<KParams>();
+  void* args[2] = {(void*)&K2, (void*)&dparams};
+  if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, h->stream) != hipSuccess) return 1;
+  *name = std::string(kname) + (W::waves == 64 ? " x64" : " x32");   // (x64: cns::w64::k_wide in a profile, x32: cns::w32::k_wide)
   return 0;
 }
 // Which selection kernel runs: k_pipe (decoupled test / commit pipeline) for partitions its tile covers, k_select
@@ -264,19 +270,25 @@ int launch_wide(cns_engine* h, const KParams& K) {
 #ifndef CNS_DEFAULT_WIDE
 #define CNS_DEFAULT_WIDE 1
 #endif
-// k_wide (many CUs per partition) when every workgroup of the launch can be resident at once and the partitions fit its tile
-bool use_wide_kernel(const cns_engine* h) {
+// k_wide (many CUs per partition) when every workgroup of the launch can be resident at once and the partitions fit its tile:
+// 64 scanner waves per partition (17 workgroups) for up to 8 partitions, 32 (9 workgroups) for up to 24.  Returns 0 / 32 / 64.
+// CNS_SELECT_KERNEL=wide32 forces the 32-wave build (A/B measurements, and the parity tests run both).
+u32 use_wide_kernel(const cns_engine* h) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_WIDE != 0;
   if (e && (!strcmp(e, "legacy") || !strcmp(e, "pipe"))) want = false;
-  if (e && !strcmp(e, "wide")) want = true;
-  return want && !h->shared && h->P <= kWMaxParts && h->max_np <= kWLanes * (u32)kWNplMax;
+  const bool only32 = e && !strcmp(e, "wide32");
+  if (e && (!strcmp(e, "wide") || only32)) want = true;
+  if (!want || h->shared) return 0;
+  if (!only32 && h->P <= w64::WideInfo::max_parts && h->max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max) return 64;
+  if (h->P <= w32::WideInfo::max_parts && h->max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max) return 32;
+  return 0;
 }
 bool use_pipe_kernel(const cns_engine* h) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_PIPE != 0;
   if (e && !strcmp(e, "legacy")) want = false;
-  if (e && (!strcmp(e, "pipe") || !strcmp(e, "wide"))) want = true;
+  if (e && (!strcmp(e, "pipe") || !strcmp(e, "wide") || !strcmp(e, "wide32"))) want = true;
   return want && !h->shared && h->max_np <= kPScan * (u32)kPNplMax;   // (shared nodes: k_select's sequential protocol)
 }
 
@@ -355,7 +367,7 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   HIPCHK(h, h->d_bfj.ensure(S1 * sizeof(u32)));
   HIPCHK(h, h->d_gupd.ensure(S1 * sizeof(UpdRec)));
   HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
-  HIPCHK(h, h->d_prof.ensure((size_t)(h->P + 8) * (size_t)kWGroup * 32 * sizeof(u64)));   // (k_wide: blocks > partitions)
+  HIPCHK(h, h->d_prof.ensure((size_t)(h->P + 8) * (size_t)w64::WideInfo::group * 32 * sizeof(u64)));   // (k_wide: blocks > partitions)
   // no running jobs until cns_set_running
   std::vector<u32> rn_off(S + 1, 0);
   if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
@@ -838,10 +850,10 @@ int cns_run_resident(cns_handle* h, int64_t now) {
     launch_select<CNS_ONLY_NPL>(h, K);
 #else
     bool launched = false;
-    if (!h->pre_active && use_wide_kernel(h)) {
-#define CNS_TRY_WWIDTH(w) if (!launched && np <= kWLanes * (w)) { if (launch_wide<w>(h, K)) return fail(h, CNS_ERR_HIP, "k_wide: control block allocation / upload failed"); launched = true; h->last_kernel = "k_wide<" #w ">"; }
-      CNS_WNPL_LIST(CNS_TRY_WWIDTH)
-#undef CNS_TRY_WWIDTH
+    if (const u32 ww = h->pre_active ? 0u : use_wide_kernel(h)) {
+      const int rc = ww == 64 ? launch_wide<w64::WideInfo>(h, K, np, &h->last_kernel) : launch_wide<w32::WideInfo>(h, K, np, &h->last_kernel);
+      if (rc == 1) return fail(h, CNS_ERR_HIP, "k_wide: control block allocation / upload / launch failed");
+      launched = rc == 0;
     }
     if (!launched && !h->pre_active && use_pipe_kernel(h)) {
 #define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; h->last_kernel = "k_pipe<" #w ">"; }

@@ -2443,7 +2443,24 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 }
 
 #include "pipe_kernel.inc"
+// k_wide in two builds: 8 scanner workgroups (32 scanner waves, up to 24 partitions) and 16 (64 waves, up to 8 partitions)
+#ifndef CNS_WIDE_WGS
+#define CNS_WIDE_WGS_BOTH
+#define CNS_WIDE_WGS 8
+#endif
+namespace w32 {
 #include "wide_kernel.inc"
+}
+#ifdef CNS_WIDE_WGS_BOTH
+#undef CNS_WIDE_WGS
+#define CNS_WIDE_WGS 16
+namespace w64 {
+#include "wide_kernel.inc"
+}
+#undef CNS_WIDE_WGS
+#else
+namespace w64 = w32;   // experiment builds with one explicit shape
+#endif
 
 #ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
 template __global__ void k_select<CNS_ONLY_NPL>(const KParams, const KParams*);

@@ -38,10 +38,10 @@ def test_scaled_configs(engine_cls, name, J, N, P):
     assert (r == 1).sum() > 0, "scenario must exercise backfill"
 
 
-@pytest.mark.parametrize("P", [9, 20, 24, 25])
+@pytest.mark.parametrize("P", [8, 9, 20, 24, 25])
 def test_many_partitions(engine_cls, P):
-    """k_wide lays 9 workgroups per partition out over the XCDs in groups of 8 partitions and serves at most 24 of them
-    (beyond that the launch falls back to k_pipe): the edges of that layout, against the oracle."""
+    """k_wide lays 17 (up to 8 partitions) or 9 (up to 24) workgroups per partition out over the XCDs in groups of 8 partitions
+    (beyond 24 the launch falls back to k_pipe): the edges of that layout, against the oracle."""
     c, j, now = synth.make_config("C4", J=24000, N=128 * P, P=P)
     got, t = _run(engine_cls, c, j, now, tag=f"C4 with {P} partitions")
     assert (got.reason[:j.num_jobs] == 1).sum() > 0, "scenario must exercise backfill"
