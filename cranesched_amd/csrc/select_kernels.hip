@@ -145,6 +145,8 @@ __device__ __forceinline__ u64 wave_and_u64(u64 v) {
 __device__ __forceinline__ u64 wave_or_u64(u64 v) { return ~wave_and_u64(~v); }
 // lexicographic argmin of (cost key, code) over the wave: three cascaded 32-bit minima
 __device__ __forceinline__ void wave_argmin(u64& c, u32& p) {
+  // (measured: leaving the cascade as soon as one lane is left — ballot, popcount, branch — costs more than the 6 or 12
+  // DPP steps it saves: C4 337 vs 328 ms)
   const u32 hi = (u32)(c >> 32), lo = (u32)c;
   const u32 mh = wave_umin32(hi);
   const bool e1 = hi == mh;
