@@ -22,10 +22,12 @@ print(f"{name} J={j.num_jobs} N={c.num_nodes} P={c.num_partitions} {e.last_kerne
       f"{1e3*t['select_ms']/jobs:.2f} us/job/partition; supervisor loop {m[28]/jobs:.0f} cycles/job "
       f"(=> {m[28]/max(t['select_ms'],1e-9)/1e3:.0f} MHz counter)")
 rows = {19: "leader scanner: whole job", 16: "leader:   (fetch + decode +) row loop", 17: "leader:   lap guard (waiting for the supervisor)",
-        18: "leader:   argmins + publish + exchange wait", 21: "leader: stopped (command wait + reload)",
+        18: "leader:   argmins + publish + exchange wait", 10: "leader:     own argmins + payload", 11: "leader:     publish + own-row arithmetic + next record",
+        12: "leader:     exchange wait (polls)", 14: "leader:   decision (argmin over the granules), node_num 1", 21: "leader: stopped (command wait + reload)",
         22: "supervisor: records -> task (incl. slot wait)", 23: "supervisor:   waiting for a free task slot", 26: "supervisor: stop handling"}
 for k, v in rows.items():
     print(f"  {v:50s} {m[k]/jobs:10.0f} cyc/job")
+print(f"  leader polls {m[13]:.0f} ({m[13]/max(m[20],1):.2f} per job)")
 print(f"  leader jobs {m[20]:.0f}; supervisor: consumed {m[24]:.0f}, empty polls {m[27]:.0f}, stops {m[25]:.0f}, flushes {m[29]:.0f}")
 if m[9]:
     print(f"  tester 0: {m[9]:.0f} tasks tested, {m[8]/m[9]:.0f} cyc/test (incl. dependency waits); 7 testers => {m[8]/m[9]/7:.0f} cyc/job of test capacity used")
