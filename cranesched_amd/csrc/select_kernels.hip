@@ -1605,9 +1605,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   const u32 part = blockIdx.x;
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 wave = uni32(tid >> 6);  // wave-uniform: the role split below is a scalar branch
-  const u32 qbeg = P.part_off[part];
-  const u32 nn = P.part_off[part + 1] - qbeg;
-  const u64 jbeg = P.pj_off[part], jend = P.pj_off[part + 1];
+  // (flat loads are sources of divergence for the compiler: make what steers the control flow uniform)
+  const u32 qbeg = uni32(P.part_off[part]);
+  const u32 nn = uni32(P.part_off[part + 1]) - qbeg;
+  const u64 jbeg = uni64(P.pj_off[part]), jend = uni64(P.pj_off[part + 1]);
   if (jbeg >= jend) return;
   // a reservation's scheduler exists only while the reservation is active (JobScheduler.cpp:6643,6754-6759)
   const bool resv_part = part >= P.num_real_parts;
