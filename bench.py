@@ -7,8 +7,8 @@ src/CraneCtld/JobScheduler.cpp:6507-6836, bracket :1439-1447) over the synthetic
 with the job table and node snapshot already resident in HBM when the timed region starts.
 At N > 1 the queue is job-sharded by partition (rank r owns partitions p % N == r; partitions that share nodes
 stay together) and each step ends with one RCCL all-gather of the packed placement buffers; total work is fixed
-("strong").  A partition is ONE sequential chain; k_wide spreads its per-job node scan over 8 more workgroups of the SAME
-XCD (exchange through that XCD's L2, ~0.4 us per job), so 8 partitions occupy 72 of 256 CUs and run concurrently on one
+("strong").  A partition is ONE sequential chain; k_wide spreads its per-job node scan over 16 more workgroups of the SAME
+XCD (exchange through that XCD's L2, ~0.4 us per job), so 8 partitions occupy 136 of 256 CUs and run concurrently on one
 GPU: more GPUs do not add chains and the curve is flat by construction (an exchange over xGMI would cost more per job
 than the whole chain does now).
 
