@@ -156,6 +156,30 @@ __device__ __forceinline__ void wave_argmin(u64& c, u32& p) {
   c = ((u64)mh << 32) | ml;
   p = mp;
 }
+// two independent argmins in one pass: the DPP steps of the two cascades alternate, so that each hides the other's wait states
+// (a lone wave per SIMD has nothing else to issue)
+__device__ __forceinline__ void wave_umin32x2(u32& a, u32& b) {
+  CNS_DPP_STEP32(op_umin, a, 0xFFFFFFFFu, 0x111, 0xF); CNS_DPP_STEP32(op_umin, b, 0xFFFFFFFFu, 0x111, 0xF);
+  CNS_DPP_STEP32(op_umin, a, 0xFFFFFFFFu, 0x112, 0xF); CNS_DPP_STEP32(op_umin, b, 0xFFFFFFFFu, 0x112, 0xF);
+  CNS_DPP_STEP32(op_umin, a, 0xFFFFFFFFu, 0x114, 0xF); CNS_DPP_STEP32(op_umin, b, 0xFFFFFFFFu, 0x114, 0xF);
+  CNS_DPP_STEP32(op_umin, a, 0xFFFFFFFFu, 0x118, 0xF); CNS_DPP_STEP32(op_umin, b, 0xFFFFFFFFu, 0x118, 0xF);
+  CNS_DPP_STEP32(op_umin, a, 0xFFFFFFFFu, 0x142, 0xA); CNS_DPP_STEP32(op_umin, b, 0xFFFFFFFFu, 0x142, 0xA);
+  CNS_DPP_STEP32(op_umin, a, 0xFFFFFFFFu, 0x143, 0xC); CNS_DPP_STEP32(op_umin, b, 0xFFFFFFFFu, 0x143, 0xC);
+  a = rl32(a, 63); b = rl32(b, 63);
+}
+__device__ __forceinline__ void wave_argmin2(u64& c1, u32& p1, u64& c2, u32& p2) {
+  const u32 h1 = (u32)(c1 >> 32), l1 = (u32)c1, h2 = (u32)(c2 >> 32), l2 = (u32)c2;
+  u32 mh1 = h1, mh2 = h2;
+  wave_umin32x2(mh1, mh2);
+  const bool e1 = h1 == mh1, f1 = h2 == mh2;
+  u32 ml1 = e1 ? l1 : 0xFFFFFFFFu, ml2 = f1 ? l2 : 0xFFFFFFFFu;
+  wave_umin32x2(ml1, ml2);
+  const bool e2 = e1 & (l1 == ml1), f2 = f1 & (l2 == ml2);
+  u32 mp1 = e2 ? p1 : 0xFFFFFFFFu, mp2 = f2 ? p2 : 0xFFFFFFFFu;
+  wave_umin32x2(mp1, mp2);
+  c1 = ((u64)mh1 << 32) | ml1; p1 = mp1;
+  c2 = ((u64)mh2 << 32) | ml2; p2 = mp2;
+}
 // the same over 16 per-wave slots replicated in every row
 __device__ __forceinline__ void reduce16(u64& c, u32& p) {
   const u32 hi = (u32)(c >> 32), lo = (u32)c;
