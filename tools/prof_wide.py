@@ -27,6 +27,9 @@ rows = {19: "leader scanner: whole job", 16: "leader:   (fetch + decode +) row l
         22: "supervisor: records -> task (incl. slot wait)", 23: "supervisor:   waiting for a free task slot", 26: "supervisor: stop handling"}
 for k, v in rows.items():
     print(f"  {v:50s} {m[k]/jobs:10.0f} cyc/job")
+if m[0]:
+    print(f"  leader, node_num > 1: {m[0]:.0f} jobs; per such job: lists {m[1]/m[0]:.0f}, exchange wait {m[2]/m[0]:.0f}, vote {m[3]/m[0]:.0f} cycles; "
+          f"{m[4]:.0f} second exchanges at {m[5]/max(m[4],1):.0f} cycles; {m[7]/max(m[0]+m[4],1):.2f} polls per list exchange")
 print(f"  leader polls {m[13]:.0f} ({m[13]/max(m[20],1):.2f} per job)")
 print(f"  leader jobs {m[20]:.0f}; supervisor: consumed {m[24]:.0f}, empty polls {m[27]:.0f}, stops {m[25]:.0f}, flushes {m[29]:.0f}")
 if m[9]:
