@@ -70,6 +70,7 @@ struct cns_engine {
   // partition (workgroup) that runs their jobs in queue order; a node then has one slot per member partition.
   u32 Pu = 0;                                 // partitions of the caller
   bool shared = false;                        // some node belongs to several partitions
+  u32 num_cus = 0;                            // compute units of the device (0: unknown); k_wide needs one per workgroup, all resident at once
   std::vector<u32> upart_eng, upart_size;     // caller's partition -> engine partition, its schedulable node count
   std::vector<uint8_t> upart_tag;             // ... and its member tag inside that engine partition
   std::vector<std::vector<u32>> node_slots;   // node -> all its slots
@@ -280,8 +281,11 @@ u32 use_wide_kernel(const cns_engine* h) {
   const bool only32 = e && !strcmp(e, "wide32");
   if (e && (!strcmp(e, "wide") || only32)) want = true;
   if (!want || h->shared) return 0;
-  if (!only32 && h->P <= w64::WideInfo::max_parts && h->max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max) return 64;
-  if (h->P <= w32::WideInfo::max_parts && h->max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max) return 32;
+  // every workgroup of the launch must be resident at once, one per CU (a partitioned or smaller device falls to k_pipe)
+  const u32 groups = (h->P + 7u) / 8u;
+  auto fits = [&](u32 wgs_per_part) { return h->num_cus == 0 || 8u * groups * wgs_per_part <= h->num_cus; };
+  if (!only32 && h->P <= w64::WideInfo::max_parts && h->max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max && fits(w64::WideInfo::group)) return 64;
+  if (h->P <= w32::WideInfo::max_parts && h->max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max && fits(w32::WideInfo::group)) return 32;
   return 0;
 }
 bool use_pipe_kernel(const cns_engine* h) {
@@ -408,6 +412,11 @@ int cns_create(const cns_config* cfg, cns_handle** out) {
     std::string m = hipGetErrorString(e);
     delete h;
     return fail(nullptr, CNS_ERR_HIP, "device/stream init: " + m);
+  }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->num_cus = (u32)cus;
+    else (void)hipGetLastError();
   }
   for (auto& ev : h->ev)
     if ((e = hipEventCreate(&ev)) != hipSuccess) {
