@@ -32,5 +32,7 @@ if m[0]:
           f"{m[4]:.0f} second exchanges at {m[5]/max(m[4],1):.0f} cycles; {m[7]/max(m[0]+m[4],1):.2f} polls per list exchange")
 print(f"  leader polls {m[13]:.0f} ({m[13]/max(m[20],1):.2f} per job)")
 print(f"  leader jobs {m[20]:.0f}; supervisor: consumed {m[24]:.0f}, empty polls {m[27]:.0f}, stops {m[25]:.0f}, flushes {m[29]:.0f}")
+if m[15]:
+    print(f"  tester 0: {m[15]:.0f} retirements with progress at {m[6]/m[15]:.0f} cycles (incl. commits); {m[31]:.0f} idle naps")
 if m[9]:
     print(f"  tester 0: {m[9]:.0f} tasks tested, {m[8]/m[9]:.0f} cyc/test (incl. dependency waits); 7 testers => {m[8]/m[9]/7:.0f} cyc/job of test capacity used")
