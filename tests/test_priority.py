@@ -149,3 +149,47 @@ def test_gpu_priority_full_size(engine_cls):
     pd, rn, now = synth_priority_case(J, R, A, seed=9)
     t = _gpu_vs_oracle(engine_cls, PriorityConfig(), A, pd, rn, now)
     assert t["kernels_ms"] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The oracle against the independent Python restatement (tests/prio_pyref.py, written from the reference alone)
+# ---------------------------------------------------------------------------------------------------------------------
+def _pyref_run(now, cfg, pd, rn):
+    from tests import prio_pyref as pr
+    pend = [dict(submit=int(pd.submit_sec[i]), qos=int(pd.qos_priority[i]), part=int(pd.partition_priority[i]),
+                 nodes=int(pd.node_num[i]), cpu_raw=int(pd.total_cpu_raw[i]), mem=int(pd.total_mem[i]), account=int(pd.account[i]),
+                 cached=0.0 if pd.cached_priority is None else float(pd.cached_priority[i])) for i in range(pd.num_jobs)]
+    run = [] if rn is None else [
+        dict(start=int(rn.start_sec[i]), qos=int(rn.qos_priority[i]), part=int(rn.partition_priority[i]), nodes=int(rn.node_num[i]),
+             cpu_raw=int(rn.alloc_cpu_raw[i]), mem=int(rn.alloc_mem[i]), account=int(rn.account[i])) for i in range(rn.num_jobs)]
+    c = dict(max_age=cfg.max_age_sec, w_age=cfg.weight_age, w_fair=cfg.weight_fair_share, w_size=cfg.weight_job_size,
+             w_part=cfg.weight_partition, w_qos=cfg.weight_qos, favor_small=cfg.favor_small)
+    return pr.ordered(now, c, pend, run)
+
+
+def test_python_restatement_on_the_hand_derived_case():
+    cfg, pd, rn = _kat()
+    order, prio = _pyref_run(NOW, cfg, pd, rn)
+    assert np.array(prio).view(np.uint64).tolist() == _expected_kat().view(np.uint64).tolist()
+    assert order == [2, 0, 1]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_python_restatement_agrees_with_the_oracle(seed):
+    rng = np.random.default_rng(seed)
+    J, R, A = int(rng.integers(1, 400)), int(rng.integers(0, 120)), int(rng.integers(1, 12))
+    pd, rn, now = synth_priority_case(J, R, A, seed=seed, cached_frac=0.15 if seed % 3 == 0 else 0.0)
+    if seed % 5 == 0:       # degenerate bounds: one value per attribute
+        pd.node_num[:] = 2; pd.total_mem[:] = 4 * GIB
+        if R:
+            rn.node_num[:] = 2; rn.alloc_mem[:] = 4 * GIB
+    if seed % 7 == 0:       # a job "submitted in the future": the unsigned age wraps and is capped at MaxAge (:7664-7665)
+        pd.submit_sec[0] = now + 50
+    cfg = PriorityConfig(max_age_sec=int(rng.integers(100, 100000)), weight_age=int(rng.integers(0, 2000)),
+                         weight_fair_share=int(rng.integers(0, 2000)), weight_job_size=int(rng.integers(0, 2000)),
+                         weight_partition=int(rng.integers(0, 2000)), weight_qos=int(rng.integers(0, 2000)),
+                         favor_small=bool(seed % 2))
+    order, prio = pyoracle.priority_order(now, cfg, A, pd, rn if R else None)
+    o2, p2 = _pyref_run(now, cfg, pd, rn if R else None)
+    assert np.array(p2).view(np.uint64).tolist() == prio.view(np.uint64).tolist()
+    assert o2 == order.tolist()
