@@ -211,3 +211,73 @@ def test_gpu_argument_checks(engine_cls):
         assert list(got.scheduled[:3]) == [1, 0, 0]
     finally:
         eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The oracle against the independent Python restatement (tests/steps_pyref.py, written from the reference alone)
+# ---------------------------------------------------------------------------------------------------------------------
+def _pyref_steps(lay, jobs, steps):
+    from tests import select_pyref as pr, steps_pyref
+    from tests.test_select_pyref import _res, _mask
+    types_of = lambda name: [g for g in range(len(lay.class_name)) if lay.class_name[g] == name]
+
+    def view(cpu, mem, gt, gs, s):
+        gtot = {} if gt is None else {a: int(v) for a, v in enumerate(gt[s]) if v}
+        gspec = {} if gs is None else {(lay.class_name[g], g): int(v) for g, v in enumerate(gs[s]) if v}
+        return pr.Req(int(cpu[s]), int(mem[s]), gtot, gspec)
+
+    rows = []   # per step: None or (places, tasks) with masks
+    avail_out = [None] * jobs.num_nodes
+    for j in range(jobs.num_jobs):
+        lo, hi = int(jobs.node_offsets[j]), int(jobs.node_offsets[j + 1])
+        nodes = [int(x) for x in jobs.node_idx[lo:hi]]
+        avail = [_res(lay, jobs.avail_cpu_raw[p], jobs.avail_mem[p], jobs.avail_core_lo[p], jobs.avail_core_hi[p], jobs.avail_gres[p])
+                 for p in range(lo, hi)]
+        sts = []
+        for s in range(int(jobs.step_offsets[j]), int(jobs.step_offsets[j + 1])):
+            incl = set() if steps.incl_offsets is None else set(int(x) for x in steps.incl_nodes[int(steps.incl_offsets[s]):int(steps.incl_offsets[s + 1])])
+            excl = set() if steps.excl_offsets is None else set(int(x) for x in steps.excl_nodes[int(steps.excl_offsets[s]):int(steps.excl_offsets[s + 1])])
+            sts.append(dict(node_view=view(steps.node_cpu_raw, steps.node_mem, steps.node_gres_total, steps.node_gres_spec, s),
+                            task_view=view(steps.task_cpu_raw, steps.task_mem, steps.task_gres_total, steps.task_gres_spec, s),
+                            k=int(steps.node_num[s]), ntasks=int(steps.ntasks[s]), tmin=int(steps.tmin[s]), tmax=int(steps.tmax[s]),
+                            incl=incl, excl=excl))
+        rows += steps_pyref.schedule_pending_steps(nodes, avail, sts, types_of)
+        for p in range(lo, hi):
+            avail_out[p] = avail[p - lo]
+    return rows, avail_out, _mask
+
+
+def _compare_steps(lay, jobs, steps, ref):
+    rows, avail, _mask = _pyref_steps(lay, jobs, steps)
+    for s, row in enumerate(rows):
+        assert bool(ref.scheduled[s]) == (row is not None), f"step {s}: scheduled {ref.scheduled[s]} (oracle)"
+        if row is None:
+            continue
+        places, tasks = row
+        o, t = int(ref.place_offsets[s]), int(ref.task_offsets[s])
+        got = [(int(ref.node_idx[o + i]), int(ref.node_ntasks[o + i]), int(ref.node_cpu_raw[o + i]), int(ref.node_mem[o + i]),
+                int(ref.node_core_lo[o + i]), int(ref.node_core_hi[o + i]), int(ref.node_gres[o + i])) for i in range(len(places))]
+        want = [(n, k, a.cpu, a.mem) + _mask(lay, a) for n, k, a in places]
+        assert got == want, f"step {s}: nodes {got} (oracle) vs {want} (python)"
+        got = [(int(ref.task_node[t + i]), int(ref.task_cpu_raw[t + i]), int(ref.task_mem[t + i]), int(ref.task_core_lo[t + i]),
+                int(ref.task_core_hi[t + i]), int(ref.task_gres[t + i])) for i in range(len(tasks))]
+        want = [(n, a.cpu, a.mem) + _mask(lay, a) for n, a in tasks]
+        assert got == want, f"step {s}: tasks {got} (oracle) vs {want} (python)"
+    for p, a in enumerate(avail):
+        got = (int(ref.avail_cpu_raw[p]), int(ref.avail_mem[p]), int(ref.avail_core_lo[p]), int(ref.avail_core_hi[p]), int(ref.avail_gres[p]))
+        assert got == (a.cpu, a.mem) + _mask(lay, a), f"node row {p}: step_res_avail_ {got} (oracle)"
+    return sum(r is not None for r in rows), len(rows), sum(len(r[1]) for r in rows if r is not None)
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_python_restatement_on_the_hand_derived_scenarios(name):
+    jobs, steps, exp = SCENARIOS[name]()
+    lay = abi.GresLayout()
+    _compare_steps(lay, jobs, steps, pyoracle.schedule_steps(lay, jobs, steps))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_python_restatement_agrees_with_the_oracle(seed):
+    lay, jobs, steps = random_step_case(10 + seed, J=120)
+    done, total, tasks = _compare_steps(lay, jobs, steps, pyoracle.schedule_steps(lay, jobs, steps))
+    assert 20 < done < total and tasks > 2 * done, (done, total, tasks)   # the cases schedule, refuse, and place several tasks per step
