@@ -175,18 +175,29 @@ class Node:
         self.idx, self.total = idx, total
         self.avail0 = total.copy()
         self.allocated = []   # (end, Res) in arrival order
+        self.reserved = []    # (start, end, Res): future reservations on the node
         self.tmap = []        # sorted [[t, Res]]
 
-    def init_map(self, now, end=INF):   # InitTimeAvailResMap, JobScheduler.h:301-338 (no future reservations in this restatement)
+    def init_map(self, now, end=INF):   # InitTimeAvailResMap, JobScheduler.h:301-338
+        # resource_changes: (time, allocate?, res); reserved_res first (- at its start, + at its end), then allocated_res
+        # (+ at its end, and out of res_avail); sorted by time, "release before allocate" at equal times (h:317-322; the sort
+        # is not stable in the reference — equal (time, flag) entries commute: all additions or all subtractions)
         changes = []
+        for st, en, r in getattr(self, "reserved", []):
+            changes.append((st, True, r))
+            changes.append((en, False, r))
         for e, r in self.allocated:
-            changes.append(e)
+            changes.append((e, False, r))
             res_sub(self.avail0, r)
+        changes.sort(key=lambda x: (x[0], x[1]))
         self.tmap = [[now, self.avail0.copy()]]
-        for e, r in sorted(self.allocated, key=lambda x: x[0]):   # stable: equal end times accumulate on one entry
-            if e != self.tmap[-1][0]:
-                self.tmap.append([e, self.tmap[-1][1].copy()])
-            res_add(self.tmap[-1][1], r)
+        for t, alloc, r in changes:
+            if t != self.tmap[-1][0]:
+                self.tmap.append([t, self.tmap[-1][1].copy()])
+            if alloc:
+                res_sub(self.tmap[-1][1], r)
+            else:
+                res_add(self.tmap[-1][1], r)
         if self.tmap[-1][0] == end:
             self.tmap[-1][1] = Res()
         else:
@@ -250,6 +261,8 @@ class Cycle:
             c = {}
             for i in p:
                 nd, v = self.nodes[i], 0.0
+                for st, en, r in nd.reserved:                       # reserved_res first, over [start, end) (h:502-506)
+                    v += float(en - st) * ((float(r.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
                 for e, r in nd.allocated:
                     v += float(e - self.now) * ((float(r.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
                 c[i] = v
@@ -391,6 +404,82 @@ class Cycle:
             if any(not res_le(alloc, self.nodes[i].avail0) for i, _, alloc in picks):
                 reason = 2
         return reason, start, sorted(picks, key=lambda x: x[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reservations inside NodeSelect (JobScheduler.cpp:6619-6679 prologue, :6692-6707 running jobs inside a reservation,
+# :6715-6719 time maps up to the reservation's end, :6729-6732 one scheduler per reservation, :6754-6760 dispatch,
+# :6797-6830 reasons).  Written from those lines; shares nothing with oracle/sched_oracle.hpp.  Canonicalisation: the
+# reservations (an unordered map in the reference) are taken in ascending index.
+# ---------------------------------------------------------------------------------------------------------------------
+REASON_RESV_NOT_FOUND = 6
+REASON_RESOURCE_RESERVED = 3
+
+
+class ResvCycle(Cycle):
+    def __init__(self, *a, reservations=(), pending_resv=(), **kw):
+        """reservations: dicts start, end, allocs = [(node, Res)]; pending_resv: reservation ids named by pending jobs."""
+        super().__init__(*a, **kw)
+        self.first_resv = {}          # craned_id_first_resv_map
+        self.resv_sched = {}          # reservation id -> {node: Node} (active AND named by a pending job, :6652-6668)
+        self.resv_end = {}
+        pend = set(pending_resv)
+        for v, rv in enumerate(reservations):
+            if self.now >= rv["end"]:                                   # expired but not cleaned up (:6631-6634)
+                continue
+            for node, _ in rv["allocs"]:                                # :6635-6642
+                self.first_resv[node] = min(self.first_resv.get(node, INF), rv["start"])
+            if self.now >= rv["start"]:                                 # active: its share is allocated until its end (:6643-6651)
+                for node, res in rv["allocs"]:
+                    if node in self.nodes:
+                        self.nodes[node].allocated.append((rv["end"], res))
+                if v not in pend:
+                    continue                                            # no pending jobs, skip (:6652-6655)
+                self.resv_end[v] = rv["end"]
+                self.resv_sched[v] = {node: Node(node, res.copy()) for node, res in rv["allocs"]}
+            else:                                                       # future: a dip in the node's map (:6669-6678)
+                for node, res in rv["allocs"]:
+                    if node in self.nodes:
+                        self.nodes[node].reserved.append((rv["start"], rv["end"], res))
+
+    def add_running(self, end, allocs, resv=None):                      # :6681-6709
+        if resv is None:
+            return super().add_running(end, allocs)
+        if resv not in self.resv_sched:
+            return                                                      # "not found in resv_node_state_map": ignored
+        end = max(end, self.now + 1)
+        for node, res in allocs:
+            if node in self.resv_sched[resv]:
+                self.resv_sched[resv][node].allocated.append((end, res))
+
+    def start(self):
+        super().start()
+        self.resv_cost = {}
+        for v, nodes in self.resv_sched.items():                        # :6715-6719, :6729-6732
+            c = {}
+            for i, nd in nodes.items():
+                nd.init_map(self.now, self.resv_end[v])
+                val = 0.0
+                for e, r in nd.allocated:
+                    val += float(e - self.now) * ((float(r.cpu) / 256.0) / (float(nd.total.cpu) / 256.0))
+                c[i] = val
+            self.resv_cost[v] = c
+
+    def run_job(self, job):
+        v = job.get("resv")
+        if v is None:
+            reason, start, picks = super().run_job(job)
+            if reason in (1, 2) and any(self.first_resv.get(i, INF) < self.now + job["L"] for i, _, _ in picks):
+                reason = REASON_RESOURCE_RESERVED                       # :6798-6806 comes before the res_avail test
+            return reason, start, picks
+        if v not in self.resv_sched:
+            return REASON_RESV_NOT_FOUND, 0, []                         # :6754-6759
+        saved = (self.nodes, self.parts, self.cost)
+        try:
+            self.nodes, self.parts, self.cost = self.resv_sched[v], [sorted(self.resv_sched[v])], [self.resv_cost[v]]
+            return Cycle.run_job(self, dict(job, part=0))               # reasons against the reservation's own res_avail (:6818-6829)
+        finally:
+            self.nodes, self.parts, self.cost = saved
 
 
 # ---------------------------------------------------------------------------------------------------------------------

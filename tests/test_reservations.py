@@ -264,3 +264,100 @@ def test_oracle_core_id_shortfall():
 def test_gpu_core_id_shortfall(engine_cls):
     c, j, rn, rv = core_id_shortfall_case()
     _gpu_run(engine_cls, c, j, NOW, rn, rv)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The oracle against the independent Python restatement (tests/select_pyref.py: ResvCycle, written from the reference alone)
+# ---------------------------------------------------------------------------------------------------------------------
+def run_pyref_resv(c, j, now, run, rv):
+    from tests import select_pyref as pr
+    from tests.test_select_pyref import _res
+    lay = c.gres
+    N = c.num_nodes
+    chi = c.core_hi if c.core_hi is not None else np.zeros(N, np.uint64)
+    gs = c.gres_slots if c.gres_slots is not None else np.zeros(N, np.uint64)
+    totals = [_res(lay, c.cpu_total_raw[n], c.mem_total[n], c.core_lo[n], chi[n], gs[n]) for n in range(N)]
+    parts = [list(map(int, c.part_nodes[c.part_offsets[p]:c.part_offsets[p + 1]])) for p in range(c.num_partitions)]
+    types_of = lambda name: [g for g in range(len(lay.class_name)) if lay.class_name[g] == name]
+    V = len(rv.start_sec)
+    resvs = [dict(start=int(rv.start_sec[v]), end=int(rv.end_sec[v]),
+                  allocs=[(int(rv.alloc_node[a]), _res(lay, rv.alloc_cpu_raw[a], rv.alloc_mem[a], rv.alloc_core_lo[a], rv.alloc_core_hi[a], rv.alloc_gres[a]))
+                          for a in range(int(rv.alloc_offsets[v]), int(rv.alloc_offsets[v + 1]))]) for v in range(V)]
+    jresv = j.reservation if getattr(j, "reservation", None) is not None else np.full(j.num_jobs, abi.RESV_NONE, np.uint32)
+    pend = {int(x) for x in jresv if x != abi.RESV_NONE}             # resv_pd_job_ptr_map (:6524-6530): every pending job counts
+    cyc = pr.ResvCycle(now, totals, parts, schedulable=None if c.schedulable is None else list(c.schedulable), types_of=types_of,
+                       reservations=resvs, pending_resv=pend)
+    if run is not None:
+        ahi = run.alloc_core_hi if run.alloc_core_hi is not None else np.zeros(len(run.alloc_node), np.uint64)
+        ag = run.alloc_gres if run.alloc_gres is not None else np.zeros(len(run.alloc_node), np.uint64)
+        rres = run.reservation if getattr(run, "reservation", None) is not None else [abi.RESV_NONE] * len(run.end_sec)
+        for r in range(len(run.end_sec)):
+            al = [(int(run.alloc_node[a]), _res(lay, run.alloc_cpu_raw[a], run.alloc_mem[a], run.alloc_core_lo[a], ahi[a], ag[a]))
+                  for a in range(int(run.alloc_offsets[r]), int(run.alloc_offsets[r + 1]))]
+            cyc.add_running(int(run.end_sec[r]), al, resv=None if rres[r] == abi.RESV_NONE else int(rres[r]))
+    cyc.start()
+    out = []
+    for i in range(j.num_jobs):
+        if j.skip is not None and j.skip[i]:
+            out.append((abi.REASON_SKIPPED, 0, []))
+            continue
+        v = None if jresv[i] == abi.RESV_NONE else int(jresv[i])
+        if v is None and j.partition[i] >= c.num_partitions:
+            out.append((abi.REASON_PARTITION_NOT_FOUND, 0, []))
+            continue
+        gtot = {a: int(x) for a, x in enumerate(j.gres_total[i]) if x} if j.gres_total is not None else {}
+        gspec = {(lay.class_name[g], g): int(x) for g, x in enumerate(j.gres_spec[i]) if x} if j.gres_spec is not None else {}
+        node_view = pr.Req(int(j.node_cpu_raw[i]) if j.node_cpu_raw is not None else 0, int(j.node_mem[i]), gtot, gspec)
+        incl = set(map(int, j.incl_nodes[int(j.incl_offsets[i]):int(j.incl_offsets[i + 1])])) if j.incl_offsets is not None else set()
+        excl = set(map(int, j.excl_nodes[int(j.excl_offsets[i]):int(j.excl_offsets[i + 1])])) if j.excl_offsets is not None else set()
+        job = dict(part=int(j.partition[i]), L=int(j.time_limit_sec[i]), k=int(j.node_num[i]), ntasks=int(j.ntasks[i]),
+                   tmin=int(j.ntasks_per_node_min[i]), tmax=int(j.ntasks_per_node_max[i]), tcpu=int(j.task_cpu_raw[i]),
+                   tmem=int(j.task_mem[i]), node_view=node_view, exclusive=bool(j.exclusive[i]) if j.exclusive is not None else False,
+                   incl=incl, excl=excl, resv=v)
+        job["min_view"] = pr.compose(node_view, job["tcpu"], job["tmem"], job["tmin"])
+        out.append(cyc.run_job(job))
+    return cyc, out
+
+
+def _compare_pyref_resv(tag, c, j, ref, cyc, out):
+    from tests.test_select_pyref import _mask
+    lay = c.gres
+    pl = ref.placements if hasattr(ref, "placements") else ref
+    for i, (reason, start, picks) in enumerate(out):
+        assert int(pl.reason[i]) == reason, f"{tag}: job {i} reason {pl.reason[i]} (oracle) vs {reason} (python)"
+        assert int(pl.start_sec[i]) == start, f"{tag}: job {i} start {pl.start_sec[i]} vs {start}"
+        o = int(pl.place_offsets[i])
+        got = [(int(pl.node_idx[o + x]), int(pl.ntasks[o + x]), int(pl.cpu_raw[o + x]), int(pl.mem[o + x]), int(pl.core_lo[o + x]),
+                int(pl.core_hi[o + x]), int(pl.gres[o + x])) for x in range(int(j.node_num[i])) if pl.node_idx[o + x] != abi.NODE_NONE]
+        want = [(n, t, a.cpu, a.mem) + _mask(lay, a) for n, t, a in picks]
+        assert got == want, f"{tag}: job {i} placements {got} (oracle) vs {want} (python)"
+    if hasattr(ref, "timeline"):          # the real nodes' final time maps
+        for n, nd in cyc.nodes.items():
+            m = ref.timeline(n)
+            got = [(int(t), int(cpu), int(lo)) for t, cpu, lo in zip(m["t"], m["cpu_raw"], m["core_lo"])]
+            want = [(t if t != pr_inf() else int(np.iinfo(np.int64).max), r.cpu, _mask(lay, r)[0]) for t, r in nd.tmap]
+            assert got == want, f"{tag}: time map of node {n}: {got} (oracle) vs {want} (python)"
+
+
+def pr_inf():
+    from tests import select_pyref as pr
+    return pr.INF
+
+
+@pytest.mark.parametrize("name", sorted(SCENARIOS))
+def test_python_restatement_on_the_hand_derived_reservation_scenarios(name):
+    c, j, rn, rv, exp = SCENARIOS[name]()
+    ref = pyoracle.select(c, j, NOW, running=rn, reservations=rv)
+    cyc, out = run_pyref_resv(c, j, NOW, rn, rv)
+    _compare_pyref_resv(name, c, j, ref, cyc, out)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_python_restatement_agrees_with_the_oracle_on_reservations(seed):
+    c, j, now, run, rv = random_resv_case(seed, N=24 + 4 * seed, J=150)
+    ref = pyoracle.select(c, j, now, running=run, reservations=rv)
+    cyc, out = run_pyref_resv(c, j, now, run, rv)
+    _compare_pyref_resv(f"resv {seed}", c, j, ref, cyc, out)
+    reasons = [o[0] for o in out]
+    if seed == 0:
+        assert reasons.count(abi.REASON_RESV_NOT_FOUND if hasattr(abi, "REASON_RESV_NOT_FOUND") else 6) > 0 and reasons.count(3) + reasons.count(1) > 0
