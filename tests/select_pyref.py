@@ -553,8 +553,10 @@ class SegTree:
         return self.root["sat"]
 
 
-class PreemptCycle(Cycle):
-    """Cycle + preemption.  Jobs are referred to as ("pd", index) / ("rn", index)."""
+class PreemptCycle(ResvCycle):
+    """Cycle (with reservations) + preemption.  Jobs are referred to as ("pd", index) / ("rn", index).  Every scheduler —
+    a partition's or a reservation's — sees the qos_job_map of ITS NodeStates: `node_jobs` for the real nodes,
+    `resv_node_jobs[v]` for the reservation's own (JobScheduler.cpp:6688 / :6705)."""
 
     def __init__(self, *a, qos_preempt=(), preempting=(), **kw):
         super().__init__(*a, **kw)
@@ -564,10 +566,11 @@ class PreemptCycle(Cycle):
         self.rn = []                            # dicts: id, qos, qprio, start, end, allocs {node: Res}
         self.pd = {}                            # index -> dict: qos, qprio, prio, start, end, allocs, reason, nodes
         self.node_jobs = {}                     # node -> {qos: set(ref)}     (NodeState::qos_job_map)
+        self.resv_node_jobs = {}                # reservation -> the same for its own NodeStates
 
-    def add_running_job(self, job_id, qos, qprio, start, end, allocs):
+    def add_running_job(self, job_id, qos, qprio, start, end, allocs, resv=None):
         end = max(end, self.now + 1)                                             # :6513-6514
-        self.rn.append(dict(id=job_id, qos=qos, qprio=qprio, start=start, end=end, allocs=allocs))
+        self.rn.append(dict(id=job_id, qos=qos, qprio=qprio, start=start, end=end, allocs=allocs, resv=resv))
 
     def start(self):
         ids = {r["id"] for r in self.rn}
@@ -577,14 +580,19 @@ class PreemptCycle(Cycle):
                 r["end"] = self.now + 1
         for x, r in enumerate(self.rn):                                          # :6681-6690
             merged = {}
+            v = r.get("resv")
             for node, res in r["allocs"]:
                 if node in merged:
                     res_add(merged[node], res)
                 else:
                     merged[node] = res.copy()
-                if node in self.nodes:
-                    self.nodes[node].allocated.append((r["end"], res))
-                    self.node_jobs.setdefault(node, {}).setdefault(r["qos"], set()).add(("rn", x))
+                if v is None:
+                    if node in self.nodes:
+                        self.nodes[node].allocated.append((r["end"], res))
+                        self.node_jobs.setdefault(node, {}).setdefault(r["qos"], set()).add(("rn", x))
+                elif v in self.resv_sched and node in self.resv_sched[v]:           # :6692-6707
+                    self.resv_sched[v][node].allocated.append((r["end"], res))
+                    self.resv_node_jobs.setdefault(v, {}).setdefault(node, {}).setdefault(r["qos"], set()).add(("rn", x))
             r["allocs"] = merged
         super().start()
 
@@ -648,7 +656,27 @@ class PreemptCycle(Cycle):
         return chosen
 
     def run_job_p(self, idx, job, jinfo):
-        """-> (reason, start, picks ascending node, preempted refs)."""
+        """-> (reason, start, picks ascending node, preempted refs).  A job inside a reservation runs on that reservation's
+        scheduler (its nodes, costs and job lists), or gets "Reservation Not Found"."""
+        v = job.get("resv")
+        if v is None:
+            reason, start, picks, pre = self._run_job_p(idx, job, jinfo)
+            if reason in (1, 2) and any(self.first_resv.get(i, INF) < self.now + job["L"] for i, _, _ in picks):
+                reason = REASON_RESOURCE_RESERVED                                 # :6798-6806 (before the res_avail test)
+                self.pd[idx]["reason"] = reason
+            return reason, start, picks, pre
+        if v not in self.resv_sched:
+            self.pd[idx] = dict(qos=jinfo["qos"], qprio=jinfo["qprio"], prio=jinfo["prio"], start=0, end=0, allocs={}, reason=REASON_RESV_NOT_FOUND, nodes=[])
+            return REASON_RESV_NOT_FOUND, 0, [], []
+        saved = (self.nodes, self.parts, self.cost, self.node_jobs)
+        try:
+            self.nodes, self.parts, self.cost = self.resv_sched[v], [sorted(self.resv_sched[v])], [self.resv_cost[v]]
+            self.node_jobs = self.resv_node_jobs.setdefault(v, {})
+            return self._run_job_p(idx, dict(job, part=0), jinfo)
+        finally:
+            self.nodes, self.parts, self.cost, self.node_jobs = saved
+
+    def _run_job_p(self, idx, job, jinfo):
         self.pd[idx] = dict(qos=jinfo["qos"], qprio=jinfo["qprio"], prio=jinfo["prio"], start=0, end=0, allocs={}, reason=None, nodes=[])
         r = self.try_schedule(job)
         if r is None:

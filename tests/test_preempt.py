@@ -56,7 +56,7 @@ def test_disabled_preemption_is_the_plain_cycle(built):
 # ---------------------------------------------------------------------------------------------------------------------
 # The C++ oracle against the independent Python restatement (tests/select_pyref.py: PreemptCycle, SegTree)
 # ---------------------------------------------------------------------------------------------------------------------
-def run_pyref_preempt(c, j, now, run, pre, max_job_num_per_node=0, max_time_window_sec=0):
+def run_pyref_preempt(c, j, now, run, pre, max_job_num_per_node=0, max_time_window_sec=0, rv=None):
     from tests import select_pyref as pr
     from tests.test_select_pyref import _res
     lay = c.gres
@@ -66,24 +66,36 @@ def run_pyref_preempt(c, j, now, run, pre, max_job_num_per_node=0, max_time_wind
     totals = [_res(lay, c.cpu_total_raw[n], c.mem_total[n], c.core_lo[n], chi[n], gs[n]) for n in range(N)]
     parts = [list(map(int, c.part_nodes[c.part_offsets[p]:c.part_offsets[p + 1]])) for p in range(c.num_partitions)]
     types_of = lambda name: [g for g in range(len(lay.class_name)) if lay.class_name[g] == name]
+    resvs, pend = [], set()
+    jresv = j.reservation if getattr(j, "reservation", None) is not None else None
+    if rv is not None:
+        resvs = [dict(start=int(rv.start_sec[v]), end=int(rv.end_sec[v]),
+                      allocs=[(int(rv.alloc_node[a]), _res(lay, rv.alloc_cpu_raw[a], rv.alloc_mem[a], rv.alloc_core_lo[a], rv.alloc_core_hi[a], rv.alloc_gres[a]))
+                              for a in range(int(rv.alloc_offsets[v]), int(rv.alloc_offsets[v + 1]))]) for v in range(len(rv.start_sec))]
+        pend = {int(x) for x in jresv if x != abi.RESV_NONE} if jresv is not None else set()
     cyc = pr.PreemptCycle(now, totals, parts, schedulable=None if c.schedulable is None else list(c.schedulable), types_of=types_of,
                           max_jobs_per_node=max_job_num_per_node or pr.MAX_JOBS_PER_NODE, max_window=max_time_window_sec or pr.MAX_WINDOW,
-                          qos_preempt=pre.qos_preempt if pre.enabled else [], preempting=[int(x) for x in pre.preempting])
+                          qos_preempt=pre.qos_preempt if pre.enabled else [], preempting=[int(x) for x in pre.preempting],
+                          reservations=resvs, pending_resv=pend)
     if run is not None:
         ahi = run.alloc_core_hi if run.alloc_core_hi is not None else np.zeros(len(run.alloc_node), np.uint64)
         ag = run.alloc_gres if run.alloc_gres is not None else np.zeros(len(run.alloc_node), np.uint64)
         for r in range(len(run.end_sec)):
             al = [(int(run.alloc_node[a]), _res(lay, run.alloc_cpu_raw[a], run.alloc_mem[a], run.alloc_core_lo[a], ahi[a], ag[a]))
                   for a in range(int(run.alloc_offsets[r]), int(run.alloc_offsets[r + 1]))]
+            rres = None
+            if getattr(run, "reservation", None) is not None and run.reservation[r] != abi.RESV_NONE:
+                rres = int(run.reservation[r])
             cyc.add_running_job(int(pre.rn_job_id[r]), int(pre.rn_qos[r]), int(pre.rn_qos_priority[r]), int(pre.rn_start_sec[r]),
-                                int(run.end_sec[r]), al)
+                                int(run.end_sec[r]), al, resv=rres)
     cyc.start()
     out, lists = [], []
     for i in range(j.num_jobs):
         if j.skip is not None and j.skip[i]:
             out.append([abi.REASON_SKIPPED, 0, []]); lists.append([])
             continue
-        if j.partition[i] >= c.num_partitions:
+        jv = None if jresv is None or jresv[i] == abi.RESV_NONE else int(jresv[i])
+        if jv is None and j.partition[i] >= c.num_partitions:
             out.append([abi.REASON_PARTITION_NOT_FOUND, 0, []]); lists.append([])
             continue
         gtot = {a: int(v) for a, v in enumerate(j.gres_total[i]) if v} if j.gres_total is not None else {}
@@ -95,6 +107,7 @@ def run_pyref_preempt(c, j, now, run, pre, max_job_num_per_node=0, max_time_wind
                    incl=set(map(int, j.incl_nodes[int(j.incl_offsets[i]):int(j.incl_offsets[i + 1])])) if j.incl_offsets is not None else set(),
                    excl=set(map(int, j.excl_nodes[int(j.excl_offsets[i]):int(j.excl_offsets[i + 1])])) if j.excl_offsets is not None else set())
         job["min_view"] = pr.compose(node_view, job["tcpu"], job["tmem"], job["tmin"])
+        job["resv"] = jv
         jinfo = dict(qos=int(pre.pd_qos[i]), qprio=int(pre.pd_qos_priority[i]), prio=float(pre.pd_priority[i]))
         reason, start, picks, refs = cyc.run_job_p(i, job, jinfo)
         out.append([reason, start, picks])
@@ -369,3 +382,13 @@ def test_engine_preempt_with_shared_nodes(built, seed, lay):
         compare_engine(f"overlap preempt {seed} {lay}", c, j, ref, eng, pl, po)
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_python_restatement_on_preemption_with_reservations(built, seed):
+    """Reservations (their own schedulers, job lists and dips) AND preemption in the second restatement."""
+    from oracle import pyoracle
+    c, j, now, run, rv, pre = resv_preempt_case(seed)
+    ref = pyoracle.select(c, j, now, running=run, reservations=rv, preempt=pre)
+    cyc, out, lists = run_pyref_preempt(c, j, now, run, pre, rv=rv)
+    compare_preempt(f"resv preempt {seed}", c, j, ref, cyc, out, lists)
