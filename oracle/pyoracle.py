@@ -47,14 +47,66 @@ def build(force: bool = False) -> str:
     return path
 
 
-def lib():
+def lib(backend: str = "oracle"):
+    """`oracle`: the restatement (liboracle.so).  `ref` / `ref_hash`: the REFERENCE's own sliced sources behind the
+    same entry points (oracle/_ref/libcrane_ref*.so, oracle/ref_build/); see ref_available()."""
     global _LIB
+    if backend != "oracle":
+        return ref_lib(backend)
     if _LIB is None:
         _LIB = C.CDLL(build())
         _LIB.ora_seconds.restype = C.c_double
         _LIB.ora_jobs_ordered.restype = C.c_uint64
         _LIB.ora_free.restype = None
     return _LIB
+
+
+_REF_LIBS: dict = {}
+_REF_FILES = {"ref": "libcrane_ref.so", "ref_hash": "libcrane_ref_hash.so"}
+REFERENCE_ROOT = "/root/reference"
+
+
+def build_ref(force: bool = False) -> bool:
+    """Build oracle/_ref/*.so from the reference's own sources (needs /root/reference).  Returns availability."""
+    paths = [os.path.join(_HERE, "_ref", f) for f in _REF_FILES.values()]
+    if os.path.isdir(REFERENCE_ROOT):
+        srcs = [os.path.join(_HERE, "ref_build", f) for f in
+                ("extract.py", "ref_harness.cpp", "shim/absl_shim.h", "shim/crane_shim.h", "shim/crane_shim_ctld.h", "shim/fpm/fixed.hpp")]
+        stale = force or any(not os.path.exists(p) for p in paths) or any(
+            os.path.getmtime(s) > min(os.path.getmtime(p) for p in paths) for s in srcs)
+        if stale:
+            subprocess.run(["make", "-C", _HERE, "-B", "_ref"], check=True, capture_output=True)
+    return all(os.path.exists(p) for p in paths)
+
+
+def ref_available() -> bool:
+    """True when the build of the reference's sliced sources is there (built here from /root/reference, or shipped
+    prebuilt to a box without the reference)."""
+    try:
+        return build_ref()
+    except subprocess.CalledProcessError:
+        return False
+
+
+def ref_lib(backend: str = "ref"):
+    if backend not in _REF_LIBS:
+        if not build_ref():
+            raise RuntimeError("oracle/_ref is not built and /root/reference is not present")
+        L = C.CDLL(os.path.join(_HERE, "_ref", _REF_FILES[backend]))
+        L.ora_seconds.restype = C.c_double
+        L.ora_jobs_ordered.restype = C.c_uint64
+        L.ora_free.restype = None
+        L.ref_last_error.restype = C.c_char_p
+        _REF_LIBS[backend] = L
+    return _REF_LIBS[backend]
+
+
+class RefAsserted(RuntimeError):
+    """A CRANE_ASSERT / ABSL_ASSERT of the reference's own code failed on this input."""
+
+
+class RefUnsupported(RuntimeError):
+    """The call asks for a constant the reference fixes at compile time (kAlgoMaxJobNumPerNode, kAlgoMaxTimeWindow)."""
 
 
 def make_req(cpu=0, mem=0, gtot=(), gspec=()) -> OraReq:
@@ -71,38 +123,38 @@ def make_res(cpu=0, mem=0, clo=0, chi=0, gres=0) -> OraRes:
     return OraRes(cpu, mem, clo, chi, gres)
 
 
-def feasible(layout: abi.GresLayout, algebra: int, req: OraReq, avail: OraRes):
+def feasible(layout: abi.GresLayout, algebra: int, req: OraReq, avail: OraRes, backend: str = "oracle"):
     out = OraRes()
     gl = layout.to_c()
-    ok = lib().ora_feasible(C.byref(gl), algebra, C.byref(req), C.byref(avail), C.byref(out))
+    ok = lib(backend).ora_feasible(C.byref(gl), algebra, C.byref(req), C.byref(avail), C.byref(out))
     return (bool(ok), out.tup() if ok else None)
 
 
-def binop(layout: abi.GresLayout, algebra: int, op: str, a: OraRes, b: OraRes):
+def binop(layout: abi.GresLayout, algebra: int, op: str, a: OraRes, b: OraRes, backend: str = "oracle"):
     code = {"ckmin": 0, "add": 1, "sub": 2, "le": 3}[op]
     out = OraRes()
     gl = layout.to_c()
-    ret = lib().ora_binop(C.byref(gl), algebra, code, C.byref(a), C.byref(b), C.byref(out))
+    ret = lib(backend).ora_binop(C.byref(gl), algebra, code, C.byref(a), C.byref(b), C.byref(out))
     return bool(ret) if op == "le" else out.tup()
 
 
 class OracleRun:
     """Result of one oracle cycle; keeps the C++ state alive for cost / timeline queries."""
 
-    def __init__(self, handle, placements, cluster):
-        self._h, self.placements, self._cluster = handle, placements, cluster
+    def __init__(self, handle, placements, cluster, backend: str = "oracle"):
+        self._h, self.placements, self._cluster, self._backend = handle, placements, cluster, backend
 
     @property
     def seconds(self) -> float:
-        return lib().ora_seconds(self._h)
+        return lib(self._backend).ora_seconds(self._h)
 
     @property
     def jobs_ordered(self) -> int:
-        return lib().ora_jobs_ordered(self._h)
+        return lib(self._backend).ora_jobs_ordered(self._h)
 
     def costs(self) -> np.ndarray:
         c = np.zeros(len(self._cluster.part_nodes), np.float64)
-        lib().ora_get_costs(self._h, c.ctypes.data_as(C.c_void_p))
+        lib(self._backend).ora_get_costs(self._h, c.ctypes.data_as(C.c_void_p))
         return c
 
     def timeline(self, node: int, cap: int = 1100):
@@ -111,14 +163,14 @@ class OracleRun:
         mem = np.zeros(cap, np.uint64); lo = np.zeros(cap, np.uint64)
         hi = np.zeros(cap, np.uint64); g = np.zeros(cap, np.uint64)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
-        lib().ora_get_timeline(self._h, C.c_uint32(node), C.c_uint32(cap), C.byref(n), p(t), p(cpu), p(mem),
+        lib(self._backend).ora_get_timeline(self._h, C.c_uint32(node), C.c_uint32(cap), C.byref(n), p(t), p(cpu), p(mem),
                                p(lo), p(hi), p(g))
         k = n.value
         return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k]}
 
     def close(self):
         if self._h:
-            lib().ora_free(self._h)
+            lib(self._backend).ora_free(self._h)
             self._h = None
 
     def __del__(self):
@@ -131,7 +183,7 @@ class OracleRun:
 def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running | None = None,
            algebra: int = MASK, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0,
            max_time_window_sec: int = 0, reservations: abi.Reservations | None = None,
-           preempt: "abi.Preempt | None" = None) -> OracleRun:
+           preempt: "abi.Preempt | None" = None, backend: str = "oracle") -> OracleRun:
     cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, 0, scheduled_batch_size, max_job_num_per_node, 0,
                         max_time_window_sec)
     out = abi.Placements(jobs.num_jobs, jobs.total_places())
@@ -139,28 +191,41 @@ def select(cluster: abi.Cluster, jobs: abi.Jobs, now: int, running: abi.Running 
     cr = running.to_c() if running is not None else None
     cv = reservations.to_c() if reservations is not None else None
     h = C.c_void_p()
+    L = lib(backend)
+
+    def check(rc, what):
+        if rc == 0:
+            return
+        if backend != "oracle":
+            msg = (L.ref_last_error() or b"").decode()
+            if rc == -3:
+                raise RefAsserted(msg)
+            if rc == -5:
+                raise RefUnsupported(msg)
+            raise RuntimeError(f"{what} ({backend}) failed: {rc}: {msg}")
+        raise RuntimeError(f"{what} failed: {rc}")
+
     if preempt is not None:   # include/crane_gpu/preempt.h
         pout = abi.PreemptOut(jobs.num_jobs, len(running.end_sec) if running is not None else 0)
         cp, cpo = preempt.to_c(), pout.to_c()
-        rc = lib().ora_select_preempt(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
+        rc = L.ora_select_preempt(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
                                       C.byref(cv) if cv is not None else None, C.c_int64(now), C.byref(cj), C.byref(cp),
                                       C.byref(co), C.byref(cpo), algebra, C.byref(h))
-        if rc != 0:
-            raise RuntimeError(f"ora_select_preempt failed: {rc}")
-        run = OracleRun(h, out, cluster)
+        check(rc, "ora_select_preempt")
+        run = OracleRun(h, out, cluster, backend)
         run.preempt_out = pout
         return run
-    rc = lib().ora_select_resv(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
+    rc = L.ora_select_resv(C.byref(cfg), C.byref(cn), C.byref(cr) if cr is not None else None,
                                C.byref(cv) if cv is not None else None,
                                C.c_int64(now), C.byref(cj), C.byref(co), algebra, C.byref(h))
-    if rc != 0:
-        raise RuntimeError(f"ora_select failed: {rc}")
-    return OracleRun(h, out, cluster)
+    check(rc, "ora_select")
+    return OracleRun(h, out, cluster, backend)
 
 
-def priority_order(now: int, cfg, num_accounts: int, pending, running=None):
-    """CPU restatement of MultiFactorPriority (oracle/prio_oracle.hpp).  Returns (order, priority)."""
-    L = lib()
+def priority_order(now: int, cfg, num_accounts: int, pending, running=None, backend: str = "oracle"):
+    """CPU restatement of MultiFactorPriority (oracle/prio_oracle.hpp).  Returns (order, priority).
+    backend `ref`: the reference's own MultiFactorPriority::GetOrderedJobPtrVec (JobScheduler.cpp:7606-7819)."""
+    L = lib(backend)
     J = pending.num_jobs
     R = running.num_jobs if running is not None else 0
     order = np.empty(max(J, 1), np.uint32)
