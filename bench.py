@@ -73,11 +73,20 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    cluster, jobs, now = synth.make_config(args.config, J=args.jobs, N=args.nodes)
+    # --config: a frozen queue (C1..C5, C4p64) or its loaded-cluster variant (C4r, C2r, C5r: the same queue on a cluster
+    # that already runs jobs, synth.make_running — the cycle CraneCtld normally executes)
+    running = None
+    base_cfg = synth.LOADED.get(args.config, (args.config,))[0]
+    if args.config in synth.LOADED:
+        cluster, jobs, now, running = synth.make_loaded(args.config, J=args.jobs, N=args.nodes)
+    else:
+        cluster, jobs, now = synth.make_config(args.config, J=args.jobs, N=args.nodes)
     my_jobs, my_idx = sharding.shard(cluster, jobs, rank, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))
 
     eng = GpuNodeSelector(device=local_rank)
     eng.set_nodes(cluster)
+    if running is not None:
+        eng.set_running(running)       # (every rank holds the whole running set: allocations on other ranks' nodes are inert)
     eng.upload_jobs(my_jobs)           # inputs resident in HBM before the timed region
     h2d_ms = eng.timing()["h2d_ms"]
 
@@ -144,6 +153,8 @@ def main():
         merged = sharding.merge(jobs, shards)
         eng1 = GpuNodeSelector(device=local_rank)
         eng1.set_nodes(cluster)
+        if running is not None:
+            eng1.set_running(running)
         single = eng1.node_select(now, jobs)
         eng1.close()
         gather_check = merged.diff(single) is None
@@ -203,12 +214,15 @@ def main():
         r = got.reason[:my_jobs.num_jobs]
         line = {
             "metric": "scheduling decisions/sec at 1M pending x 64k nodes",
-            "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # `value`: inputs resident in HBM when the timed region starts (the bench contract: a PCIe-inclusive rate is never
+            # `value`).  The reference's own bracket incl. H2D of the job arrays and D2H of the placements: `incl_h2d_d2h`.
+            "value": value, "kernel_resident_decisions_per_s": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
             "config": {"workload": f"{args.config}: {jobs.num_jobs} pending jobs x {cluster.num_nodes} nodes, "
                                    f"{cluster.num_partitions} disjoint partitions, CPU+mem+GRES(gpu/npu), FIFO, "
-                                   f"seed 0x43524E45^{synth.CONFIGS[args.config]['idx']}",
+                                   f"seed 0x43524E45^{synth.CONFIGS[base_cfg]['idx']}" +
+                                   (f"; loaded cluster: {len(running.end_sec)} running jobs, {len(running.alloc_node)} allocations (synth.make_running)" if running is not None else ""),
                        "jobs": jobs.num_jobs, "nodes": cluster.num_nodes, "partitions": cluster.num_partitions,
                        "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else
                                    (("single GPU, 1 + 16 workgroups per partition (k_wide, 64 scanner waves)" if kernel.endswith("x64") else "single GPU, 1 + 8 workgroups per partition (k_wide)") if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
@@ -250,15 +264,33 @@ def main():
             # pinned to one core.  Its placements are then diffed against the engine's: a free full-partition parity check.
             from oracle import pyoracle  # the checker, timed here only as the reported baseline
             p0 = args.cpu_partition
-            cj = jobs if not args.cpu_sample_jobs else synth.make_config(args.config, J=min(args.cpu_sample_jobs, jobs.num_jobs), N=args.nodes)[1]
+            cj = jobs if not args.cpu_sample_jobs else synth.make_config(base_cfg, J=min(args.cpu_sample_jobs, jobs.num_jobs), N=args.nodes)[1]
             sub, idx = synth.select_partitions(cluster, cj, [p0])   # a prefix of the queue keeps the job indices
+            run_p0 = None if running is None else synth.running_of_partitions(cluster, running, [p0])
             core = None
             try:
                 core = sorted(os.sched_getaffinity(0))[-1]
                 os.sched_setaffinity(0, {core})
             except (AttributeError, OSError):
                 pass
-            ref = pyoracle.select(cluster, sub, now)
+            ref = pyoracle.select(cluster, sub, now, running=run_p0)
+            # ... and THE REFERENCE'S OWN CODE (oracle/_ref: slices of JobScheduler.{h,cpp} / PublicHeader.{h,cpp} compiled in the
+            # build container, shipped prebuilt) on a bounded prefix of that partition's queue, the port timed on the same prefix
+            # beside it.  A prefix only reaches the cluster-filling regime (it flatters both): the whole-partition figure of the
+            # reference build is in profiles/r03_ref_vs_oracle_fullsize.txt.
+            ref_build = None
+            if pyoracle.ref_available() and not args.cpu_sample_jobs:
+                n_pre = min(sub.num_jobs, 6000)
+                pre_cfg = synth.make_config(base_cfg, J=int(idx[n_pre - 1]) + 1, N=args.nodes)[1]
+                pre_sub, pre_idx = synth.select_partitions(cluster, pre_cfg, [p0])
+                rb = pyoracle.select(cluster, pre_sub, now, running=run_p0, backend="ref")
+                rp = pyoracle.select(cluster, pre_sub, now, running=run_p0)
+                same_pre = rb.placements.diff(rp.placements) is None and bool(np.array_equal(rb.placements.start_sec[:pre_sub.num_jobs], got.start_sec[pre_idx]))
+                ref_build = {"value": pre_sub.num_jobs / rb.seconds, "unit": "decisions/s", "cores": 1, "kind": "reference",
+                             "sample": f"first {pre_sub.num_jobs} jobs of partition {p0} ({rb.seconds:.1f} s on the same pinned core); "
+                                       f"the port on the same prefix: {pre_sub.num_jobs / rp.seconds:.0f} decisions/s ({rp.seconds:.2f} s)",
+                             "port_on_same_sample_decisions_per_s": pre_sub.num_jobs / rp.seconds,
+                             "identical_to_port_and_engine": bool(same_pre)}
             try:
                 os.sched_setaffinity(0, set(range(os.cpu_count() or 1)))
             except (AttributeError, OSError):
@@ -282,6 +314,8 @@ def main():
                           f"~{cluster.num_partitions}x that on one core",
                 "whole_queue_core_seconds_estimate": ref.seconds * jobs.num_jobs / max(sub.num_jobs, 1),
                 "sample_identical_to_engine": same, "host_cpus": os.cpu_count()}
+            if ref_build is not None:
+                line["cpu_baseline"]["reference_build"] = ref_build
         print(json.dumps(line), flush=True)
     eng.close()
     if use_dist:

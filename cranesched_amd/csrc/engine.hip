@@ -93,7 +93,7 @@ struct cns_engine {
   DevBuf d_slot_total, d_slot_end, d_slot_type, d_rv_off, d_rv_start, d_rv_end, d_rv_res, d_first_resv, d_resv_se;
   // device buffers
   DevBuf d_part_off, d_slot_node, d_type_total, d_blocks, d_cost, d_fcpu,
-      d_fmem, d_fcnt, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
+      d_fmem, d_fcnt, d_dipt, d_dipcm, d_dipg, d_rn_off, d_rn_end, d_rn_res, d_heap, d_bfj, d_gupd, d_fault;
   DevBuf d_pj_off, d_jobs, d_incl, d_excl, d_reason_init, d_results, d_params, d_prof, d_wide;
   DevBuf d_raw[16];  // the caller's job arrays as uploaded (k_pack_jobs reads them; d_raw[14] = place offsets)
   // job table
@@ -103,6 +103,8 @@ struct cns_engine {
   cns_timing timing{};
   std::string last_kernel;
   i64 last_now = 0;
+  bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
+  u32 wide_retries = 0;                         // cycles that were re-run on k_pipe / k_select after a k_wide fault (lifetime of the handle)
   // MultiFactorPriority (priority_host.inc)
   DevBuf d_prio[27];
   double prio_ms = 0.0;
@@ -176,6 +178,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.max_jobs_per_node = h->cfg.max_job_num_per_node;
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
+  if (const char* inj = getenv("CNS_WIDE_INJECT_STALL")) K.wide_inject_stall = (u32)strtoul(inj, nullptr, 10) + 1u;
   K.part_off = h->d_part_off.as<u32>();
   K.slot_node = h->d_slot_node.as<u32>();
   K.slot_total = h->d_slot_total.as<Res>();
@@ -195,6 +198,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.f_cpu = h->d_fcpu.as<int>();
   K.f_mem = h->d_fmem.as<u32>();
   K.f_cnt = h->d_fcnt.as<u64>();
+  K.dip_t = h->d_dipt.as<u32>(); K.dip_cm = h->d_dipcm.as<u32>(); K.dip_g = h->d_dipg.as<u32>();
   K.rn_off = h->d_rn_off.as<u32>();
   K.rn_end = h->d_rn_end.as<i64>();
   K.rn_res = h->d_rn_res.as<Res>();
@@ -257,6 +261,12 @@ int launch_wide(cns_engine* h, const KParams& K, u32 np, std::string* name) {
     dyn = 84u * 1024u - fa.sharedSizeBytes;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { dyn = 0; (void)hipGetLastError(); }
   }
+  // The workgroups of this launch spin on each other: ALL of them must be resident at once.  Proof, not assumption: the
+  // runtime's own occupancy figure for this kernel at this block size and LDS footprint, times the device's CUs, must
+  // cover the grid — else the launch is refused here and the cycle runs on k_pipe / k_select, which need no co-residency.
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)W::block, dyn) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+  if (per_cu < 1 || (u64)per_cu * h->num_cus < grid) return 2;
   const KParams* dparams = h->d_params.as<KParams>();
   void* args[2] = {(void*)&K2, (void*)&dparams};
   if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, h->stream) != hipSuccess) return 1;
@@ -280,10 +290,10 @@ u32 use_wide_kernel(const cns_engine* h) {
   if (e && (!strcmp(e, "legacy") || !strcmp(e, "pipe"))) want = false;
   const bool only32 = e && !strcmp(e, "wide32");
   if (e && (!strcmp(e, "wide") || only32)) want = true;
-  if (!want || h->shared) return 0;
+  if (!want || h->shared || h->wide_off) return 0;
   // every workgroup of the launch must be resident at once, one per CU (a partitioned or smaller device falls to k_pipe)
   const u32 groups = (h->P + 7u) / 8u;
-  auto fits = [&](u32 wgs_per_part) { return h->num_cus == 0 || 8u * groups * wgs_per_part <= h->num_cus; };
+  auto fits = [&](u32 wgs_per_part) { return h->num_cus != 0 && 8u * groups * wgs_per_part <= h->num_cus; };   // (unknown CU count: no proof of co-residency, no k_wide)
   if (!only32 && h->P <= w64::WideInfo::max_parts && h->max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max && fits(w64::WideInfo::group)) return 64;
   if (h->P <= w32::WideInfo::max_parts && h->max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max && fits(w32::WideInfo::group)) return 32;
   return 0;
@@ -366,12 +376,13 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   HIPCHK(h, h->d_fcpu.ensure(S1 * sizeof(int)));
   HIPCHK(h, h->d_fmem.ensure(S1 * sizeof(u32)));
   HIPCHK(h, h->d_fcnt.ensure(S1 * sizeof(u64)));
+  HIPCHK(h, h->d_dipt.ensure(S1 * sizeof(u32))); HIPCHK(h, h->d_dipcm.ensure(S1 * sizeof(u32))); HIPCHK(h, h->d_dipg.ensure(S1 * sizeof(u32)));
   HIPCHK(h, h->d_first_resv.ensure(S1 * sizeof(i64)));
   HIPCHK(h, h->d_heap.ensure((size_t)(S + h->P + 1) * sizeof(HeapEnt)));
   HIPCHK(h, h->d_bfj.ensure(S1 * sizeof(u32)));
   HIPCHK(h, h->d_gupd.ensure(S1 * sizeof(UpdRec)));
   HIPCHK(h, h->d_fault.ensure(4 * sizeof(u32)));
-  HIPCHK(h, h->d_prof.ensure((size_t)(h->P + 8) * (size_t)w64::WideInfo::group * 32 * sizeof(u64)));   // (k_wide: blocks > partitions)
+  HIPCHK(h, h->d_prof.ensure(((size_t)(h->P + 8) * (size_t)w64::WideInfo::group * 32 + (size_t)h->P * 8 + 2048) * sizeof(u64)));   // (k_wide: blocks > partitions)
   // no running jobs until cns_set_running
   std::vector<u32> rn_off(S + 1, 0);
   if (int rc = upload(h, h->d_rn_off, rn_off)) return rc;
@@ -432,7 +443,7 @@ void cns_destroy(cns_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   for (DevBuf* b : {&h->d_part_off, &h->d_slot_node, &h->d_type_total,
-                    &h->d_blocks, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_rn_off,
+                    &h->d_blocks, &h->d_cost, &h->d_fcpu, &h->d_fmem, &h->d_fcnt, &h->d_dipt, &h->d_dipcm, &h->d_dipg, &h->d_rn_off,
                     &h->d_rn_end, &h->d_rn_res, &h->d_heap, &h->d_bfj, &h->d_gupd, &h->d_fault, &h->d_pj_off, &h->d_jobs,
                     &h->d_incl, &h->d_excl, &h->d_reason_init, &h->d_results, &h->d_params, &h->d_prof, &h->d_wide, &h->d_slot_total,
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
@@ -831,9 +842,9 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   return CNS_OK;
 }
 
-int cns_run_resident(cns_handle* h, int64_t now) {
-  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_run_resident: null handle");
-  if (!h->have_nodes || !h->have_jobs) return fail(h, CNS_ERR_STATE, "cns_run_resident before set_nodes/upload_jobs");
+// One pass of the cycle on the device.  *fault_code: the device fault it ended with (0: none).
+static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
+  *fault_code = 0;
   HIPCHK(h, hipSetDevice(h->device));
   KParams K;
   fill_params(h, K, now);
@@ -845,7 +856,7 @@ int cns_run_resident(cns_handle* h, int64_t now) {
   HIPCHK(h, hipMemsetAsync(rb + h->ro.ntasks, 0, 4 * pl, h->stream));
   HIPCHK(h, hipMemcpyAsync(rb + h->ro.reason, h->d_reason_init.p, J, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_fault.p, 0, 16, h->stream));
-  HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, (size_t)h->P * 32 * sizeof(u64), h->stream));
+  HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, ((size_t)h->P * (32 + 8) + 2048) * sizeof(u64), h->stream));   // cycle counters + the always-on protocol counters
   HIPCHK(h, h->d_params.ensure(sizeof(KParams)));
   HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
   if (h->S) hipLaunchKernelGGL(k_init_nodes, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_params.as<KParams>());
@@ -888,12 +899,45 @@ int cns_run_resident(cns_handle* h, int64_t now) {
   u32 fault[4] = {0, 0, 0, 0};
   HIPCHK(h, hipMemcpy(fault, h->d_fault.p, 16, hipMemcpyDeviceToHost));
   h->last_now = now;
-  if (fault[0])
+  if (fault[0] && h->pre_active && (fault[0] == 31 || fault[0] == 32)) {
+    *fault_code = fault[0];
+    return fail(h, CNS_ERR_UNSUPPORTED, std::string("cns_select_preempt: job ") + std::to_string(fault[1]) + (fault[0] == 31
+                    ? " has more preemption candidates on its nodes than the candidate buffer holds"
+                    : " needs more segment-tree nodes than the per-partition pool (65536) holds") +
+                    "; keep the CPU SchedulerAlgo for this cycle (include/crane_gpu/preempt.h, limits)");
+  }
+  if (fault[0]) {
+    *fault_code = fault[0];
     return fail(h, CNS_ERR_DEVICE_FAULT, "device invariant violated: code " + std::to_string(fault[0]) + " job " +
                                              std::to_string(fault[1]) + " aux " + std::to_string(fault[2]) + "," +
-                                             std::to_string(fault[3]));
+                                             std::to_string(fault[3]) + " (" + h->last_kernel + ")");
+  }
   h->have_run = true;
   return CNS_OK;
+}
+
+// k_wide is a persistent kernel whose workgroups wait for each other; its waits are bounded and end in a device fault
+// (codes 20..41: a wait of the exchange / command / task-ring protocol ran out, or a protocol position did not match).
+// Such a fault says nothing about the INPUT: the cycle is re-run once on k_pipe / k_select, which live inside one
+// workgroup per partition (every run starts from the caller's tables: k_init_nodes, k_prep_jobs and the result buffers
+// are part of the pass).  Faults below 20 are data invariants of the shared routines (e.g. 3: the input class on which
+// the reference itself asserts) and would recur: they fail the call.
+int cns_run_resident(cns_handle* h, int64_t now) {
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_run_resident: null handle");
+  if (!h->have_nodes || !h->have_jobs) return fail(h, CNS_ERR_STATE, "cns_run_resident before set_nodes/upload_jobs");
+  u32 code = 0;
+  h->wide_off = false;
+  int rc = run_resident_once(h, now, &code);
+  if (rc == CNS_ERR_DEVICE_FAULT && code >= 20 && h->last_kernel.rfind("k_wide", 0) == 0) {
+    const std::string first = h->err;
+    h->wide_off = true;
+    ++h->wide_retries;
+    rc = run_resident_once(h, now, &code);
+    h->wide_off = false;
+    if (rc == CNS_OK) h->last_kernel += " (retry after: " + first + ")";
+    else h->err = first + "; retry on " + h->last_kernel + ": " + h->err;
+  }
+  return rc;
 }
 
 int cns_download(cns_handle* h, cns_placement_soa* out) {
@@ -938,8 +982,8 @@ int cns_select(cns_handle* h, int64_t now, const cns_job_soa* jobs, cns_placemen
 // pipelined kernels exclude by construction (node state monotone within a cycle: caches, predicted tiles, decoupled
 // commits).  A cycle with preemption enabled therefore runs k_select with every job on its general path
 // (KParams::general_only) and the device form of TryPreempt_ / PreemptSegTree between the res_total selection and the
-// backfill (csrc/preempt_dev.inc).  Reservations are served (their virtual nodes carry their own job lists, cpp:6705);
-// not combined yet with partitions that share nodes: refused.
+// backfill (csrc/preempt_dev.inc).  Reservations are served (their virtual nodes carry their own job lists, cpp:6705), and
+// so are partitions that share nodes (node-level job lists).
 int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* pre,
                        cns_placement_soa* out, cns_preempt_out* pout) {
   if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null handle");
@@ -993,7 +1037,18 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   }
   bool patched = false;
   for (u32 r = 0; r < R; ++r) patched = patched || rj_pre[r];
-  if (patched) { if (int rc = upload(h, h->d_rn_end, ent_end)) return rc; }
+  // The device's running table carries the patched end times for THIS call only: whatever way the call ends, the resident
+  // table goes back to the caller's end times (later cns_select / cns_run_resident calls reuse it).
+  struct RestoreEnd {
+    cns_engine* h; bool armed;
+    ~RestoreEnd() {
+      if (!armed) return;
+      const std::string keep = h->err;   // the restore must not overwrite the call's own error
+      if (upload(h, h->d_rn_end, h->ent_end) == CNS_OK) (void)hipStreamSynchronize(h->stream);
+      h->err = keep;
+    }
+  } restore_end{h, false};
+  if (patched) { restore_end.armed = true; if (int rc = upload(h, h->d_rn_end, ent_end)) return rc; }
   // No pending job's qos may preempt anything: TryPreempt_ returns at :6385 for every job, so the cycle is the plain one
   // (with the preempting jobs ending at now + 1) and runs on the pipelined kernels.
   bool any_list = false;
@@ -1003,7 +1058,6 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   }
   if (!any_list) {
     int rc = cns_run_resident(h, now);
-    if (patched) { if (int rc2 = upload(h, h->d_rn_end, h->ent_end)) return rc2; HIPCHK(h, hipStreamSynchronize(h->stream)); }
     if (rc) return rc;
     if (int rc3 = cns_download(h, out)) return rc3;
     for (u64 j = 0; j <= J; ++j) pout->offsets[j] = 0;
@@ -1027,7 +1081,11 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   std::vector<double> pj_prio(std::max<u64>(J, 1), 0.0);
   for (u64 j = 0; j < J; ++j) { pj_qos[j] = pre->pd_qos[j]; pj_qprio[j] = pre->pd_qos_priority[j]; pj_prio[j] = pre->pd_priority[j]; }
   const u64 places = std::max<u64>(h->places, 1);
-  const u32 pool_nodes = 1u << 16, cand_cap = 4096;
+  // work buffers per partition (documented in include/crane_gpu/preempt.h): candidate / chosen lists sized for every running
+  // job plus every pending job of the cycle (at most all of them hold resources on one job's nodes), bounded by 64 Mi entries
+  // over all partitions; segment-tree pools of 65 536 nodes.  Exceeding either is CNS_ERR_UNSUPPORTED, not a device fault.
+  const u32 pool_nodes = 1u << 16;
+  const u32 cand_cap = (u32)std::max<u64>(4096, std::min<u64>((u64)R + J + 1, (64ull << 20) / std::max<u32>(h->P, 1)));
   const u32 out_cap = (u32)std::min<u64>(4 * (J + R) + 64, 1u << 28);
   enum { B_QPOFF, B_QP, B_PJQOS, B_PJQP, B_PJPRIO, B_PJREC0, B_PJK, B_PJEND, B_RNJOB, B_ENTSLOT, B_ENTGONE, B_RJQOS, B_RJQP,
          B_RJSTART, B_RJEND, B_RJPRE, B_RJOFF, B_RJENT, B_HEAD, B_RECNEXT, B_RECORIG, B_RECSLOT, B_RECGONE, B_MISC };
@@ -1074,7 +1132,6 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   h->pre_active = true;
   int rc = cns_run_resident(h, now);
   h->pre_active = false;
-  if (patched) { if (int rc2 = upload(h, h->d_rn_end, h->ent_end)) return rc2; HIPCHK(h, hipStreamSynchronize(h->stream)); }
   if (rc) return rc;
   if (int rc3 = cns_download(h, out)) return rc3;
   // ---- the preempted lists: (pending job, reference) pairs in push_back order per job -> CSR by job ------------------
@@ -1142,7 +1199,12 @@ int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity) {
   if (!h || !out) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_prof: null argument");
   if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_prof before a successful run");
   HIPCHK(h, hipSetDevice(h->device));
-  const size_t n = std::min<size_t>((size_t)h->P * 32, capacity);
+  // behind them (from index 32 * P): 8 always-on protocol counters per partition of k_wide (every build; wide_kernel.inc kWs*)
+#ifdef CNS_DEBUG_FLUSH_LOG
+  const size_t n = std::min<size_t>((size_t)h->P * (32 + 8) + 2048, capacity);   // + the flush log of partition 0 (diagnostics build)
+#else
+  const size_t n = std::min<size_t>((size_t)h->P * (32 + 8), capacity);
+#endif
   HIPCHK(h, hipMemcpy(out, h->d_prof.p, n * sizeof(u64), hipMemcpyDeviceToHost));
   return CNS_OK;
 }

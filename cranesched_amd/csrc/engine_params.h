@@ -125,7 +125,9 @@ struct KParams {
   // ---- cluster -------------------------------------------------------------------------
   u32 num_nodes, num_parts, num_slots, num_types;
   u32 tl_cap, max_jobs_per_node;
-  u32 reserved0, reserved1;
+  u32 wide_inject_stall;   // test hook (CNS_WIDE_INJECT_STALL=<job>): job index + 1 of partition 0 whose exchange the leader scanner of k_wide
+                           // never publishes — every other wave's wait then runs out (fault 28) and the cycle is re-run on k_pipe / k_select
+  u32 reserved1;
   i64 now, max_window;
   const u32* part_off;     // [P+1] slot range of each partition
   const u32* slot_node;    // [S]   dense node index of slot q (ascending inside a partition)
@@ -146,6 +148,15 @@ struct KParams {
   int* f_cpu;              // [S]   front (t = now) summary: cpu raw, exact
   u32* f_mem;              // [S]   front mem in MiB, rounded up (conservative)
   u64* f_cnt;              // [S]   front GRES popcount per class, byte g
+  // One FUTURE entry of the slot's time map that lies below the front in some component ("dip": a backfilled job, a pending
+  // reservation, the end of a reservation's map) — a second NECESSARY condition for "starts now": a job whose window reaches
+  // past dip_t must also fit the dip.  Time-map entries are never removed and only shrink within a cycle without preemption,
+  // so a recorded dip stays valid when it is stale; the committers keep the earliest one (pipe_commit_node), k_wide's
+  // scanners pick it up when they reload their tile (without it a loaded cluster trips over the same reservation again and
+  // again: 0.7 flushes per job on C4r).
+  u32* dip_t;              // [S]   seconds after `now` (0xFFFFFFFF: none)
+  u32* dip_cm;             // [S]   whole cpus, rounded up << 16 | memory in GiB, rounded up (both saturating)
+  u32* dip_g;              // [S]   GRES popcount per class as 8 saturating nibbles
   // running allocations grouped by node, input order preserved
   const u32* rn_off;       // [N+1]
   const i64* rn_end;       // [A]

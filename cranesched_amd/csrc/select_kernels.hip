@@ -200,6 +200,22 @@ __device__ __forceinline__ u32 mem_mib_ceil(u64 m) {
   if (m > 0xFFFFFFFFFFF00000ull) v = 0xFFFFFFFFull;
   return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)v;
 }
+__device__ __forceinline__ u32 nibbles_of(u64 cnt);
+__device__ __forceinline__ u32 mem_gib16(u32 mib);
+// KParams::dip_*: the packed upper bounds of one time-map entry, and "is it below the front somewhere" (on the summaries:
+// what the scanners' filters can tell apart)
+__device__ __forceinline__ u32 dip_cm_of(const Res& r) {
+  const i64 c = r.cpu <= 0 ? 0 : ((r.cpu + 255) >> 8);
+  return ((u32)(c > 0xFFFF ? 0xFFFF : c) << 16) | mem_gib16(mem_mib_ceil(r.mem));
+}
+__device__ __forceinline__ u64 class_counts(u64 gres, const GresDev& L);
+__device__ __forceinline__ bool dip_below(const Res& e, const Res& front, const GresDev& L) {
+  if (e.cpu < front.cpu || e.mem < front.mem) return true;
+  const u64 ce = class_counts(e.gres, L), cf = class_counts(front.gres, L);
+  for (u32 g = 0; g < 8; ++g)
+    if (((ce >> (8 * g)) & 0xFFull) < ((cf >> (8 * g)) & 0xFFull)) return true;
+  return false;
+}
 __device__ __forceinline__ u64 class_counts(u64 gres, const GresDev& L) {
   u64 c = 0;
   for (int g = 0; g < (int)L.num_classes; ++g) c |= (u64)popc64(gres & L.class_mask[g]) << (8 * g);
@@ -318,6 +334,14 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
   P.f_cpu[q] = clamp_cpu(a0.cpu);
   P.f_mem[q] = mem_mib_ceil(a0.mem);
   P.f_cnt[q] = class_counts(a0.gres, P.gres);
+  {  // the earliest entry below the front (a pending reservation's dip; the zero entry at the end of a reservation's own map)
+    u32 dt = 0xFFFFFFFFu, dcm = 0, dg = 0;
+    for (u32 i = 1; i < len; ++i) {
+      if (T[i].t == kInf || T[i].t - P.now >= 0xFFFFFFFFll) break;
+      if (dip_below(T[i].r, a0, P.gres)) { dt = (u32)(T[i].t - P.now); dcm = dip_cm_of(T[i].r); dg = nibbles_of(class_counts(T[i].r.gres, P.gres)); break; }
+    }
+    P.dip_t[q] = dt; P.dip_cm[q] = dcm; P.dip_g[q] = dg;
+  }
   P.first_resv[q] = first;
 }
 
@@ -1263,6 +1287,22 @@ __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, No
   e = tl_of(hd)[lane];
   h.len = uni32(h.len); h.node = uni32(h.node); h.type = uni32(h.type);
   h.avail0 = uni_res(h.avail0); h.total = uni_res(h.total);
+}
+
+// The exact test rejected this slot for a job that the front (the entry at `now`) admits: a FUTURE entry inside the job's window
+// holds less.  The first such entry that by itself cannot host the job (cpu, memory, GRES counts) becomes the slot's dip
+// (KParams::dip_*): when the scanners reload their tile they stop proposing the node to jobs whose windows reach it.  Written
+// where the misprediction is found — nothing on the path of a prediction that holds.  Register maps (<= 64 entries) only.
+__device__ __forceinline__ void record_dip(const KParams& P, u32 q, const TlEntry& e, u32 len, const Req& mv, i64 E, u32 lane) {
+  if (len > 64) return;
+  const bool cand = lane >= 1 && lane < len && e.t < E && e.t - P.now < 0xFFFFFFFFll &&
+                    !feasible_counts(mv, e.r.cpu, e.r.mem, 0u, class_counts(e.r.gres, P.gres), P.gres);
+  const u64 b = __ballot(cand);
+  if (!b) return;
+  const u32 i = (u32)__builtin_ctzll(b);
+  const Res r = rl_res(e.r, i);
+  const i64 t = (i64)rl64((u64)e.t, i);
+  if (lane == 0) { P.dip_t[q] = (u32)(t - P.now); P.dip_cm[q] = dip_cm_of(r); P.dip_g[q] = nibbles_of(class_counts(r.gres, P.gres)); }
 }
 
 // Commit pick i of a multi-node selection (time map, cost, owner update i); H[i].res = its allocation.

@@ -254,6 +254,19 @@ class GpuNodeSelector:
         self._check(self._L.cns_debug_get_prof(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(P * 32)))
         return out.reshape(P, 32)
 
+    WIDE_STATS = ("looks_empty", "looks_consumed", "leader_polls_ring_full", "stops", "flushes", "redo_with_exclusion",
+                  "serial_jobs", "resource_verdicts")
+
+    def wide_stats(self) -> dict:
+        """Always-on protocol counters of k_wide's last run, summed over the partitions (every build; zeros for the other
+        kernels): who waited for whom (supervisor looks without / with a decision, leader polls in front of a full ring) and
+        how often the chain was broken (stops, flushes) and mended (redo with an excluded candidate, serial jobs, "Resource")."""
+        P = self._cluster.num_partitions
+        out = np.zeros(P * 40, np.uint64)
+        self._check(self._L.cns_debug_get_prof(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(P * 40)))
+        st = out[P * 32:].reshape(P, 8).sum(axis=0)
+        return {k: int(v) for k, v in zip(self.WIDE_STATS, st)}
+
     def timeline(self, node: int, cap: int = 1100):
         n = C.c_uint32(0)
         t = np.zeros(cap, np.int64); cpu = np.zeros(cap, np.int64)

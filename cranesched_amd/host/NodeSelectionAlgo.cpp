@@ -83,6 +83,7 @@ struct GpuNodeSelectionAlgo::Impl {
   std::set<job_id_t> preempting;                                    // m_preempting_set_
   std::vector<job_id_t> cancelled;                                  // EnqueuePreemptCancel of the last cycle
   std::vector<RnJobInScheduler*> r_src;                             // packed running job r -> the caller's object
+  bool r_src_valid = false;                                         // r_src was filled by THIS pack (pack_running), not by an earlier cycle
   uint32_t qos_of(const std::string& name) {
     auto it = qos_id.find(name);
     if (it != qos_id.end()) return it->second;
@@ -212,6 +213,8 @@ struct GpuNodeSelectionAlgo::Impl {
   }
   void pack_from_mirror() {
     r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
+    r_src.clear();        // the mirror has no RnJobInScheduler objects: a cycle with preemption must be refused, never served from an
+    r_src_valid = false;  // earlier explicit cycle's (freed) pointers that happen to match in number
     r_off.assign(1, 0);
     for (const auto& [id, mj] : mirror) {
       uint32_t rv = CNS_RESV_NONE;
@@ -248,6 +251,7 @@ struct GpuNodeSelectionAlgo::Impl {
   void pack_running(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
     r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
     r_src.clear();
+    r_src_valid = true;
     r_off.assign(1, 0);
     ++alloc_gen;
     PackedAlloc scratch;
@@ -315,7 +319,9 @@ struct GpuNodeSelectionAlgo::Impl {
   // core ids as two 64-bit masks; an id >= 128 does not fit the engine's model: it is RECORDED (core_overflow) and the
   // snapshot / cycle is refused — silently dropping it would make integer requests fail the `popc < n` test, or come back
   // without core ids, where ResourceView::GetFeasibleResourceInNode (PublicHeader.cpp:528-538) fits them
-  bool core_overflow = false;
+  bool core_overflow = false;   // a core id >= 128 was met by the pack in progress (snapshot, running jobs or steps)
+  bool snap_overflow = false;   // ... by the SNAPSHOT: it stays refused until the next SetClusterSnapshot
+  std::string snap_error;       // why the last snapshot was refused (kept for the NodeSelect calls that follow it)
   void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi) {
     lo = hi = 0;
     for (uint32_t c : ids) {
@@ -612,9 +618,11 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     I.v_off.push_back((uint32_t)I.v_node.size());
   }
   I.repack_mirror();
+  I.snap_overflow = I.core_overflow;
+  I.snap_error.clear();
   if (I.core_overflow) {
     status_ = CNS_ERR_UNSUPPORTED;
-    error_ = "a node or reservation lists a core id >= 128 (the engine keeps core ids in two 64-bit masks); keep the CPU SchedulerAlgo";
+    error_ = I.snap_error = "a node or reservation lists a core id >= 128 (the engine keeps core ids in two 64-bit masks); keep the CPU SchedulerAlgo";
     return;
   }
   if (!I.h) return;   // no device: the dictionaries above still serve PackRunningForBench
@@ -689,9 +697,14 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
     for (const auto& j : pending_jobs) if (j->reason.empty()) j->reason = "GpuEngineError";
   };
   if (!I.h) return fail_all(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
-  if (!I.have_snapshot) return fail_all(CNS_ERR_STATE, "NodeSelect before SetClusterSnapshot");
-
-  if (I.core_overflow) return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 128");
+  if (!I.have_snapshot) {
+    if (I.snap_overflow) return fail_all(CNS_ERR_UNSUPPORTED, I.snap_error);   // the refused snapshot's own message, every cycle
+    return fail_all(CNS_ERR_STATE, "NodeSelect before SetClusterSnapshot");
+  }
+  if (I.core_overflow) {
+    I.core_overflow = false;   // per pack: the next cycle's running set is judged on its own
+    return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 128");
+  }
   const auto &r_end = I.r_end, &r_cpu = I.r_cpu;
   const auto &r_off = I.r_off, &r_node = I.r_node, &r_resv = I.r_resv;
   const auto &r_mem = I.r_mem, &r_lo = I.r_lo, &r_hi = I.r_hi, &r_g = I.r_g;
@@ -782,7 +795,7 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
     if (st != 0) return fail_all(st, cns_last_error(I.h));
   } else {
     // ---- the cycle with preemption (include/crane_gpu/preempt.h): qos ids, the fields TryPreempt_ reads, the set ------
-    if (I.r_src.size() != I.r_end.size())
+    if (!I.r_src_valid || I.r_src.size() != I.r_end.size())
       return fail_all(CNS_ERR_STATE, "preemption needs the running jobs themselves: call NodeSelect(now, running_jobs, pending_jobs)");
     const uint32_t R = (uint32_t)I.r_src.size();
     std::vector<uint32_t> pj_id(J + 1), pj_qos(J + 1), pj_qp(J + 1), rj_id(R + 1), rj_qos(R + 1), rj_qp(R + 1), pset;
@@ -876,7 +889,7 @@ bool GpuNodeSelectionAlgo::AppendResourceInNodeV3Wire(const PdJobInScheduler& jo
 
 void GpuNodeSelectionAlgo::ComposeJobToDWire(uint32_t job_id, uint32_t uid, const std::string& partition, const std::string& account,
                                              const std::string& qos, const std::string& name, const std::string& res_wire,
-                                             std::string* out) {
+                                             std::string* out, const ArrayTaskIdentity* array_task) {
   Impl::put_u64(*out, 1, job_id);
   Impl::put_u64(*out, 2, uid);
   Impl::put_str(*out, 4, res_wire);   // a message field is written whenever it is set (mutable_res(), CtldPublicDefs.cpp:537-554)
@@ -884,13 +897,19 @@ void GpuNodeSelectionAlgo::ComposeJobToDWire(uint32_t job_id, uint32_t uid, cons
   if (!account.empty()) Impl::put_str(*out, 6, account);
   if (!qos.empty()) Impl::put_str(*out, 7, qos);
   if (!name.empty()) Impl::put_str(*out, 9, name);
+  if (array_task) {   // optional message field 16: written whenever it is set, even when both scalars are zero
+    std::string id;
+    Impl::put_u64(id, 1, array_task->array_job_id);
+    Impl::put_u64(id, 2, array_task->task_id);
+    Impl::put_str(*out, 16, id);
+  }
 }
 
 bool GpuNodeSelectionAlgo::AppendJobToDWire(const PdJobInScheduler& job, uint32_t uid, const std::string& name,
-                                            const CranedId& craned_id, std::string* out) {
+                                            const CranedId& craned_id, std::string* out, const ArrayTaskIdentity* array_task) {
   std::string res;
   if (!AppendResourceInNodeV3Wire(job, craned_id, &res)) return false;
-  ComposeJobToDWire(job.job_id, uid, job.partition_id, job.account, job.qos, name, res, out);
+  ComposeJobToDWire(job.job_id, uid, job.partition_id, job.account, job.qos, name, res, out, array_task);
   return true;
 }
 

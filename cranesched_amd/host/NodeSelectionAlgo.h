@@ -158,9 +158,9 @@ struct ClusterSnapshot {
   std::vector<ResvMeta> reservations;                                     // g_meta_container->GetResvMetaMapPtr(); vector order = canonical order
   // g_config.Preempt.PreemptType != NONE (PREEMPT_QOS): NodeSelect calls LocalScheduler::TryPreempt_ (JobScheduler.cpp:
   // 6140-6143) with the preempt lists of the QoS table (cpp:6532-6543: Qos::preempt of every pending job's qos).  Served by
-  // cns_select_preempt (include/crane_gpu/preempt.h) through NodeSelect(now, running_jobs, pending_jobs); a snapshot that
-  // combines it with reservations or with partitions that share nodes is refused (status() = CNS_ERR_UNSUPPORTED) so that
-  // the integrator keeps the CPU SchedulerAlgo instead of getting "GpuEngineError" on every job of every cycle.
+  // cns_select_preempt (include/crane_gpu/preempt.h) through NodeSelect(now, running_jobs, pending_jobs) — also together
+  // with reservations and with partitions that share nodes.  The mirror-fed form NodeSelect(now, pending_jobs) has no
+  // RnJobInScheduler objects to hand back in preempted_jobs and is refused for such a snapshot (CNS_ERR_STATE).
   bool preempt_enabled{false};
   std::unordered_map<std::string, std::vector<std::string>> qos_preempt;   // qos name -> Qos::preempt
 };
@@ -377,10 +377,14 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   const std::vector<const PdJobInScheduler*>& LastOrder() const;
   // one allocation / one JobToD of a job of the last cycle (appends to *out; false: job or node not in the last cycle's result)
   bool AppendResourceInNodeV3Wire(const PdJobInScheduler& job, const CranedId& craned_id, std::string* out);
+  // JobToD.array_task (field 16, ArrayTaskIdentity{array_job_id, task_id}): set by the reference for array children only
+  // (GetArrayTaskIdentity(), CtldPublicDefs.cpp:547-551); pass the identity to emit it, nullptr for every other job.
+  struct ArrayTaskIdentity { uint32_t array_job_id; uint32_t task_id; };
   bool AppendJobToDWire(const PdJobInScheduler& job, uint32_t uid, const std::string& name, const CranedId& craned_id,
-                        std::string* out);
+                        std::string* out, const ArrayTaskIdentity* array_task = nullptr);
   static void ComposeJobToDWire(uint32_t job_id, uint32_t uid, const std::string& partition, const std::string& account,
-                                const std::string& qos, const std::string& name, const std::string& res_wire, std::string* out);
+                                const std::string& qos, const std::string& name, const std::string& res_wire, std::string* out,
+                                const ArrayTaskIdentity* array_task = nullptr);
   // test / bench hook (no device): the wire bytes and the ResourceInNodeV3 object of one packed allocation
   void WireOfPackedForTest(int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t core_lo, uint64_t core_hi, uint64_t gres,
                            std::string* wire, ResourceInNodeV3* obj) const;

@@ -250,8 +250,13 @@ static int wire_dump(const char* path, int n, bool jobtod) {
       const std::string part = (i % 4) ? "GPU" : "", acct = "acct" + std::to_string(i % 9), qos = (i % 3) ? "normal" : "",
                         name = (i % 6) ? "job_" + std::to_string(i) : "";
       std::string jw;
-      GpuNodeSelectionAlgo::ComposeJobToDWire(job_id, uid, part, acct, qos, name, wire, &jw);
-      fprintf(f, "JOB %u %u %s %s %s %s\nJOBHEX ", job_id, uid, part.empty() ? "-" : part.c_str(), acct.c_str(), qos.empty() ? "-" : qos.c_str(), name.empty() ? "-" : name.c_str());
+      // every third job is an array child: JobToD.array_task (field 16), incl. the all-zero identity (still written: the field is set)
+      const GpuNodeSelectionAlgo::ArrayTaskIdentity at{(i % 9) ? (uint32_t)(rnd() % 100000) : 0u, (i % 9) ? (uint32_t)(rnd() % 1000) : 0u};
+      const bool is_child = (i % 3) == 0;
+      GpuNodeSelectionAlgo::ComposeJobToDWire(job_id, uid, part, acct, qos, name, wire, &jw, is_child ? &at : nullptr);
+      fprintf(f, "JOB %u %u %s %s %s %s\n", job_id, uid, part.empty() ? "-" : part.c_str(), acct.c_str(), qos.empty() ? "-" : qos.c_str(), name.empty() ? "-" : name.c_str());
+      if (is_child) fprintf(f, "ARRAY %u %u\n", at.array_job_id, at.task_id);
+      fprintf(f, "JOBHEX ");
       for (unsigned char c : jw) fprintf(f, "%02x", c);
       fprintf(f, "\n");
     }

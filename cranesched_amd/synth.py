@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .abi import Cluster, GresLayout, Jobs, MAX_GRES_CLASSES, MAX_GRES_NAMES
+from .abi import Cluster, GresLayout, Jobs, MAX_GRES_CLASSES, MAX_GRES_NAMES, Running
 
 NOW = 1_700_000_000
 SEED0 = 0x43524E45
@@ -24,6 +24,9 @@ CONFIGS = {
     "C3": dict(idx=3, J=1_000_000, N=16_384, P=1, gres=True, Q=600, LM=24),
     "C4": dict(idx=4, J=1_000_000, N=65_536, P=8, gres=True, Q=600, LM=24),
     "C5": dict(idx=5, J=1_000_000, N=65_536, P=8, gres=False, Q=675, LM=32),
+    # C4's cluster and job mix cut into 64 partitions of 1 024 nodes: the configuration on which more GPUs DO add chains
+    # (one GPU: 64 chains on k_pipe, one CU each; 8 GPUs: 8 chains per GPU on k_wide x64) — bench.py --config C4p64, DESIGN.md 6
+    "C4p64": dict(idx=6, J=1_000_000, N=65_536, P=64, gres=True, Q=600, LM=24),
 }
 
 
@@ -99,6 +102,95 @@ def make_config(name: str, J: int | None = None, N: int | None = None, P: int | 
     cluster = make_cluster(N, P, c["gres"])
     jobs = make_jobs(J, P, c["gres"], SEED0 ^ c["idx"], c["Q"], c["LM"])
     return cluster, jobs, NOW
+
+
+# Loaded-cluster ("steady state") variants: the same queue on a cluster that already RUNS jobs — the cycle CraneCtld
+# normally executes (running jobs folded in at JobScheduler.cpp:6513-6514,6681-6709; cycle-start res_avail, deep initial
+# time maps and non-zero initial costs, JobScheduler.h:301-338,498-511).  name -> (base config, running jobs)
+LOADED = {"C4r": ("C4", 300_000), "C2r": ("C2", 20_000), "C5r": ("C5", 300_000)}
+
+
+def make_running(cluster: Cluster, R: int, seed: int, now: int = NOW) -> Running:
+    """R running jobs, frozen like the queue (splitmix64 draws): each inside ONE partition, on k in {1 (80 %), 2, 4, 8}
+    distinct nodes, cpus in {1, 2, 4, 8} per node with 2 GiB per cpu, the lowest free core ids of the node at that point
+    (what GetFeasibleResourceInNode hands out), 1 or 2 of the node's free GRES slots with probability 1/4 where the node
+    has any; end times from 120 s in the past (clamped to now + 1 by the cycle, :6513-6514) to 10 h ahead in 60 s steps.
+    A draw that no longer fits its nodes is skipped (the node state is kept consistent: allocations never overlap)."""
+    ND = 8
+    r = (splitmix64(seed ^ 0x52554E, R * ND).reshape(R, ND) >> np.uint64(11)).astype(np.int64)
+    N, P = cluster.num_nodes, cluster.num_partitions
+    free_lo = cluster.core_lo.astype(object).copy()
+    free_hi = (cluster.core_hi if cluster.core_hi is not None else np.zeros(N, np.uint64)).astype(object).copy()
+    free_g = (cluster.gres_slots if cluster.gres_slots is not None else np.zeros(N, np.uint64)).astype(object).copy()
+    free_mem = cluster.mem_total.astype(object).copy()
+    po = cluster.part_offsets.astype(np.int64)
+    pn = cluster.part_nodes.astype(np.int64)
+    end, off, node, cpu, mem, lo, hi, g = [], [0], [], [], [], [], [], []
+    M64 = (1 << 64) - 1
+
+    def lowest(mask, n):
+        out = 0
+        for _ in range(n):
+            b = mask & -mask
+            out |= b
+            mask ^= b
+        return out
+
+    for i in range(R):
+        p = int(r[i, 0] % P)
+        cnt = int(po[p + 1] - po[p])
+        kd = int(r[i, 1] % 20)
+        k = 1 if kd < 16 else (2, 2, 4, 8)[kd - 16]
+        k = min(k, cnt)
+        cpus = (1, 2, 4, 8)[int(r[i, 2] % 4)]
+        first = int(r[i, 3] % cnt)
+        stride = 1 + int(r[i, 4] % 7)
+        nodes = sorted({int(pn[po[p] + (first + t * stride) % cnt]) for t in range(k)})
+        want_g = int(r[i, 5] % 8)           # 0, 1: one / two slots where the node has free ones
+        ok = all((bin(int(free_lo[n])).count("1") + bin(int(free_hi[n])).count("1")) >= cpus and int(free_mem[n]) >= cpus * 2 * GIB
+                 for n in nodes)
+        if not ok or len(nodes) == 0:
+            continue
+        for n in nodes:
+            full = int(free_lo[n]) | (int(free_hi[n]) << 64)
+            take = lowest(full, cpus)
+            tg = 0
+            if want_g < 2 and int(free_g[n]):
+                tg = lowest(int(free_g[n]), min(want_g + 1, bin(int(free_g[n])).count("1")))
+            free_lo[n] = int(free_lo[n]) & ~(take & M64)
+            free_hi[n] = int(free_hi[n]) & ~(take >> 64)
+            free_g[n] = int(free_g[n]) & ~tg
+            free_mem[n] = int(free_mem[n]) - cpus * 2 * GIB
+            node.append(n); cpu.append(cpus * 256); mem.append(cpus * 2 * GIB)
+            lo.append(take & M64); hi.append(take >> 64); g.append(tg)
+        off.append(len(node))
+        end.append(now - 120 + 60 * int(r[i, 6] % 602))
+    return Running(end_sec=np.array(end, np.int64), alloc_offsets=np.array(off, np.uint32), alloc_node=np.array(node, np.uint32),
+                   alloc_cpu_raw=np.array(cpu, np.int64), alloc_mem=np.array(mem, np.uint64), alloc_core_lo=np.array(lo, np.uint64),
+                   alloc_core_hi=np.array(hi, np.uint64), alloc_gres=np.array(g, np.uint64))
+
+
+def make_loaded(name: str, J: int | None = None, N: int | None = None, P: int | None = None, R: int | None = None):
+    """(cluster, jobs, now, running) of a loaded-cluster variant (LOADED), optionally scaled like make_config."""
+    base, r_full = LOADED[name]
+    cluster, jobs, now = make_config(base, J=J, N=N, P=P)
+    if R is None:
+        R = max(1, int(r_full * cluster.num_nodes / CONFIGS[base]["N"]))
+    return cluster, jobs, now, make_running(cluster, R, SEED0 ^ CONFIGS[base]["idx"], now)
+
+
+def running_of_partitions(cluster: Cluster, running: Running, parts: list[int]) -> Running:
+    """The running jobs whose nodes lie in `parts` (every job of make_running lives inside one partition), order kept."""
+    inpart = np.zeros(cluster.num_nodes, bool)
+    for p in parts:
+        inpart[np.asarray(cluster.part_nodes[cluster.part_offsets[p]:cluster.part_offsets[p + 1]], np.int64)] = True
+    o = running.alloc_offsets.astype(np.int64)
+    keep = np.nonzero(inpart[running.alloc_node[o[:-1]].astype(np.int64)])[0] if len(o) > 1 else np.zeros(0, np.int64)
+    cnt = (o[1:] - o[:-1])[keep]
+    idx = np.repeat(o[:-1][keep], cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+    return Running(end_sec=running.end_sec[keep], alloc_offsets=np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32),
+                   alloc_node=running.alloc_node[idx], alloc_cpu_raw=running.alloc_cpu_raw[idx], alloc_mem=running.alloc_mem[idx],
+                   alloc_core_lo=running.alloc_core_lo[idx], alloc_core_hi=running.alloc_core_hi[idx], alloc_gres=running.alloc_gres[idx])
 
 
 def make_limits(name: str, cluster: Cluster, jobs: Jobs):

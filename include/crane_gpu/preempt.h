@@ -19,6 +19,11 @@
  * and reservations are served together with it.  Candidates that
  * the reference's comparator leaves unordered (it sorts the iteration order of a hash set) are taken in ascending
  * index.  With `enabled == 0` the call is cns_select.
+ *
+ * Limits (exceeding one returns CNS_ERR_UNSUPPORTED with a message, never a device fault; the integrator then runs the
+ * CPU SchedulerAlgo for the cycle): per partition, candidate / chosen lists of max(4096, running + pending jobs)
+ * entries (capped so that all partitions together stay below 64 Mi entries) and a segment-tree pool of 65 536 nodes
+ * (one job's trees: about node_num x (entries of the nodes' time maps inside its window) x log2 of that).
  */
 #ifndef CRANE_GPU_PREEMPT_H
 #define CRANE_GPU_PREEMPT_H

@@ -527,6 +527,20 @@ class SchedOracle {
           A_.ckmin(min_res_on_node, res);
         }
         int ntasks_on_node_avail = get_max_tasks(min_res_on_node);
+        if (dbg_false_cand_ && !ntasks_on_node_avail) {
+          // (diagnostics for the engine's front filter: the entry at `now` alone would have admitted this node)
+          const Res& front = time_avail_res_map.begin()->second;
+          Res fr;
+          if (A_.feasible(min_res_view, front, &fr)) {
+            ++dbg_false_total_;
+            const MaskRes m = A_.to_mask(min_res_on_node), f = A_.to_mask(front);
+            const ReqView& v = min_res_view;
+            if (v.cpu > m.cpu) ++dbg_false_cpu_;
+            else if (v.mem > m.mem) ++dbg_false_mem_;
+            else if (__builtin_popcountll(m.gres) < __builtin_popcountll(f.gres)) ++dbg_false_gres_;
+            else ++dbg_false_cores_;
+          }
+        }
         if (ntasks_on_node_avail) {
           topk_ntasks_sum_avail += ntasks_on_node_avail;
           topk_nodes_avail.push(node_info{ntasks_on_node_avail, min_res_on_node, node_state});
@@ -936,6 +950,15 @@ class SchedOracle {
   std::vector<i64> resv_end_, first_resv_;
   std::vector<char> resv_live_;
   u64 jobs_ordered_ = 0;
+ public:
+  bool dbg_false_cand_ = getenv("ORA_DEBUG_FALSE_CAND") != nullptr;
+  u64 dbg_false_total_ = 0, dbg_false_cpu_ = 0, dbg_false_mem_ = 0, dbg_false_gres_ = 0, dbg_false_cores_ = 0;
+  ~SchedOracle() {
+    if (dbg_false_cand_)
+      fprintf(stderr, "oracle: nodes the front entry admits but the window minimum rejects: %llu (cpu %llu, mem %llu, gres %llu, core ids %llu)\n",
+              (unsigned long long)dbg_false_total_, (unsigned long long)dbg_false_cpu_, (unsigned long long)dbg_false_mem_,
+              (unsigned long long)dbg_false_gres_, (unsigned long long)dbg_false_cores_);
+  }
 };
 
 }  // namespace ora

@@ -31,3 +31,14 @@ def engine_cls(built, request, monkeypatch):
     monkeypatch.setenv("CNS_SELECT_KERNEL", request.param)
     from cranesched_amd.engine import GpuNodeSelector
     return GpuNodeSelector
+
+
+@pytest.fixture
+def engine_default(built):
+    """The engine class on its default selection kernel: for the kernels that never read CNS_SELECT_KERNEL (run limits,
+    MultiFactorPriority, step scheduler) — running those under four settings only repeated the same case four times."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cranesched_amd.engine import GpuNodeSelector
+    return GpuNodeSelector

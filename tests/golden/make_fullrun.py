@@ -27,12 +27,19 @@ from tests import fullrun  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def load_case(name, J=None, N=None, P=None):
+    """(cluster, jobs, now, running or None) of a CASES entry: a frozen config, or its loaded-cluster variant (synth.LOADED)."""
+    if name in synth.LOADED:
+        return synth.make_loaded(name, J=J, N=N, P=P)
+    return (*synth.make_config(name, J=J, N=N, P=P), None)
+
+
 def _one_partition(args):
     name, J, N, P, p = args
     from oracle import pyoracle
-    cluster, jobs, now = synth.make_config(name, J=J, N=N, P=P)
+    cluster, jobs, now, running = load_case(name, J, N, P)
     sub, idx = synth.select_partitions(cluster, jobs, [p])
-    r = pyoracle.select(cluster, sub, now)
+    r = pyoracle.select(cluster, sub, now, running=None if running is None else synth.running_of_partitions(cluster, running, [p]))
     lo, hi = int(cluster.part_offsets[p]), int(cluster.part_offsets[p + 1])
     nodes = [int(n) for n in fullrun.timeline_nodes(cluster.num_nodes) if lo <= n < hi]  # contiguous partitions (synth)
     assert np.array_equal(cluster.part_nodes[lo:hi], np.arange(lo, hi))
@@ -53,12 +60,15 @@ CASES = {
     "c5deep": ("C5", None, 16_384, 8),
     "tile1": ("C3", 6_000, 380, 1), "tile3": ("C3", 18_000, 1_100, 1), "tile10": ("C3", 65_000, 4_100, 1),
     "tile19": ("C3", 130_000, 8_192, 1), "tile28": ("C3", 160_000, 10_000, 1), "tile37": ("C3", 200_000, 13_000, 1),
+    # the cycle CraneCtld normally runs: the same 1 M-job queue on a cluster that already RUNS 300 k jobs (480 k allocations:
+    # cycle-start res_avail != res_total, initial time maps of up to ~30 entries, non-zero initial costs; synth.make_running)
+    "c4r": ("C4r", None, None, None),
 }
 
 
 def merge_parts(name, J, N, P, parts):
     """Scatters per-partition oracle results (tuples of _one_partition) back into one full result."""
-    cluster, jobs, now = synth.make_config(name, J=J, N=N, P=P)
+    cluster, jobs, now, _ = load_case(name, J, N, P)
     Pn = cluster.num_partitions
     full = abi.Placements(jobs.num_jobs, jobs.total_places())
     off = np.concatenate([[0], np.cumsum(jobs.node_num.astype(np.int64))])
@@ -82,7 +92,7 @@ def merge_parts(name, J, N, P, parts):
 
 def merged_run(name, J=None, N=None, P=None, procs=None):
     """(cluster, jobs, Placements, costs_u64, timelines, seconds per partition), one oracle process per partition."""
-    Pn = P or synth.CONFIGS[name]["P"]
+    Pn = P or synth.CONFIGS[synth.LOADED.get(name, (name,))[0]]["P"]
     with mp.get_context("fork").Pool(procs or min(Pn, os.cpu_count() or 1)) as pool:
         parts = pool.map(_one_partition, [(name, J, N, P, p) for p in range(Pn)], chunksize=1)
     return merge_parts(name, J, N, P, parts)
@@ -93,7 +103,7 @@ def main(tags):
     work = []
     for tag in tags:
         name, J, N, P = CASES[tag]
-        work += [(tag, (name, J, N, P, p)) for p in range(P or synth.CONFIGS[name]["P"])]
+        work += [(tag, (name, J, N, P, p)) for p in range(P or synth.CONFIGS[synth.LOADED.get(name, (name,))[0]]["P"])]
     with mp.get_context("fork").Pool(min(len(work), os.cpu_count() or 1)) as pool:
         results = pool.map(_one_partition, [w[1] for w in work], chunksize=1)
     for tag in tags:

@@ -13,16 +13,18 @@ from tests.golden import make_fullrun
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name,J,N,P", [("C4", 24000, 2048, 8), ("C5", 12000, 512, 4)])
+@pytest.mark.parametrize("name,J,N,P", [("C4", 24000, 2048, 8), ("C5", 12000, 512, 4), ("C4r", 24000, 2048, 8)])
 def test_partition_merge_equals_single_run(built, name, J, N, P):
     from oracle import pyoracle
     cluster, jobs, full, costs, timelines, _ = make_fullrun.merged_run(name, J=J, N=N, P=P, procs=2)
-    ref = pyoracle.select(cluster, jobs, synth.NOW)
+    running = make_fullrun.load_case(name, J, N, P)[3]   # (C4r: the loaded cluster's running jobs, split by partition in the merge)
+    ref = pyoracle.select(cluster, jobs, synth.NOW, running=running)
     assert full.diff(ref.placements) is None
     a = fullrun.digest(full, costs, lambda n: timelines[n], cluster.num_nodes)
     b = fullrun.digest(ref.placements, ref.costs().view(np.uint64), ref.timeline, cluster.num_nodes)
     assert fullrun.compare(a, b) is None
-    assert (ref.placements.reason[:J] == 1).sum() > J // 20, "case must exercise backfill"
+    # (a later start is "Priority", or "Resource" when the allocation exceeds the cycle-start res_avail: loaded clusters)
+    assert (ref.placements.start_sec[:J] > synth.NOW).sum() > J // 20, "case must exercise backfill"
 
 
 @pytest.mark.parametrize("tag", list(make_fullrun.CASES))
@@ -33,9 +35,11 @@ def test_committed_digests_well_formed(tag):
     assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
     d = np.load(path)
     name, J, N, P = make_fullrun.CASES[tag]
-    J = J or synth.CONFIGS[name]["J"]
-    assert int(d["jobs"][0]) == J and int(d["nodes"][0]) == (N or synth.CONFIGS[name]["N"])
+    base = synth.LOADED.get(name, (name,))[0]
+    J = J or synth.CONFIGS[base]["J"]
+    assert int(d["jobs"][0]) == J and int(d["nodes"][0]) == (N or synth.CONFIGS[base]["N"])
     assert len(d["chunk_crc"]) == (J + fullrun.CHUNK - 1) // fullrun.CHUNK
     assert int(d["counts"].sum()) == J
     if tag != "c5":  # the frozen C5 queue does not fill its 64 k nodes (see make_fullrun.CASES["c5deep"])
-        assert d["counts"][1] >= J // 5, "the queue must reach the backfill regime (>= 20 % backfilled)"
+        # later starts: "Priority", or "Resource" with a start time on a loaded cluster (allocation > cycle-start res_avail)
+        assert d["counts"][1] + (d["counts"][2] if name in synth.LOADED else 0) >= J // 5, "the queue must reach the backfill regime (>= 20 % backfilled)"

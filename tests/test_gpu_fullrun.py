@@ -10,7 +10,7 @@ import pytest
 
 from cranesched_amd import synth
 from tests import fullrun
-from tests.golden.make_fullrun import CASES
+from tests.golden.make_fullrun import CASES, load_case
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -24,10 +24,12 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
     assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
     ref = dict(np.load(path))
     name, J, N, P = CASES[tag]
-    cluster, jobs, now = synth.make_config(name, J=J, N=N, P=P)
+    cluster, jobs, now, running = load_case(name, J, N, P)
     eng = engine_cls(device=0)
     try:
         eng.set_nodes(cluster)
+        if running is not None:
+            eng.set_running(running)
         got = eng.node_select(now, jobs)
         d = fullrun.digest(got, eng.costs().view(np.uint64), eng.timeline, cluster.num_nodes)
         msg = fullrun.compare(d, ref)

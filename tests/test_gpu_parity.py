@@ -106,3 +106,32 @@ def test_wide_multi_node_jobs(engine_cls, seed):
     got, _ = _run(engine_cls, c, j, now, running=run, tag=f"wide{seed}")
     r = got.reason[:j.num_jobs]
     assert ((r == 0) & wide).sum() > 10 and ((r == 1) & wide).sum() > 10, "wide jobs must start now and backfill"
+
+
+def test_wide_protocol_fault_is_retried_on_the_single_workgroup_kernels(built, monkeypatch):
+    """k_wide's workgroups wait for each other; every wait is bounded and ends in a device fault.  Such a fault says
+    nothing about the input: the cycle is re-run on k_pipe / k_select (one workgroup per partition, no co-residency
+    needed) and the caller gets the exact result.  The hook makes the leader scanner of partition 0 drop its granules of
+    one exchange, so that every other wave's wait really runs out (fault 28 after ~2 s)."""
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    monkeypatch.setenv("CNS_SELECT_KERNEL", "wide")
+    c, j, now = synth.make_config("C4", J=6000, N=1024, P=8)
+    ref = pyoracle.select(c, j, now)
+    eng = GpuNodeSelector(device=0)
+    try:
+        eng.set_nodes(c)
+        got = eng.node_select(now, j)
+        assert eng.last_kernel().startswith("k_wide") and "retry" not in eng.last_kernel()
+        helpers.assert_same(eng, got, ref, c, tag="before the stall")
+        monkeypatch.setenv("CNS_WIDE_INJECT_STALL", "137")
+        got = eng.node_select(now, j)
+        k = eng.last_kernel()
+        assert not k.startswith("k_wide") and "retry after" in k and "code 2" in k, k
+        helpers.assert_same(eng, got, ref, c, tag="retried after the injected stall")
+        monkeypatch.delenv("CNS_WIDE_INJECT_STALL")
+        got = eng.node_select(now, j)
+        assert eng.last_kernel().startswith("k_wide") and "retry" not in eng.last_kernel()   # the next cycle is back on k_wide
+        helpers.assert_same(eng, got, ref, c, tag="after the stall")
+    finally:
+        eng.close()

@@ -101,8 +101,8 @@ def test_priority_abi_symbols():
 
 # ---- GPU parity ------------------------------------------------------------------------------------------
 
-def _gpu_vs_oracle(engine_cls, cfg, A, pd, rn, now, limit=None):
-    eng = engine_cls(device=0)
+def _gpu_vs_oracle(engine_default, cfg, A, pd, rn, now, limit=None):
+    eng = engine_default(device=0)
     try:
         order, prio, nord = eng.priority_order(now, cfg, A, pd, rn, limit=limit)
         ro, rp = pyoracle.priority_order(now, cfg, A, pd, rn)
@@ -115,26 +115,26 @@ def _gpu_vs_oracle(engine_cls, cfg, A, pd, rn, now, limit=None):
 
 
 @pytest.mark.gpu
-def test_gpu_priority_kat(engine_cls):
+def test_gpu_priority_kat(engine_default):
     cfg, pd, rn = _kat()
-    _gpu_vs_oracle(engine_cls, cfg, 2, pd, rn, NOW)
+    _gpu_vs_oracle(engine_default, cfg, 2, pd, rn, NOW)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("J,R,A,seed,cached", [(1, 0, 1, 1, 0.0), (257, 3, 2, 2, 0.0), (4097, 1000, 64, 3, 0.2),
                                                (100_000, 20_000, 300, 4, 0.05), (50_000, 0, 10, 5, 0.0)])
-def test_gpu_priority_random(engine_cls, J, R, A, seed, cached):
+def test_gpu_priority_random(engine_default, J, R, A, seed, cached):
     pd, rn, now = synth_priority_case(J, R, A, seed, cached_frac=cached)
     for cfg in (PriorityConfig(), PriorityConfig(favor_small=False, weight_job_size=777, weight_age=3)):
-        _gpu_vs_oracle(engine_cls, cfg, A, pd, rn if R else None, now, limit=J // 2 + 1)
+        _gpu_vs_oracle(engine_default, cfg, A, pd, rn if R else None, now, limit=J // 2 + 1)
 
 
 @pytest.mark.gpu
-def test_gpu_priority_all_equal(engine_cls):
+def test_gpu_priority_all_equal(engine_default):
     J = 10_000   # one priority value for everybody: the stable radix sort must return the identity
     pd = PrioPending(submit_sec=[NOW - 5] * J, qos_priority=[1] * J, partition_priority=[1] * J, node_num=[1] * J,
                      total_cpu_raw=[256] * J, total_mem=[GIB] * J, account=[0] * J)
-    eng = engine_cls(device=0)
+    eng = engine_default(device=0)
     try:
         order, prio, _ = eng.priority_order(NOW, PriorityConfig(), 1, pd, None)
         assert order.tolist() == list(range(J))
@@ -143,11 +143,11 @@ def test_gpu_priority_all_equal(engine_cls):
 
 
 @pytest.mark.gpu
-def test_gpu_priority_full_size(engine_cls):
+def test_gpu_priority_full_size(engine_default):
     # 1 M pending jobs (the benchmark queue length): sortedness + permutation + tie order, and a sample vs the oracle
     J, R, A = 1_000_000, 100_000, 256
     pd, rn, now = synth_priority_case(J, R, A, seed=9)
-    t = _gpu_vs_oracle(engine_cls, PriorityConfig(), A, pd, rn, now)
+    t = _gpu_vs_oracle(engine_default, PriorityConfig(), A, pd, rn, now)
     assert t["kernels_ms"] > 0
 
 

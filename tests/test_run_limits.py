@@ -295,8 +295,8 @@ def mode(request, monkeypatch):
     return request.param
 
 
-def _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, tag="", expect_fallback=None):
-    eng = engine_cls(device=0)
+def _gpu_vs_oracle(engine_default, cluster, jobs, now, lay, t, lj, tag="", expect_fallback=None):
+    eng = engine_default(device=0)
     try:
         eng.set_nodes(cluster)
         got = eng.node_select(now, jobs)
@@ -326,21 +326,21 @@ def _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, tag="", expect_fa
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
-def test_gpu_kat(engine_cls, name, mode):
+def test_gpu_kat(engine_default, name, mode):
     specs, keys, ua, t, exp, extra = SCENARIOS[name]()
     cluster, lay = _cluster()
     jobs = kat.jobs(specs)
     lj = _limjobs(keys, ua, jobs.time_limit_sec)
-    reason, usage = _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, name, expect_fallback=mode == "ordered")
+    reason, usage = _gpu_vs_oracle(engine_default, cluster, jobs, NOW, lay, t, lj, name, expect_fallback=mode == "ordered")
     assert list(reason) == exp
     _check_extra(usage, extra)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,tight", [(1, True), (2, True), (3, True), (4, False), (5, True), (6, False)])
-def test_gpu_random(engine_cls, seed, tight, mode):
+def test_gpu_random(engine_default, seed, tight, mode):
     cluster, jobs, now, lay, t, lj = random_limit_case(seed, J=900, N=128, tight=tight)
-    _gpu_vs_oracle(engine_cls, cluster, jobs, now, lay, t, lj, f"seed {seed}", expect_fallback=mode == "ordered")
+    _gpu_vs_oracle(engine_default, cluster, jobs, now, lay, t, lj, f"seed {seed}", expect_fallback=mode == "ordered")
 
 
 def dependency_chain_case(n=200):
@@ -367,24 +367,24 @@ def test_oracle_dependency_chain():
 
 
 @pytest.mark.gpu
-def test_gpu_dependency_chain_falls_back_to_ordered_kernel(engine_cls, monkeypatch):
+def test_gpu_dependency_chain_falls_back_to_ordered_kernel(engine_default, monkeypatch):
     monkeypatch.delenv("CNS_LIMITS_MODE", raising=False)
     cluster, jobs, lay, t, lj = dependency_chain_case(200)
-    reason, _ = _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, "chain", expect_fallback=True)
+    reason, _ = _gpu_vs_oracle(engine_default, cluster, jobs, NOW, lay, t, lj, "chain", expect_fallback=True)
     assert list(reason[:4]) == [0, 11, 0, 11]
     cluster, jobs, lay, t, lj = dependency_chain_case(40)        # short chain: the rounds finish it
-    _gpu_vs_oracle(engine_cls, cluster, jobs, NOW, lay, t, lj, "short chain", expect_fallback=False)
+    _gpu_vs_oracle(engine_default, cluster, jobs, NOW, lay, t, lj, "short chain", expect_fallback=False)
 
 
 @pytest.mark.gpu
-def test_gpu_state_and_argument_checks(engine_cls):
+def test_gpu_state_and_argument_checks(engine_default):
     from cranesched_amd.engine import EngineError
     cluster, lay = _cluster()
     jobs = kat.jobs([dict(cpu=1)] * 3)
     ua = [(0, 0)]
     t = _tables([lm.qos_limits()], [NONE], 1, ua)
     lj = _limjobs([(0, 0, 0)] * 3, ua, jobs.time_limit_sec)
-    eng = engine_cls(device=0)
+    eng = engine_default(device=0)
     try:
         with pytest.raises(EngineError):      # the GRES layout arrives with the nodes
             eng.set_run_limits(t)

@@ -167,9 +167,9 @@ def test_steps_abi_symbols(built):
 
 
 # ---------------------------------------------------------------- GPU ----------------------------------------------------
-def _gpu(engine_cls, lay, jobs, steps):
+def _gpu(engine_default, lay, jobs, steps):
     from tests import kat
-    eng = engine_cls(device=0)
+    eng = engine_default(device=0)
     try:
         eng.set_nodes(kat.cluster([4], layout=lay))      # the handle's GRES layout comes with a node table
         got, ms = eng.schedule_steps(jobs, steps)
@@ -182,24 +182,24 @@ def _gpu(engine_cls, lay, jobs, steps):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(SCENARIOS))
-def test_gpu_kat(engine_cls, name):
+def test_gpu_kat(engine_default, name):
     jobs, steps, exp = SCENARIOS[name]()
-    _check(_gpu(engine_cls, abi.GresLayout(), jobs, steps), exp)
+    _check(_gpu(engine_default, abi.GresLayout(), jobs, steps), exp)
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
-def test_gpu_random(engine_cls, seed):
+def test_gpu_random(engine_default, seed):
     lay, jobs, steps = random_step_case(seed, J=2000 if seed == 3 else 300)
-    _gpu(engine_cls, lay, jobs, steps)
+    _gpu(engine_default, lay, jobs, steps)
 
 
 @pytest.mark.gpu
-def test_gpu_argument_checks(engine_cls):
+def test_gpu_argument_checks(engine_default):
     from cranesched_amd.engine import EngineError
     from tests import kat
     jobs, steps, _ = scenario_fifo()
-    eng = engine_cls(device=0)
+    eng = engine_default(device=0)
     try:
         with pytest.raises(EngineError):     # the GRES layout arrives with the nodes
             eng.schedule_steps(jobs, steps)

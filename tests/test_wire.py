@@ -56,6 +56,10 @@ def _messages():
     field(j, "account", 6, F.TYPE_STRING)
     field(j, "qos", 7, F.TYPE_STRING)
     field(j, "name", 9, F.TYPE_STRING)
+    at = msg("ArrayTaskIdentity")                      # PublicDefs.proto:161-164
+    field(at, "array_job_id", 1, F.TYPE_UINT32)
+    field(at, "task_id", 2, F.TYPE_UINT32)
+    f16 = field(j, "array_task", 16, F.TYPE_MESSAGE, type_name=".crane.grpc.t.ArrayTaskIdentity")   # `optional ArrayTaskIdentity array_task = 16`
     pool = descriptor_pool.DescriptorPool()
     pool.Add(fd)
     get = getattr(message_factory, "GetMessageClass", None)
@@ -82,7 +86,7 @@ def _records(path):
         elif tag == "GRES":
             name, typ, *slots = rest.split()
             rec["gres"].setdefault(name, {})[typ] = slots
-        elif tag in ("JOB", "JOBHEX"):
+        elif tag in ("JOB", "JOBHEX", "ARRAY"):
             rec["extra"][tag] = rest
         elif tag == "END":
             yield rec
@@ -122,7 +126,7 @@ def test_job_to_d_wire(built, tmp_path):
     out = tmp_path / "jobtod.txt"
     r = subprocess.run([EXE, "--wire-dump", str(out), "60", "jobtod"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    n = 0
+    n = children = 0
     for rec in _records(out):
         if "JOBHEX" not in rec["extra"]:
             continue
@@ -135,5 +139,11 @@ def test_job_to_d_wire(built, tmp_path):
         assert (m.partition, m.account, m.qos, m.name) == (undash(part), acct, undash(qos), undash(name))
         assert m.res.SerializeToString(deterministic=True) == rec["wire"]
         assert m.SerializeToString(deterministic=True) == raw
+        if "ARRAY" in rec["extra"]:        # array children carry their identity (CtldPublicDefs.cpp:547-551), others no field 16 at all
+            aj, at = map(int, rec["extra"]["ARRAY"].split(" "))
+            assert m.HasField("array_task") and (m.array_task.array_job_id, m.array_task.task_id) == (aj, at)
+            children += 1
+        else:
+            assert not m.HasField("array_task")
         n += 1
-    assert n == 60
+    assert n == 60 and children == 20

@@ -12,9 +12,16 @@ name = sys.argv[1] if len(sys.argv) > 1 else "C4"
 J = int(sys.argv[2]) if len(sys.argv) > 2 else None
 N = int(sys.argv[3]) if len(sys.argv) > 3 else None
 P = int(sys.argv[4]) if len(sys.argv) > 4 else None
-c, j, now = synth.make_config(name, J=J, N=N, P=P)
+running = None
+if name in synth.LOADED:
+    c, j, now, running = synth.make_loaded(name, J=J, N=N, P=P)
+else:
+    c, j, now = synth.make_config(name, J=J, N=N, P=P)
 e = GpuNodeSelector()
-e.set_nodes(c); e.upload_jobs(j); e.run_resident(now)
+e.set_nodes(c)
+if running is not None:
+    e.set_running(running)
+e.upload_jobs(j); e.run_resident(now)
 t = e.timing(); pr = e.prof().astype(np.float64)
 jobs = j.num_jobs / c.num_partitions
 m = pr.mean(axis=0)
@@ -30,6 +37,9 @@ for k, v in rows.items():
 if m[0]:
     print(f"  leader, node_num > 1: {m[0]:.0f} jobs; per such job: lists {m[1]/m[0]:.0f}, exchange wait {m[2]/m[0]:.0f}, vote {m[3]/m[0]:.0f} cycles; "
           f"{m[4]:.0f} second exchanges at {m[5]/max(m[4],1):.0f} cycles; {m[7]/max(m[0]+m[4],1):.2f} polls per list exchange")
+ws = e.wide_stats()
+print(f"  always-on counters (every build): {ws}; jobs per consuming look {j.num_jobs/max(ws['looks_consumed'],1):.2f}; "
+      f"leader polls in front of a full ring per job {ws['leader_polls_ring_full']/j.num_jobs:.2f}")
 print(f"  leader polls {m[13]:.0f} ({m[13]/max(m[20],1):.2f} per job)")
 print(f"  leader jobs {m[20]:.0f}; supervisor: consumed {m[24]:.0f}, empty polls {m[27]:.0f}, stops {m[25]:.0f}, flushes {m[29]:.0f}")
 if m[15]:
