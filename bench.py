@@ -18,9 +18,12 @@ than the whole chain does now).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (k_wide; k_pipe / k_select when CNS_SELECT_KERNEL=pipe / legacy) with the ALGORITHMIC
 bytes of SURVEY.md §8(d) (N_p*S_node + S_job + S_out per decision) over its HIP-event duration;
-`cpu_baseline` times the CPU oracle (a port of the reference algorithm; the reference itself cannot
-be built offline) on ONE WHOLE PARTITION of the same queue (partitions never interact), single pinned
-thread like the reference, and diffs its placements against the engine's.
+`cpu_baseline` times the CPU oracle (kind "port": a restatement of the reference algorithm on bit masks, pinned to the
+reference's own code by tests/test_ref_pin.py) on ONE WHOLE PARTITION of the same queue (partitions never interact), single
+pinned thread like the reference, and diffs its placements against the engine's; `cpu_baseline.reference_build` times THE
+REFERENCE'S OWN CODE (oracle/_ref: slices of JobScheduler.{h,cpp} / PublicHeader.{h,cpp} compiled in the build container and
+shipped prebuilt) on a bounded prefix of that partition's queue (its whole-partition figures: profiles/r03_ref_vs_oracle_fullsize.txt).
+--config C4r / C2r / C5r: the same queue on a cluster that already runs jobs (the cycle CraneCtld normally executes).
 """
 from __future__ import annotations
 
@@ -280,10 +283,17 @@ def main():
             # reference build is in profiles/r03_ref_vs_oracle_fullsize.txt.
             ref_build = None
             if pyoracle.ref_available() and not args.cpu_sample_jobs:
-                n_pre = min(sub.num_jobs, 6000)
-                pre_cfg = synth.make_config(base_cfg, J=int(idx[n_pre - 1]) + 1, N=args.nodes)[1]
-                pre_sub, pre_idx = synth.select_partitions(cluster, pre_cfg, [p0])
-                rb = pyoracle.select(cluster, pre_sub, now, running=run_p0, backend="ref")
+                # the prefix grows until the reference build has worked for ~10 s (its cost per decision rises steeply once the
+                # partition fills: a longer prefix is predicted from the last one and not started if it would pass ~30 s)
+                n_pre, rb = min(sub.num_jobs, 6000), None
+                while True:
+                    pre_cfg = synth.make_config(base_cfg, J=int(idx[n_pre - 1]) + 1, N=args.nodes)[1]
+                    pre_sub, pre_idx = synth.select_partitions(cluster, pre_cfg, [p0])
+                    rb = pyoracle.select(cluster, pre_sub, now, running=run_p0, backend="ref")
+                    nxt = min(sub.num_jobs, int(n_pre * 1.5))
+                    if rb.seconds >= 10.0 or nxt == n_pre or rb.seconds * (nxt / n_pre) ** 3 > 30.0:
+                        break
+                    n_pre = nxt
                 rp = pyoracle.select(cluster, pre_sub, now, running=run_p0)
                 same_pre = rb.placements.diff(rp.placements) is None and bool(np.array_equal(rb.placements.start_sec[:pre_sub.num_jobs], got.start_sec[pre_idx]))
                 ref_build = {"value": pre_sub.num_jobs / rb.seconds, "unit": "decisions/s", "cores": 1, "kind": "reference",

@@ -58,6 +58,8 @@ struct cns_engine {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipStream_t stream2 = nullptr;                // second launch of a split cycle (the partitions that need k_select), beside the first
+  hipEvent_t ev2[2] = {nullptr, nullptr};
   std::string err;
 
   // cluster (host copies)
@@ -103,6 +105,10 @@ struct cns_engine {
   cns_timing timing{};
   std::string last_kernel;
   i64 last_now = 0;
+  std::vector<u32> eng_members;                 // engine partition -> number of caller partitions it runs (> 1: they share nodes)
+  std::vector<u32> job_part;                    // pending job (queue index) -> engine partition (kNone: not given to the ordered loop)
+  std::vector<uint8_t> pre_part;                // cycle with preemption: engine partition has a pending job whose qos may preempt
+  DevBuf d_params2, d_pmap_a, d_pmap_b;
   bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
   u32 wide_retries = 0;                         // cycles that were re-run on k_pipe / k_select after a k_wide fault (lifetime of the handle)
   // MultiFactorPriority (priority_host.inc)
@@ -232,29 +238,39 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   }
 }
 
+// One launch of a cycle: the partitions it serves (all of them, or the part_map of K), its stream and its copy of the
+// parameter block in HBM (the out-of-line routines read that one).
+struct LaunchCtx {
+  u32 nparts;            // partitions of this launch
+  u32 max_np;            // widest of them (slots)
+  hipStream_t stream;
+  const KParams* dparams;
+  u32 other_blocks;      // workgroups of the cycle's other launch (they hold CUs while k_wide needs all of its own resident)
+};
 template <int NPL>
-void launch_select(cns_engine* h, const KParams& K) {
-  hipLaunchKernelGGL((k_select<NPL>), dim3(h->P), dim3(kBlock), 0, h->stream, K, h->d_params.as<KParams>());
+void launch_select(cns_engine* h, const KParams& K, const LaunchCtx& L) {
+  hipLaunchKernelGGL((k_select<NPL>), dim3(L.nparts), dim3(kBlock), 0, L.stream, K, L.dparams);
 }
 template <int NPL>
-void launch_pipe(cns_engine* h, const KParams& K) {
-  hipLaunchKernelGGL((k_pipe<NPL>), dim3(h->P), dim3(kPBlock), 0, h->stream, K, h->d_params.as<KParams>());
+void launch_pipe(cns_engine* h, const KParams& K, const LaunchCtx& L) {
+  hipLaunchKernelGGL((k_pipe<NPL>), dim3(L.nparts), dim3(kPBlock), 0, L.stream, K, L.dparams);
 }
 // k_wide: 1 + 8 (or 1 + 16) workgroups per partition; the workgroups of a partition share blockIdx % 8 (= the XCD, observed).
 // A pad of dynamic LDS keeps it at one workgroup per CU (one scanner wave per SIMD is the point of the kernel).
 template <class W>
-int launch_wide(cns_engine* h, const KParams& K, u32 np, std::string* name) {
+int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string* name) {
+  const u32 np = L.max_np;
   const char* kname = "";
   const void* fn = W::pick(np, &kname);
   if (!fn) return 2;
-  const unsigned groups = (h->P + 7u) / 8u;
+  const unsigned groups = (L.nparts + 7u) / 8u;
   const unsigned grid = 8u * groups * W::group;
   const size_t need = (size_t)h->P * W::ctl_bytes;
   if (h->d_wide.ensure(need) != hipSuccess) return 1;
-  if (hipMemsetAsync(h->d_wide.p, 0, need, h->stream) != hipSuccess) return 1;
+  if (hipMemsetAsync(h->d_wide.p, 0, need, L.stream) != hipSuccess) return 1;
   KParams K2 = K;
   K2.wide_ctl = h->d_wide.as<char>();
-  if (hipMemcpyAsync(&h->d_params.as<KParams>()->wide_ctl, &K2.wide_ctl, sizeof(char*), hipMemcpyHostToDevice, h->stream) != hipSuccess) return 1;
+  if (hipMemcpyAsync(&const_cast<KParams*>(L.dparams)->wide_ctl, &K2.wide_ctl, sizeof(char*), hipMemcpyHostToDevice, L.stream) != hipSuccess) return 1;
   size_t dyn = 0;
   hipFuncAttributes fa;
   if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes < 84u * 1024u) {
@@ -266,10 +282,10 @@ int launch_wide(cns_engine* h, const KParams& K, u32 np, std::string* name) {
   // cover the grid — else the launch is refused here and the cycle runs on k_pipe / k_select, which need no co-residency.
   int per_cu = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, (int)W::block, dyn) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
-  if (per_cu < 1 || (u64)per_cu * h->num_cus < grid) return 2;
-  const KParams* dparams = h->d_params.as<KParams>();
+  if (per_cu < 1 || (u64)per_cu * h->num_cus < (u64)grid + L.other_blocks) return 2;
+  const KParams* dparams = L.dparams;
   void* args[2] = {(void*)&K2, (void*)&dparams};
-  if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, h->stream) != hipSuccess) return 1;
+  if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, L.stream) != hipSuccess) return 1;
   *name = std::string(kname) + (W::waves == 64 ? " x64" : " x32");   // (x64: cns::w64::k_wide in a profile, x32: cns::w32::k_wide)
   return 0;
 }
@@ -284,26 +300,55 @@ int launch_wide(cns_engine* h, const KParams& K, u32 np, std::string* name) {
 // k_wide (many CUs per partition) when every workgroup of the launch can be resident at once and the partitions fit its tile:
 // 64 scanner waves per partition (17 workgroups) for up to 8 partitions, 32 (9 workgroups) for up to 24.  Returns 0 / 32 / 64.
 // CNS_SELECT_KERNEL=wide32 forces the 32-wave build (A/B measurements, and the parity tests run both).
-u32 use_wide_kernel(const cns_engine* h) {
+// (for a launch over partitions that neither share nodes nor run with preemption: the others go to k_select)
+u32 use_wide_kernel(const cns_engine* h, const LaunchCtx& L) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_WIDE != 0;
   if (e && (!strcmp(e, "legacy") || !strcmp(e, "pipe"))) want = false;
   const bool only32 = e && !strcmp(e, "wide32");
   if (e && (!strcmp(e, "wide") || only32)) want = true;
-  if (!want || h->shared || h->wide_off) return 0;
+  if (!want || h->wide_off) return 0;
   // every workgroup of the launch must be resident at once, one per CU (a partitioned or smaller device falls to k_pipe)
-  const u32 groups = (h->P + 7u) / 8u;
-  auto fits = [&](u32 wgs_per_part) { return h->num_cus != 0 && 8u * groups * wgs_per_part <= h->num_cus; };   // (unknown CU count: no proof of co-residency, no k_wide)
-  if (!only32 && h->P <= w64::WideInfo::max_parts && h->max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max && fits(w64::WideInfo::group)) return 64;
-  if (h->P <= w32::WideInfo::max_parts && h->max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max && fits(w32::WideInfo::group)) return 32;
+  const u32 groups = (L.nparts + 7u) / 8u;
+  auto fits = [&](u32 wgs_per_part) { return h->num_cus != 0 && 8u * groups * wgs_per_part + L.other_blocks <= h->num_cus; };   // (unknown CU count: no proof of co-residency, no k_wide)
+  if (!only32 && L.nparts <= w64::WideInfo::max_parts && L.max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max && fits(w64::WideInfo::group)) return 64;
+  if (L.nparts <= w32::WideInfo::max_parts && L.max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max && fits(w32::WideInfo::group)) return 32;
   return 0;
 }
-bool use_pipe_kernel(const cns_engine* h) {
+bool use_pipe_kernel(const cns_engine* h, const LaunchCtx& L) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_PIPE != 0;
   if (e && !strcmp(e, "legacy")) want = false;
   if (e && (!strcmp(e, "pipe") || !strcmp(e, "wide") || !strcmp(e, "wide32"))) want = true;
-  return want && !h->shared && h->max_np <= kPScan * (u32)kPNplMax;   // (shared nodes: k_select's sequential protocol)
+  return want && L.max_np <= kPScan * (u32)kPNplMax;
+}
+// One launch: k_wide / k_pipe where the partitions allow it (`plain`: none of them shares nodes or runs with preemption), else
+// k_select.  0 ok (kernel name in *name), else a status for fail().
+int launch_one(cns_engine* h, const KParams& K, const LaunchCtx& L, bool plain, std::string* name, std::string* err) {
+  const u32 np = L.max_np;
+#ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
+  if (np > kScan * CNS_ONLY_NPL) { *err = "experiment build: partition too large for its one tile width"; return CNS_ERR_UNSUPPORTED; }
+  launch_select<CNS_ONLY_NPL>(h, K, L);
+  *name = "k_select";
+  return 0;
+#else
+  bool launched = false;
+  if (const u32 ww = plain ? use_wide_kernel(h, L) : 0u) {
+    const int rc = ww == 64 ? launch_wide<w64::WideInfo>(h, K, L, name) : launch_wide<w32::WideInfo>(h, K, L, name);
+    if (rc == 1) { *err = "k_wide: control block allocation / upload / launch failed"; return CNS_ERR_HIP; }
+    launched = rc == 0;
+  }
+  if (!launched && plain && use_pipe_kernel(h, L)) {
+#define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K, L); launched = true; *name = "k_pipe<" #w ">"; }
+    CNS_PNPL_LIST(CNS_TRY_PWIDTH)
+#undef CNS_TRY_PWIDTH
+  }
+#define CNS_TRY_WIDTH(w) if (!launched && np <= kScan * (w)) { launch_select<w>(h, K, L); launched = true; *name = "k_select<" #w ">"; }
+  CNS_NPL_LIST(CNS_TRY_WIDTH)
+#undef CNS_TRY_WIDTH
+  if (!launched) { *err = "partition too large for the widest register tile"; return CNS_ERR_UNSUPPORTED; }
+  return 0;
+#endif
 }
 
 // Everything that depends on the slot list (real + virtual): per-slot res_total / time-map end, node types
@@ -435,6 +480,12 @@ int cns_create(const cns_config* cfg, cns_handle** out) {
       cns_destroy(h);
       return fail(nullptr, CNS_ERR_HIP, "hipEventCreate: " + m);
     }
+  if ((e = hipStreamCreate(&h->stream2)) != hipSuccess || (e = hipEventCreateWithFlags(&h->ev2[0], hipEventDisableTiming)) != hipSuccess ||
+      (e = hipEventCreateWithFlags(&h->ev2[1], hipEventDisableTiming)) != hipSuccess) {
+    std::string m = hipGetErrorString(e);
+    cns_destroy(h);
+    return fail(nullptr, CNS_ERR_HIP, "second stream: " + m);
+  }
   *out = h;
   return CNS_OK;
 }
@@ -449,7 +500,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
-  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag}) b->release();
+  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b}) b->release();
   for (DevBuf& b : h->d_prio) b.release();
   for (DevBuf& b : h->d_lim) b.release();
   for (DevBuf& b : h->d_raw) b.release();
@@ -457,6 +508,8 @@ void cns_destroy(cns_handle* h) {
   for (DevBuf& b : h->d_step) b.release();
   for (DevBuf& b : h->d_pre) b.release();
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : h->ev2) if (ev) (void)hipEventDestroy(ev);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -553,6 +606,8 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
     return fail(h, CNS_ERR_UNSUPPORTED, "partition (or group of partitions sharing nodes) with more than " +
                                             std::to_string(kScan * CNS_NPL_MAX) + " schedulable (partition, node) slots");
   h->Pu = P; h->shared = shared; h->upart_eng = upart_eng; h->upart_size = upart_size; h->upart_tag = upart_tag;
+  h->eng_members.clear();
+  for (const auto& m : members) h->eng_members.push_back((u32)m.size());
   h->node_slots = node_slots; h->slot_tag = slot_tag;
   P = PE;
   h->N = N; h->P = P; h->S = S; h->max_np = max_np; h->big_nodes = big;
@@ -721,6 +776,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761)
   std::vector<uint8_t> reason(std::max<u64>(J, 1), CNS_REASON_NONE);
   std::vector<u64> pj_cnt(h->P + 1, 0);
+  h->job_part.assign((size_t)J, kNone);
   std::vector<u32> part_of(std::max<u64>(J, 1), 0);  // (virtual) partition of every job that reaches the ordered loop
   h->place_off.assign(J + 1, 0);
   u64 places = 0, algo = 0;
@@ -747,6 +803,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
       p = h->upart_eng[jb->partition[j]];   // the engine partition that runs the job's partition (its group, if it shares nodes)
     }
     part_of[j] = p;
+    h->job_part[(size_t)j] = p;
     pj_cnt[p + 1]++;
     const u64 np = rsv != CNS_RESV_NONE ? (u64)(h->part_off[p + 1] - h->part_off[p]) : (u64)h->upart_size[jb->partition[j]];
     algo += np * s_node + 64 + 16 + 24ull * k;
@@ -863,28 +920,51 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
   if (h->Jg) hipLaunchKernelGGL(k_prep_jobs, dim3((unsigned)((h->Jg + 255) / 256)), dim3(256), 0, h->stream, h->d_params.as<KParams>(), (u64)h->Jg);
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  bool split = false;
   if (h->Jg) {
-    const u32 np = h->max_np;
-#ifdef CNS_ONLY_NPL   // experiment builds: one tile width only
-    if (np > kScan * CNS_ONLY_NPL) return fail(h, CNS_ERR_UNSUPPORTED, "experiment build: partition too large for its one tile width");
-    launch_select<CNS_ONLY_NPL>(h, K);
-#else
-    bool launched = false;
-    if (const u32 ww = h->pre_active ? 0u : use_wide_kernel(h)) {
-      const int rc = ww == 64 ? launch_wide<w64::WideInfo>(h, K, np, &h->last_kernel) : launch_wide<w32::WideInfo>(h, K, np, &h->last_kernel);
-      if (rc == 1) return fail(h, CNS_ERR_HIP, "k_wide: control block allocation / upload / launch failed");
-      launched = rc == 0;
+    // Which partitions need k_select: groups of partitions that share nodes (one time map per node, a cost per partition) and,
+    // in a cycle with preemption, the partitions that have a pending job whose qos may preempt anything (TryPreempt_ returns at
+    // JobScheduler.cpp:6384-6385 for every other job).  Everything else runs on k_wide / k_pipe IN THE SAME CYCLE, side by
+    // side on a second stream: partitions with disjoint node sets never interact (:6723-6732,6746-6761).
+    std::vector<u32> pa, pb;
+    u32 npa = 0, npb = 0;
+    for (u32 p = 0; p < h->P; ++p) {
+      const bool sel = (p < h->eng_members.size() && h->eng_members[p] > 1) || (h->pre_active && p < h->pre_part.size() && h->pre_part[p]);
+      const u32 np = h->part_off[p + 1] - h->part_off[p];
+      if (sel) { pb.push_back(p); npb = std::max(npb, np); } else { pa.push_back(p); npa = std::max(npa, np); }
     }
-    if (!launched && !h->pre_active && use_pipe_kernel(h)) {
-#define CNS_TRY_PWIDTH(w) if (!launched && np <= kPScan * (w)) { launch_pipe<w>(h, K); launched = true; h->last_kernel = "k_pipe<" #w ">"; }
-      CNS_PNPL_LIST(CNS_TRY_PWIDTH)
-#undef CNS_TRY_PWIDTH
+    std::string err, name_a, name_b;
+    if (pb.empty() || pa.empty()) {
+      // one launch over all partitions (identity map)
+      const bool plain = pb.empty();
+      LaunchCtx L{h->P, h->max_np, h->stream, h->d_params.as<KParams>(), 0u};
+      KParams K1 = K;
+      if (plain) { K1.general_only = 0; K1.pre = PreParams{}; }
+      if (K1.general_only != K.general_only) HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K1, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+      if (const int rc = launch_one(h, K1, L, plain, &h->last_kernel, &err)) return fail(h, rc, err);
+    } else {
+      if (int rc = upload(h, h->d_pmap_a, pa)) return rc;
+      if (int rc = upload(h, h->d_pmap_b, pb)) return rc;
+      HIPCHK(h, h->d_params2.ensure(sizeof(KParams)));
+      KParams KA = K, KB = K;
+      KA.part_map = h->d_pmap_a.as<u32>(); KA.launch_parts = (u32)pa.size();
+      KA.general_only = 0; KA.pre = PreParams{};
+      KA.slot_block = nullptr; KA.sib_off = nullptr; KA.sib = nullptr; KA.slot_tag = nullptr;   // (none of these partitions shares a node)
+      KB.part_map = h->d_pmap_b.as<u32>(); KB.launch_parts = (u32)pb.size();
+      HIPCHK(h, hipMemcpyAsync(h->d_params.p, &KA, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(h->d_params2.p, &KB, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipEventRecord(h->ev2[0], h->stream));                  // tables + init kernels done: the second stream may start
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev2[0], 0));
+      LaunchCtx LB{(u32)pb.size(), npb, h->stream2, h->d_params2.as<KParams>(), 0u};
+      if (const int rc = launch_one(h, KB, LB, false, &name_b, &err)) return fail(h, rc, err);   // first: its few workgroups take their CUs
+      LaunchCtx LA{(u32)pa.size(), npa, h->stream, h->d_params.as<KParams>(), (u32)pb.size()};
+      if (const int rc = launch_one(h, KA, LA, true, &name_a, &err)) return fail(h, rc, err);
+      HIPCHK(h, hipEventRecord(h->ev[3], h->stream));                   // the partitions on the fast kernels are done here
+      split = true;
+      HIPCHK(h, hipEventRecord(h->ev2[1], h->stream2));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev2[1], 0));           // the cycle ends when both have
+      h->last_kernel = name_a + " + " + name_b + " on " + std::to_string(pb.size()) + " of " + std::to_string(h->P) + " partitions";
     }
-#define CNS_TRY_WIDTH(w) if (!launched && np <= kScan * (w)) { launch_select<w>(h, K); launched = true; h->last_kernel = "k_select<" #w ">"; }
-    CNS_NPL_LIST(CNS_TRY_WIDTH)
-#undef CNS_TRY_WIDTH
-    if (!launched) return fail(h, CNS_ERR_UNSUPPORTED, "partition too large for the widest register tile");
-#endif
     HIPCHK(h, hipGetLastError());
   }
   HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
@@ -894,6 +974,13 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
   HIPCHK(h, hipEventElapsedTime(&b, h->ev[1], h->ev[2]));
   h->timing.init_ms = a;
   h->timing.select_ms = b;
+  if (split) {   // a split cycle: when the partitions on the fast kernels were done (the cycle itself ends with the slower launch)
+    float c = 0;
+    HIPCHK(h, hipEventElapsedTime(&c, h->ev[1], h->ev[3]));
+    char buf[64];
+    snprintf(buf, sizeof buf, " [%s partitions done after %.1f ms]", h->last_kernel.substr(0, h->last_kernel.find(' ')).c_str(), c);
+    h->last_kernel += buf;
+  }
   h->timing.jobs_ordered = h->jobs_ordered;
   h->timing.algorithmic_bytes = h->algo_bytes;
   u32 fault[4] = {0, 0, 0, 0};
@@ -1129,6 +1216,13 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   Q.pool = misc; Q.pool_nodes = pool_nodes; Q.cand_cap = cand_cap;
   Q.cand = (u32*)(misc + off_cand); Q.chosen = (u32*)(misc + off_chosen);
   Q.out_cnt = (u32*)(misc + off_cnt); Q.out = (u32*)(misc + off_out); Q.out_cap = out_cap;
+  // the partitions that have a pending job whose qos may preempt: only they run on k_select's general path (run_resident_once)
+  h->pre_part.assign(h->P, 0);
+  for (u64 j = 0; j < J; ++j) {
+    const u32 q = pre->pd_qos[j];
+    if (j < h->job_part.size() && h->job_part[(size_t)j] != kNone && q < pre->num_qos && pre->qos_preempt_offsets[q + 1] > pre->qos_preempt_offsets[q])
+      h->pre_part[h->job_part[(size_t)j]] = 1;
+  }
   h->pre_active = true;
   int rc = cns_run_resident(h, now);
   h->pre_active = false;

@@ -184,6 +184,11 @@ struct KParams {
   u64* prof;               // [P*32] cycle counters (only written by -DCNS_PROF builds)
   char* wide_ctl;          // [P] WideCtl blocks of k_wide (exchange rings + control words), zeroed before every launch
   u32 general_only, pad_go; // != 0: every job through the general path of k_select (preemption enabled)
+  // A cycle may be SPLIT over two launches: the partitions that need k_select (groups of partitions that share nodes; with
+  // preemption, the partitions whose pending jobs may preempt) and all the others on k_wide / k_pipe, side by side.  Then
+  // workgroup (group) i of a launch serves engine partition part_map[i]; null: i itself.
+  const u32* part_map;
+  u32 launch_parts, pad_lp;
   PreParams pre;
   GresDev gres;
   // ---- partitions that share nodes (null otherwise) ----------------------------------------------------------------

@@ -1434,7 +1434,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
     }
     if (__any(bad) && lane == 0) set_fault(P, 3, orig, 0, 2);
     notle = __any(notle);
-    reserved = __any(reserved) && blockIdx.x < P.num_real_parts;
+    reserved = __any(reserved) && sh.part < P.num_real_parts;   // (the partition, not the workgroup index: k_wide and split launches differ)
     __threadfence_block();
     // EarliestStartSubsetSelector::CalcEarliestStartTime as a fixed point over the k nodes
     i64 t = P.now;
@@ -1600,7 +1600,7 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const GresDev* 
   }
   bool notle = false, reserved = false;
   for (u32 m = 0; m < J.k; ++m) { notle = notle || (H[m].pad & 1u) != 0; reserved = reserved || (H[m].pad & 2u) != 0; }
-  if (blockIdx.x >= P.num_real_parts) reserved = false;  // jobs of a reservation: no "Resource Reserved" (:6798,6818)
+  if (qbeg >= P.part_off[P.num_real_parts]) reserved = false;  // jobs of a reservation (its slots lie behind the real partitions'): no "Resource Reserved" (:6798,6818)
   if (found && active) {
     helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q);
     drain_stores();
@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   // P: by-value copy in the kernarg segment (global pointers, scalar loads) for the inlined hot paths;
   // PG: the same block in HBM, handed by reference to the out-of-line cold routines.
   const KParams& PG = *Pg;
-  const u32 part = blockIdx.x;
+  const u32 part = P.part_map ? uni32(P.part_map[blockIdx.x]) : blockIdx.x;   // (a cycle may be split over two launches: KParams::part_map)
   const u32 tid = threadIdx.x, lane = tid & 63u;
   const u32 wave = uni32(tid >> 6);  // wave-uniform: the role split below is a scalar branch
   // (flat loads are sources of divergence for the compiler: make what steers the control flow uniform)

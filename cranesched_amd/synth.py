@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .abi import Cluster, GresLayout, Jobs, MAX_GRES_CLASSES, MAX_GRES_NAMES, Running
+from .abi import Cluster, GresLayout, Jobs, MAX_GRES_CLASSES, MAX_GRES_NAMES, Preempt, Running
 
 NOW = 1_700_000_000
 SEED0 = 0x43524E45
@@ -179,8 +179,9 @@ def make_loaded(name: str, J: int | None = None, N: int | None = None, P: int | 
     return cluster, jobs, now, make_running(cluster, R, SEED0 ^ CONFIGS[base]["idx"], now)
 
 
-def running_of_partitions(cluster: Cluster, running: Running, parts: list[int]) -> Running:
-    """The running jobs whose nodes lie in `parts` (every job of make_running lives inside one partition), order kept."""
+def running_of_partitions(cluster: Cluster, running: Running, parts: list[int], with_index: bool = False):
+    """The running jobs whose nodes lie in `parts` (every job of make_running lives inside one partition), order kept
+    (with_index: also their indices in `running`)."""
     inpart = np.zeros(cluster.num_nodes, bool)
     for p in parts:
         inpart[np.asarray(cluster.part_nodes[cluster.part_offsets[p]:cluster.part_offsets[p + 1]], np.int64)] = True
@@ -188,9 +189,53 @@ def running_of_partitions(cluster: Cluster, running: Running, parts: list[int]) 
     keep = np.nonzero(inpart[running.alloc_node[o[:-1]].astype(np.int64)])[0] if len(o) > 1 else np.zeros(0, np.int64)
     cnt = (o[1:] - o[:-1])[keep]
     idx = np.repeat(o[:-1][keep], cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
-    return Running(end_sec=running.end_sec[keep], alloc_offsets=np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32),
-                   alloc_node=running.alloc_node[idx], alloc_cpu_raw=running.alloc_cpu_raw[idx], alloc_mem=running.alloc_mem[idx],
-                   alloc_core_lo=running.alloc_core_lo[idx], alloc_core_hi=running.alloc_core_hi[idx], alloc_gres=running.alloc_gres[idx])
+    sub = Running(end_sec=running.end_sec[keep], alloc_offsets=np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint32),
+                  alloc_node=running.alloc_node[idx], alloc_cpu_raw=running.alloc_cpu_raw[idx], alloc_mem=running.alloc_mem[idx],
+                  alloc_core_lo=running.alloc_core_lo[idx], alloc_core_hi=running.alloc_core_hi[idx], alloc_gres=running.alloc_gres[idx])
+    return (sub, keep) if with_index else sub
+
+
+# Mixed cycles: C4-sized cycles in which ONE scheduler needs the slow path and the other seven do not.
+#   C4all: C4 plus an "ALL" partition (index 8) over the nodes of partition 0; every second job of partition 0 is submitted to it.
+#          Partitions 0 and 8 share their 8 192 nodes (one time map per node, one cost per partition): one group on k_select.
+#   C4rp:  the loaded cluster C4r with QoS preemption enabled: 8 % of the pending jobs of partition 0 (1 % of the queue) carry a
+#          QoS that may preempt the QoS of everything else; only partition 0's scheduler can ever reach TryPreempt_.
+MIXED = ("C4all", "C4rp")
+
+
+def make_mixed(name: str, J: int | None = None, N: int | None = None):
+    """(cluster, jobs, now, running or None, Preempt or None) of a mixed cycle, optionally scaled like make_config."""
+    if name == "C4all":
+        c, j, now = make_config("C4", J=J, N=N)
+        P = c.num_partitions
+        po = c.part_offsets.astype(np.int64)
+        p0 = c.part_nodes[po[0]:po[1]]
+        cluster = Cluster(c.cpu_total_raw, c.mem_total, c.core_lo, c.core_hi, c.gres_slots,
+                          np.concatenate([c.part_offsets, [po[-1] + len(p0)]]).astype(np.uint32),
+                          np.concatenate([c.part_nodes, p0]).astype(np.uint32), gres=c.gres)
+        part = j.partition.copy()
+        part[(part == 0) & (np.arange(j.num_jobs) % 2 == 1)] = P
+        j.partition = part.astype(np.uint32)
+        return cluster, j, now, None, None
+    if name == "C4rp":
+        c, j, now, run = make_loaded("C4r", J=J, N=N)
+        R = len(run.end_sec)
+        r = (splitmix64(SEED0 ^ 0x50524545, j.num_jobs) >> np.uint64(11)).astype(np.int64)
+        pd_qos = np.where((j.partition == 0) & (r % 100 < 8), 1, 0).astype(np.uint32)
+        qprio = np.array([10, 20], np.uint32)
+        pre = Preempt([[], [0]], np.arange(j.num_jobs, dtype=np.uint32) + 1, pd_qos, qprio[pd_qos],
+                      (j.num_jobs - np.arange(j.num_jobs)).astype(np.float64) + 0.5,        # all different: nothing left unordered
+                      1_000_000 + np.arange(R, dtype=np.uint32), np.zeros(R, np.uint32), np.full(R, 10, np.uint32),
+                      now - 1 - np.arange(R, dtype=np.int64))                              # all different
+        return c, j, now, run, pre
+    raise KeyError(name)
+
+
+def preempt_subset(pre: Preempt, job_idx: np.ndarray, run_idx: np.ndarray) -> Preempt:
+    """The preemption inputs of a shard: pending jobs `job_idx` and running jobs `run_idx` of the whole cycle."""
+    return Preempt(pre.qos_preempt, pre.pd_job_id[job_idx], pre.pd_qos[job_idx], pre.pd_qos_priority[job_idx], pre.pd_priority[job_idx],
+                   pre.rn_job_id[run_idx], pre.rn_qos[run_idx], pre.rn_qos_priority[run_idx], pre.rn_start_sec[run_idx],
+                   preempting=pre.preempting, enabled=pre.enabled)
 
 
 def make_limits(name: str, cluster: Cluster, jobs: Jobs):

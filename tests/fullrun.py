@@ -59,6 +59,14 @@ def digest(pl, costs_u64: np.ndarray, timeline_of, num_nodes: int) -> dict:
             "counts": np.bincount(t["reason"], minlength=8).astype(np.int64)}
 
 
+def preempt_crc(pairs: np.ndarray, cancelled: np.ndarray) -> np.ndarray:
+    """CRC of the cycle's preempted_jobs lists — (pending job, reference) rows ordered by job, push_back order within a job;
+    reference = running-table index, or pending-queue index | 2^31 — and of the sorted EnqueuePreemptCancel ids."""
+    v = zlib.crc32(_b(np.ascontiguousarray(pairs, np.int64)))
+    v = zlib.crc32(_b(np.ascontiguousarray(np.sort(cancelled), np.int64)), v)
+    return np.array([v], np.uint32)
+
+
 def compare(got: dict, ref: dict) -> str | None:
     """None if identical, else a description of the first difference."""
     if len(got["chunk_crc"]) != len(ref["chunk_crc"]):
@@ -74,4 +82,6 @@ def compare(got: dict, ref: dict) -> str | None:
         return "placements and costs identical but final time maps differ"
     if not np.array_equal(got["sha256"], ref["sha256"]):
         return "sha256 differs"
+    if "preempt_crc" in ref and ("preempt_crc" not in got or got["preempt_crc"][0] != ref["preempt_crc"][0]):
+        return "placements, costs and time maps identical but the preempted lists / cancel list differ"
     return None

@@ -27,24 +27,52 @@ from tests import fullrun  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def load_case(name, J=None, N=None, P=None):
-    """(cluster, jobs, now, running or None) of a CASES entry: a frozen config, or its loaded-cluster variant (synth.LOADED)."""
+def load_case5(name, J=None, N=None, P=None):
+    """(cluster, jobs, now, running or None, Preempt or None) of a CASES entry: a frozen config, its loaded-cluster variant
+    (synth.LOADED) or a mixed cycle (synth.MIXED)."""
+    if name in synth.MIXED:
+        return synth.make_mixed(name, J=J, N=N)
     if name in synth.LOADED:
-        return synth.make_loaded(name, J=J, N=N, P=P)
-    return (*synth.make_config(name, J=J, N=N, P=P), None)
+        return (*synth.make_loaded(name, J=J, N=N, P=P), None)
+    return (*synth.make_config(name, J=J, N=N, P=P), None, None)
+
+
+def load_case(name, J=None, N=None, P=None):
+    return load_case5(name, J, N, P)[:4]
+
+
+def case_groups(name, J=None, N=None, P=None):
+    """The units that never interact: groups of partitions connected through shared nodes (mostly single partitions)."""
+    from cranesched_amd import sharding
+    return sharding.partition_groups(load_case5(name, J, N, P)[0])
 
 
 def _one_partition(args):
-    name, J, N, P, p = args
+    """One oracle run over one GROUP of partitions (a single partition unless partitions share nodes)."""
+    name, J, N, P, group = args
     from oracle import pyoracle
-    cluster, jobs, now, running = load_case(name, J, N, P)
-    sub, idx = synth.select_partitions(cluster, jobs, [p])
-    r = pyoracle.select(cluster, sub, now, running=None if running is None else synth.running_of_partitions(cluster, running, [p]))
-    lo, hi = int(cluster.part_offsets[p]), int(cluster.part_offsets[p + 1])
-    nodes = [int(n) for n in fullrun.timeline_nodes(cluster.num_nodes) if lo <= n < hi]  # contiguous partitions (synth)
-    assert np.array_equal(cluster.part_nodes[lo:hi], np.arange(lo, hi))
+    cluster, jobs, now, running, pre = load_case5(name, J, N, P)
+    sub, idx = synth.select_partitions(cluster, jobs, group)
+    rsub, rkeep = (None, np.zeros(0, np.int64)) if running is None else synth.running_of_partitions(cluster, running, group, with_index=True)
+    psub = None if pre is None else synth.preempt_subset(pre, idx, rkeep)
+    r = pyoracle.select(cluster, sub, now, running=rsub, preempt=psub)
+    in_group = np.zeros(cluster.num_nodes, bool)
+    slots = []
+    for p in group:
+        lo, hi = int(cluster.part_offsets[p]), int(cluster.part_offsets[p + 1])
+        in_group[np.asarray(cluster.part_nodes[lo:hi], np.int64)] = True
+        slots.append((lo, hi))
+    nodes = [int(n) for n in fullrun.timeline_nodes(cluster.num_nodes) if in_group[n]]
     tl = {n: r.timeline(n) for n in nodes}
-    out = (p, idx, r.placements.trimmed(), r.costs()[lo:hi].view(np.uint64).copy(), tl, r.seconds)
+    costs = r.costs().view(np.uint64)
+    pre_pairs = None
+    if pre is not None:   # (pending job, reference) in GLOBAL indices: reference = running index, or pending index | 2^31
+        pairs = []
+        for sj, lst in enumerate(r.preempt_out.lists()):
+            for is_pd, ref in lst:
+                pairs.append((int(idx[sj]), (int(idx[ref]) | (1 << 31)) if is_pd else int(rkeep[ref])))
+        pre_pairs = (np.asarray(pairs, np.int64).reshape(-1, 2), np.asarray(r.preempt_out.cancelled_ids(), np.int64))
+    out = (group, idx, r.placements.trimmed(), [(lo, hi, costs[lo:hi].copy()) for lo, hi in slots], tl, r.seconds, pre_pairs)
     r.close()
     return out
 
@@ -63,19 +91,23 @@ CASES = {
     # the cycle CraneCtld normally runs: the same 1 M-job queue on a cluster that already RUNS 300 k jobs (480 k allocations:
     # cycle-start res_avail != res_total, initial time maps of up to ~30 entries, non-zero initial costs; synth.make_running)
     "c4r": ("C4r", None, None, None),
+    # mixed cycles (synth.MIXED): ONE scheduler needs k_select — an ALL partition over partition 0's nodes / QoS preemption among
+    # partition 0's jobs — the other seven run on k_wide in the same cycle
+    "c4all": ("C4all", None, None, None), "c4rp": ("C4rp", None, None, None),
 }
 
 
 def merge_parts(name, J, N, P, parts):
     """Scatters per-partition oracle results (tuples of _one_partition) back into one full result."""
     cluster, jobs, now, _ = load_case(name, J, N, P)
-    Pn = cluster.num_partitions
+    ngroups = len(parts)
     full = abi.Placements(jobs.num_jobs, jobs.total_places())
     off = np.concatenate([[0], np.cumsum(jobs.node_num.astype(np.int64))])
     full.place_offsets[:] = off.astype(np.uint64)
     costs = np.zeros(len(cluster.part_nodes), np.uint64)
-    timelines, secs = {}, np.zeros(Pn)
-    for p, idx, t, c, tl, s in parts:
+    timelines, secs = {}, np.zeros(ngroups)
+    pre_pairs, cancelled = [], []
+    for gi, (group, idx, t, cs, tl, s, pp) in enumerate(parts):
         full.start_sec[idx] = t["start_sec"]
         full.reason[idx] = t["reason"]
         so = t["place_offsets"].astype(np.int64)
@@ -84,17 +116,25 @@ def merge_parts(name, J, N, P, parts):
         dst = np.repeat(off[idx], k) + (np.arange(so[-1]) - np.repeat(so[:-1], k))
         for f in fullrun.REC_FIELDS:
             getattr(full, f)[dst] = t[f][:so[-1]]
-        costs[int(cluster.part_offsets[p]):int(cluster.part_offsets[p + 1])] = c
+        for lo, hi, c in cs:
+            costs[lo:hi] = c
         timelines.update(tl)
-        secs[p] = s
+        secs[gi] = s
+        if pp is not None:
+            pre_pairs.append(pp[0]); cancelled.append(pp[1])
+    if pre_pairs:   # preempted_jobs lists of the whole cycle, by pending job (stable: push_back order within a job), and the cancel list
+        allp = np.concatenate(pre_pairs)
+        merge_parts.preempt = (allp[np.argsort(allp[:, 0], kind="stable")], np.sort(np.concatenate(cancelled)))
+    else:
+        merge_parts.preempt = None
     return cluster, jobs, full, costs, timelines, secs
 
 
 def merged_run(name, J=None, N=None, P=None, procs=None):
     """(cluster, jobs, Placements, costs_u64, timelines, seconds per partition), one oracle process per partition."""
-    Pn = P or synth.CONFIGS[synth.LOADED.get(name, (name,))[0]]["P"]
-    with mp.get_context("fork").Pool(procs or min(Pn, os.cpu_count() or 1)) as pool:
-        parts = pool.map(_one_partition, [(name, J, N, P, p) for p in range(Pn)], chunksize=1)
+    groups = case_groups(name, J, N, P)
+    with mp.get_context("fork").Pool(procs or min(len(groups), os.cpu_count() or 1)) as pool:
+        parts = pool.map(_one_partition, [(name, J, N, P, g) for g in groups], chunksize=1)
     return merge_parts(name, J, N, P, parts)
 
 
@@ -103,7 +143,7 @@ def main(tags):
     work = []
     for tag in tags:
         name, J, N, P = CASES[tag]
-        work += [(tag, (name, J, N, P, p)) for p in range(P or synth.CONFIGS[synth.LOADED.get(name, (name,))[0]]["P"])]
+        work += [(tag, (name, J, N, P, g)) for g in case_groups(name, J, N, P)]
     with mp.get_context("fork").Pool(min(len(work), os.cpu_count() or 1)) as pool:
         results = pool.map(_one_partition, [w[1] for w in work], chunksize=1)
     for tag in tags:
@@ -111,6 +151,9 @@ def main(tags):
         parts = [r for (t, _), r in zip(work, results) if t == tag]
         cluster, jobs, full, costs, timelines, secs = merge_parts(name, J, N, P, parts)
         d = fullrun.digest(full, costs, lambda n: timelines[n], cluster.num_nodes)
+        if merge_parts.preempt is not None:
+            d["preempt_crc"] = fullrun.preempt_crc(*merge_parts.preempt)
+            d["preemptions"] = np.array([len(merge_parts.preempt[0]), len(merge_parts.preempt[1])])
         np.savez_compressed(os.path.join(HERE, f"fullrun_{tag}.npz"), oracle_seconds=secs,
                             jobs=np.array([jobs.num_jobs]), nodes=np.array([cluster.num_nodes]), **d)
         print(f"{tag}: {name} {jobs.num_jobs} jobs x {cluster.num_nodes} nodes, reasons {d['counts'].tolist()}, "

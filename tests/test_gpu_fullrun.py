@@ -10,7 +10,7 @@ import pytest
 
 from cranesched_amd import synth
 from tests import fullrun
-from tests.golden.make_fullrun import CASES, load_case
+from tests.golden.make_fullrun import CASES, load_case5
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -24,17 +24,25 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
     assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
     ref = dict(np.load(path))
     name, J, N, P = CASES[tag]
-    cluster, jobs, now, running = load_case(name, J, N, P)
+    cluster, jobs, now, running, pre = load_case5(name, J, N, P)
     eng = engine_cls(device=0)
     try:
         eng.set_nodes(cluster)
         if running is not None:
             eng.set_running(running)
-        got = eng.node_select(now, jobs)
+        if pre is None:
+            got = eng.node_select(now, jobs)
+        else:
+            got, po = eng.node_select_preempt(now, jobs, pre)
         d = fullrun.digest(got, eng.costs().view(np.uint64), eng.timeline, cluster.num_nodes)
+        if pre is not None:
+            pairs = [(j, (ref | (1 << 31)) if is_pd else ref) for j, lst in enumerate(po.lists()) for is_pd, ref in lst]
+            d["preempt_crc"] = fullrun.preempt_crc(np.asarray(pairs, np.int64).reshape(-1, 2), np.asarray(po.cancelled_ids(), np.int64))
         msg = fullrun.compare(d, ref)
         assert msg is None, f"{tag}: engine differs from the oracle's full run: {msg}"
         t = eng.timing()
+        if name in synth.MIXED and os.environ.get("CNS_SELECT_KERNEL") in ("wide", "wide32"):   # the split really happened
+            assert " + k_select" in eng.last_kernel() and eng.last_kernel().startswith("k_wide"), eng.last_kernel()
         print(f"{tag}: {jobs.num_jobs} jobs x {cluster.num_nodes} nodes identical to the oracle "
               f"(start-now {d['counts'][0]}, backfilled {d['counts'][1]}, failed {d['counts'][2]}); "
               f"{eng.last_kernel()} {t['select_ms']:.1f} ms = {1e3 * jobs.num_jobs / t['select_ms']:.0f} decisions/s")

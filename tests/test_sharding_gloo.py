@@ -26,16 +26,21 @@ def pack(pl, jobs):
     return buf
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, cfg=("C4", 6000, 512, 8)):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from cranesched_amd import sharding, synth
     from oracle import pyoracle
-    cluster, jobs, now = synth.make_config("C4", J=6000, N=512, P=8)
+    name, J, N, P = cfg
+    running = None
+    if name in synth.LOADED:   # the same queue on a cluster that already runs jobs: every rank holds the whole running set
+        cluster, jobs, now, running = synth.make_loaded(name, J=J, N=N, P=P)
+    else:
+        cluster, jobs, now = synth.make_config(name, J=J, N=N, P=P)
     mine, idx = sharding.shard(cluster, jobs, rank, world)
-    r = pyoracle.select(cluster, mine, now)
+    r = pyoracle.select(cluster, mine, now, running=running)
     buf = pack(r.placements, mine)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([len(buf)], dtype=torch.int64))
@@ -51,17 +56,20 @@ def _worker(rank, world, port, q):
         raw = out[rk * pad:(rk + 1) * pad].numpy()
         shards.append((sharding.unpack_results(raw, sj), sidx))
     merged = sharding.merge(jobs, shards)
-    ref = pyoracle.select(cluster, jobs, now)
+    ref = pyoracle.select(cluster, jobs, now, running=running)
     q.put((rank, merged.diff(ref.placements)))
     dist.destroy_process_group()
 
 
-def test_two_rank_shard_allgather_merge():
-    world = 2
+# C4: 8 partitions (rank r owns partitions p % world == r); C4p64: the same cluster cut into 64 partitions of 1 024 nodes — the
+# configuration on which more GPUs add chains (bench.py --config C4p64); C4r: the loaded cluster
+@pytest.mark.parametrize("world,cfg", [(2, ("C4", 6000, 512, 8)), (2, ("C4p64", 8000, 1024, 64)), (4, ("C4p64", 8000, 1024, 64)),
+                                       (2, ("C4r", 6000, 512, 8))])
+def test_shard_allgather_merge(world, cfg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29000 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29000 + (os.getpid() % 2000) + 7 * world + len(cfg[0])
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, cfg)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
