@@ -108,7 +108,7 @@ struct cns_engine {
   std::vector<u32> eng_members;                 // engine partition -> number of caller partitions it runs (> 1: they share nodes)
   std::vector<u32> job_part;                    // pending job (queue index) -> engine partition (kNone: not given to the ordered loop)
   std::vector<uint8_t> pre_part;                // cycle with preemption: engine partition has a pending job whose qos may preempt
-  DevBuf d_params2, d_pmap_a, d_pmap_b;
+  DevBuf d_params2, d_pmap_a, d_pmap_b, d_wide_last;
   bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
   u32 wide_retries = 0;                         // cycles that were re-run on k_pipe / k_select after a k_wide fault (lifetime of the handle)
   // MultiFactorPriority (priority_host.inc)
@@ -270,6 +270,12 @@ int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string
   if (hipMemsetAsync(h->d_wide.p, 0, need, L.stream) != hipSuccess) return 1;
   KParams K2 = K;
   K2.wide_ctl = h->d_wide.as<char>();
+  if (np > W::lanes * 4u) {   // 8 / 16 rows per lane: the home workgroup's last-task table does not fit the LDS
+    const size_t lb = (size_t)h->P * W::lanes * W::npl_max * sizeof(u32);
+    if (h->d_wide_last.ensure(lb) != hipSuccess) return 1;
+    if (hipMemsetAsync(h->d_wide_last.p, 0, lb, L.stream) != hipSuccess) return 1;
+    K2.wide_last = h->d_wide_last.as<u32>();
+  }
   if (hipMemcpyAsync(&const_cast<KParams*>(L.dparams)->wide_ctl, &K2.wide_ctl, sizeof(char*), hipMemcpyHostToDevice, L.stream) != hipSuccess) return 1;
   size_t dyn = 0;
   hipFuncAttributes fa;
@@ -361,8 +367,9 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   for (u32 q = h->S_real; q < S; ++q) h->slot_total[q] = (*virt_total)[q - h->S_real];
   for (u32 v = 0; v < h->V; ++v)
     for (u32 q = h->part_off[h->P_real + v]; q < h->part_off[h->P_real + v + 1]; ++q) h->slot_end[q] = h->resv_end[v];
-  if (h->max_np > kScan * (u32)CNS_NPL_MAX)
-    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(kScan * CNS_NPL_MAX) + " schedulable nodes");
+  // (per partition / group: checked in cns_set_nodes — a partition that shares no node may be as wide as k_wide's widest tile)
+  if (h->max_np > std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max))
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(w64::WideInfo::lanes * w64::WideInfo::npl_max) + " schedulable nodes");
   std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
   std::vector<uint8_t> slot_type(std::max<u32>(S, 1), 0);
@@ -500,7 +507,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
-  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b}) b->release();
+  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last}) b->release();
   for (DevBuf& b : h->d_prio) b.release();
   for (DevBuf& b : h->d_lim) b.release();
   for (DevBuf& b : h->d_raw) b.release();
@@ -602,9 +609,15 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   }
   part_off[PE] = (u32)slot_node.size();
   const u32 S = (u32)slot_node.size();
-  if (max_np > kScan * (u32)CNS_NPL_MAX)
-    return fail(h, CNS_ERR_UNSUPPORTED, "partition (or group of partitions sharing nodes) with more than " +
-                                            std::to_string(kScan * CNS_NPL_MAX) + " schedulable (partition, node) slots");
+  // k_select / k_pipe tiles hold 16 576 / 8 192 slots; k_wide (64 scanner waves x 16 rows) 65 536 — but only partitions that
+  // share no node with another one run on it (groups run on k_select), and only while the device can hold its workgroups
+  for (u32 e = 0; e < PE; ++e) {
+    const u32 npe = part_off[e + 1] - part_off[e];
+    const u32 cap = members[e].size() > 1 ? kScan * (u32)CNS_NPL_MAX : std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max);
+    if (npe > cap)
+      return fail(h, CNS_ERR_UNSUPPORTED, (members[e].size() > 1 ? "group of partitions sharing nodes with more than " : "partition with more than ") +
+                                              std::to_string(cap) + " schedulable (partition, node) slots");
+  }
   h->Pu = P; h->shared = shared; h->upart_eng = upart_eng; h->upart_size = upart_size; h->upart_tag = upart_tag;
   h->eng_members.clear();
   for (const auto& m : members) h->eng_members.push_back((u32)m.size());

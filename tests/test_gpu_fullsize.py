@@ -103,3 +103,59 @@ def test_c5_walltimes_full_partition_width(engine_cls):
         assert pre.diff(ref.placements) is None
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("N,J,Kpre", [(32_768, 300_000, 60_000), (65_536, 1_000_000, 100_000)])
+def test_single_partition_wider_than_the_register_tiles_of_k_select(engine_default, N, J, Kpre):
+    """SURVEY 8(d)'s "single 64 k partition variant" (3 145 832 algorithmic bytes per decision) and its half: ONE partition of
+    32 768 / 65 536 nodes — more than k_select's 16 576 slots — on k_wide with 8 / 16 tile rows per scanner lane (the home
+    workgroup's last-task table in HBM, multi-word row masks in the serial protocol).  Checked as the full-size C4 run: bit-exact
+    against the oracle on a prefix (prefix closure), conservation by replay, determinism."""
+    from oracle import pyoracle
+    cluster, jobs, now = synth.make_config("C4", J=J, N=N, P=1)
+    eng = engine_default(device=0)
+    try:
+        eng.set_nodes(cluster)
+        full = eng.node_select(now, jobs)
+        t_full = eng.timing()["select_ms"]
+        assert eng.last_kernel().startswith("k_wide<16>" if N > 32_768 else "k_wide<8>"), eng.last_kernel()
+        c1 = crc(full)
+        assert crc(eng.node_select(now, jobs)) == c1, "run-to-run nondeterminism"
+        assert replay_ok(cluster, jobs, full)
+        _, pre_jobs, _ = synth.make_config("C4", J=Kpre, N=N, P=1)
+        pre = eng.node_select(now, pre_jobs)
+        ref = pyoracle.select(cluster, pre_jobs, now)
+        assert pre.diff(ref.placements) is None, f"prefix differs from the oracle: {pre.diff(ref.placements)}"
+        assert np.array_equal(eng.costs().view(np.uint64), ref.costs().view(np.uint64)), "fp64 costs of the prefix run differ"
+        nrec = int(pre_jobs.node_num.astype(np.int64).sum())
+        assert np.array_equal(full.start_sec[:Kpre], pre.start_sec[:Kpre]) and np.array_equal(full.reason[:Kpre], pre.reason[:Kpre])
+        for f in ("node_idx", "ntasks", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+            assert np.array_equal(getattr(full, f)[:nrec], getattr(pre, f)[:nrec]), f
+        r = full.reason[:jobs.num_jobs]
+        bytes_per = N * 48 + 104
+        print(f"one partition of {N} nodes, {J} jobs: {eng.last_kernel()} {t_full:.1f} ms = {1e3 * J / t_full:.0f} decisions/s "
+              f"= {J * bytes_per / (t_full * 1e-3) / 8e12:.3f} of the HBM roofline at {bytes_per} B per decision; "
+              f"start-now {(r == 0).sum()}, later {(r == 1).sum() + (r == 2).sum()}; wide_stats {eng.wide_stats()}")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("seed,N", [(21, 20_000), (22, 40_000)])
+def test_wide_tile_heterogeneous_serial_paths(engine_default, seed, N):
+    """Exclusive jobs, ntasks > node_num, node lists, wide multi-node jobs (the serial protocol inside the home workgroup, its
+    memory scanners with 45 / 90 rows per lane: multi-word row masks) on partitions of 20 000 / 40 000 unequal nodes with running
+    jobs — whole result, every cost and a node sample's time maps against the oracle."""
+    from oracle import pyoracle
+    from tests import helpers
+    c, j, now, run = helpers.random_case(seed, N=N, J=2500, P=1, running=3000)
+    eng = engine_default(device=0)
+    try:
+        eng.set_nodes(c)
+        eng.set_running(run)
+        got = eng.node_select(now, j)
+        assert eng.last_kernel().startswith("k_wide<16>" if N > 32_768 else "k_wide<8>"), eng.last_kernel()
+        ref = pyoracle.select(c, j, now, running=run)
+        helpers.assert_same(eng, got, ref, c, sample_nodes=64, tag=f"wide tile {N}")
+        assert eng.wide_stats()["serial_jobs"] > 50
+    finally:
+        eng.close()
