@@ -200,7 +200,33 @@ def running_of_partitions(cluster: Cluster, running: Running, parts: list[int], 
 #          Partitions 0 and 8 share their 8 192 nodes (one time map per node, one cost per partition): one group on k_select.
 #   C4rp:  the loaded cluster C4r with QoS preemption enabled: 8 % of the pending jobs of partition 0 (1 % of the queue) carry a
 #          QoS that may preempt the QoS of everything else; only partition 0's scheduler can ever reach TryPreempt_.
-MIXED = ("C4all", "C4rp")
+#   C4v:   C4 with 16 reservations (JobScheduler.cpp:6619-6679): on every partition an ACTIVE one over its last 256 nodes (whole-node
+#          shares; 3 % of the partition's jobs are submitted into it) and a FUTURE one (starts in an hour, for two hours) over the 256
+#          nodes before those: jobs whose window crosses it wait behind it ("Resource Reserved"); a few jobs name the future
+#          reservation (its scheduler does not exist yet) or a reservation nobody created ("Reservation Not Found").
+MIXED = ("C4all", "C4rp", "C4v")
+
+
+def mixed_reservations(name: str, cluster: Cluster, now: int = NOW):
+    """The reservations of a mixed cycle (None unless it has any)."""
+    if name != "C4v":
+        return None
+    from .abi import Reservations
+    P = cluster.num_partitions
+    po = cluster.part_offsets.astype(np.int64)
+    start, end, off, node = [], [], [0], []
+    for v in range(2 * P):
+        p = v % P
+        per = int(po[p + 1] - po[p])
+        w = min(256, per // 8)
+        hi = po[p + 1] - (0 if v < P else w)
+        node.append(cluster.part_nodes[hi - w:hi].astype(np.int64))
+        off.append(off[-1] + w)
+        if v < P: start.append(now - 1000 - 7 * p); end.append(now + 8 * 3600 + 60 * p)
+        else: start.append(now + 3600 + 120 * p); end.append(now + 3 * 3600 + 120 * p)
+    node = np.concatenate(node)
+    return Reservations(start, end, off, node, cluster.cpu_total_raw[node], cluster.mem_total[node], cluster.core_lo[node],
+                        cluster.core_hi[node], cluster.gres_slots[node])
 
 
 def make_mixed(name: str, J: int | None = None, N: int | None = None):
@@ -228,6 +254,17 @@ def make_mixed(name: str, J: int | None = None, N: int | None = None):
                       1_000_000 + np.arange(R, dtype=np.uint32), np.zeros(R, np.uint32), np.full(R, 10, np.uint32),
                       now - 1 - np.arange(R, dtype=np.int64))                              # all different
         return c, j, now, run, pre
+    if name == "C4v":
+        c, j, now = make_config("C4", J=J, N=N)
+        P = c.num_partitions
+        r = (splitmix64(SEED0 ^ 0x52455356, j.num_jobs) >> np.uint64(11)).astype(np.int64) % 1000
+        part = j.partition.astype(np.int64)
+        resv = np.full(j.num_jobs, 0xFFFFFFFF, np.int64)                  # RESV_NONE
+        resv = np.where(r < 30, part, resv)                              # the partition's active reservation
+        resv = np.where((r >= 30) & (r < 32), P + part, resv)            # its future one
+        resv = np.where(r == 32, 2 * P, resv)                            # one that does not exist
+        j.reservation = resv.astype(np.uint32)
+        return c, j, now, None, None
     raise KeyError(name)
 
 
@@ -287,5 +324,5 @@ def select_partitions(cluster: Cluster, jobs: Jobs, parts: list[int]):
                ntasks_per_node_min=jobs.ntasks_per_node_min[idx],
                ntasks_per_node_max=jobs.ntasks_per_node_max[idx], node_cpu_raw=take(jobs.node_cpu_raw),
                exclusive=take(jobs.exclusive), gres_total=take(jobs.gres_total), gres_spec=take(jobs.gres_spec),
-               skip=take(jobs.skip))
+               skip=take(jobs.skip), reservation=take(jobs.reservation))
     return sub, idx

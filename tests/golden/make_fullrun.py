@@ -41,6 +41,11 @@ def load_case(name, J=None, N=None, P=None):
     return load_case5(name, J, N, P)[:4]
 
 
+def load_resv(name, cluster):
+    """The reservations of a CASES entry (None for most)."""
+    return synth.mixed_reservations(name, cluster) if name in synth.MIXED else None
+
+
 def case_groups(name, J=None, N=None, P=None):
     """The units that never interact: groups of partitions connected through shared nodes (mostly single partitions)."""
     from cranesched_amd import sharding
@@ -55,7 +60,8 @@ def _one_partition(args):
     sub, idx = synth.select_partitions(cluster, jobs, group)
     rsub, rkeep = (None, np.zeros(0, np.int64)) if running is None else synth.running_of_partitions(cluster, running, group, with_index=True)
     psub = None if pre is None else synth.preempt_subset(pre, idx, rkeep)
-    r = pyoracle.select(cluster, sub, now, running=rsub, preempt=psub)
+    # (reservations: all of them in every group's run — one over another group's nodes only leaves dips on nodes nobody here looks at)
+    r = pyoracle.select(cluster, sub, now, running=rsub, preempt=psub, reservations=load_resv(name, cluster))
     in_group = np.zeros(cluster.num_nodes, bool)
     slots = []
     for p in group:
@@ -94,6 +100,8 @@ CASES = {
     # mixed cycles (synth.MIXED): ONE scheduler needs k_select — an ALL partition over partition 0's nodes / QoS preemption among
     # partition 0's jobs — the other seven run on k_wide in the same cycle
     "c4all": ("C4all", None, None, None), "c4rp": ("C4rp", None, None, None),
+    # C4 with 8 active and 8 future reservations (24 schedulers: k_wide's nine-workgroup build)
+    "c4v": ("C4v", None, None, None),
 }
 
 

@@ -13,12 +13,15 @@ from tests.golden import make_fullrun
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("name,J,N,P", [("C4", 24000, 2048, 8), ("C5", 12000, 512, 4), ("C4r", 24000, 2048, 8)])
+@pytest.mark.parametrize("name,J,N,P", [("C4", 24000, 2048, 8), ("C5", 12000, 512, 4), ("C4r", 24000, 2048, 8), ("C4v", 24000, 2048, 8)])
 def test_partition_merge_equals_single_run(built, name, J, N, P):
     from oracle import pyoracle
     cluster, jobs, full, costs, timelines, _ = make_fullrun.merged_run(name, J=J, N=N, P=P, procs=2)
     running = make_fullrun.load_case(name, J, N, P)[3]   # (C4r: the loaded cluster's running jobs, split by partition in the merge)
-    ref = pyoracle.select(cluster, jobs, synth.NOW, running=running)
+    ref = pyoracle.select(cluster, jobs, synth.NOW, running=running, reservations=make_fullrun.load_resv(name, cluster))
+    if name == "C4v":   # the case must reach every reservation verdict
+        rs = ref.placements.reason[:J]
+        assert (rs == 3).sum() > 0 and (rs == 6).sum() > 0, np.bincount(rs, minlength=8)
     assert full.diff(ref.placements) is None
     a = fullrun.digest(full, costs, lambda n: timelines[n], cluster.num_nodes)
     b = fullrun.digest(ref.placements, ref.costs().view(np.uint64), ref.timeline, cluster.num_nodes)
@@ -35,7 +38,7 @@ def test_committed_digests_well_formed(tag):
     assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
     d = np.load(path)
     name, J, N, P = make_fullrun.CASES[tag]
-    base = {"C4all": "C4", "C4rp": "C4"}.get(name, synth.LOADED.get(name, (name,))[0])
+    base = {"C4all": "C4", "C4rp": "C4", "C4v": "C4"}.get(name, synth.LOADED.get(name, (name,))[0])
     J = J or synth.CONFIGS[base]["J"]
     assert int(d["jobs"][0]) == J and int(d["nodes"][0]) == (N or synth.CONFIGS[base]["N"])
     assert len(d["chunk_crc"]) == (J + fullrun.CHUNK - 1) // fullrun.CHUNK

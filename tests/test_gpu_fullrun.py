@@ -10,7 +10,7 @@ import pytest
 
 from cranesched_amd import synth
 from tests import fullrun
-from tests.golden.make_fullrun import CASES, load_case5
+from tests.golden.make_fullrun import CASES, load_case5, load_resv
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -28,6 +28,9 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
     eng = engine_cls(device=0)
     try:
         eng.set_nodes(cluster)
+        resv = load_resv(name, cluster)
+        if resv is not None:
+            eng.set_reservations(resv)
         if running is not None:
             eng.set_running(running)
         if pre is None:
@@ -41,7 +44,7 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
         msg = fullrun.compare(d, ref)
         assert msg is None, f"{tag}: engine differs from the oracle's full run: {msg}"
         t = eng.timing()
-        if name in synth.MIXED and os.environ.get("CNS_SELECT_KERNEL") in ("wide", "wide32"):   # the split really happened
+        if name in ("C4all", "C4rp") and os.environ.get("CNS_SELECT_KERNEL") in ("wide", "wide32"):   # the split really happened
             assert " + k_select" in eng.last_kernel() and eng.last_kernel().startswith("k_wide"), eng.last_kernel()
         print(f"{tag}: {jobs.num_jobs} jobs x {cluster.num_nodes} nodes identical to the oracle "
               f"(start-now {d['counts'][0]}, backfilled {d['counts'][1]}, failed {d['counts'][2]}); "
