@@ -152,7 +152,7 @@ def main():
         shards = []
         for rk in range(world):
             sj, sidx = sharding.shard(cluster, jobs, rk, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))
-            shards.append((sharding.unpack_results(host[rk * pad:(rk + 1) * pad], sj), sidx))
+            shards.append((sharding.unpack_results(host[rk * pad:(rk + 1) * pad], sj, cluster.wide_cores), sidx))
         merged = sharding.merge(jobs, shards)
         eng1 = GpuNodeSelector(device=local_rank)
         eng1.set_nodes(cluster)

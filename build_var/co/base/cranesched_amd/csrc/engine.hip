@@ -101,8 +101,7 @@ struct cns_engine {
   // job table
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
   std::vector<u64> place_off;
-  struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, c2, c3, total; } ro{};
-  bool wide_cores = false;   // a node of the snapshot has a core id above 127: the results carry the core_w2 / core_w3 planes
+  struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, total; } ro{};
   cns_timing timing{};
   std::string last_kernel;
   i64 last_now = 0;
@@ -219,8 +218,6 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.o_mem = (u64*)(rb + h->ro.mem);
   K.o_clo = (u64*)(rb + h->ro.clo);
   K.o_chi = (u64*)(rb + h->ro.chi);
-  K.o_c2 = h->wide_cores ? (u64*)(rb + h->ro.c2) : nullptr;
-  K.o_c3 = h->wide_cores ? (u64*)(rb + h->ro.c3) : nullptr;
   K.o_gres = (u64*)(rb + h->ro.gres);
   K.o_node = (u32*)(rb + h->ro.node);
   K.o_ntasks = (u32*)(rb + h->ro.ntasks);
@@ -373,13 +370,13 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   // (per partition / group: checked in cns_set_nodes — a partition that shares no node may be as wide as k_wide's widest tile)
   if (h->max_np > std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max))
     return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(w64::WideInfo::lanes * w64::WideInfo::npl_max) + " schedulable nodes");
-  std::map<std::tuple<i64, u64, u64, u64, u64, u64, u64>, u32> tmap;
+  std::map<std::tuple<i64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
   std::vector<uint8_t> slot_type(std::max<u32>(S, 1), 0);
   h->slot_tag.resize(S, 0);   // virtual (reservation) slots: tag 0
   for (u32 q = 0; q < S; ++q) {
     const Res& r = h->slot_total[q];
-    auto key = std::make_tuple(r.cpu, r.mem, r.clo, r.chi, r.gres, r.c2, r.c3);
+    auto key = std::make_tuple(r.cpu, r.mem, r.clo, r.chi, r.gres);
     auto it = tmap.find(key);
     if (it == tmap.end()) {
       if (type_total.size() >= CNS_MAX_NODE_TYPES)
@@ -426,7 +423,7 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   }
   if (int rc = upload(h, h->d_resv_se, resv_se)) return rc;
   const size_t S1 = std::max<u32>(S, 1);
-  HIPCHK(h, h->d_blocks.ensure(S1 * kBlockStride));  // 64.6 KB per node: HBM is plentiful
+  HIPCHK(h, h->d_blocks.ensure(S1 * kBlockStride));  // 48.5 KB per node: HBM is plentiful
   HIPCHK(h, h->d_cost.ensure(S1 * sizeof(double)));
   HIPCHK(h, h->d_fcpu.ensure(S1 * sizeof(int)));
   HIPCHK(h, h->d_fmem.ensure(S1 * sizeof(u32)));
@@ -537,15 +534,12 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   std::vector<Res> total(N);
   u64 all_gres = 0;
   for (u32 c = 0; c < h->gres.num_classes; ++c) all_gres |= h->gres.class_mask[c];
-  bool big = false, wide = false;
+  bool big = false;
   for (u32 n = 0; n < N; ++n) {
     total[n].cpu = nd->cpu_total_raw[n];
     total[n].mem = nd->mem_total[n];
     total[n].clo = nd->core_lo[n];
     total[n].chi = nd->core_hi ? nd->core_hi[n] : 0;
-    total[n].c2 = nd->core_w2 ? nd->core_w2[n] : 0;
-    total[n].c3 = nd->core_w3 ? nd->core_w3[n] : 0;
-    if (total[n].c2 | total[n].c3) wide = true;
     total[n].gres = nd->gres_slots ? nd->gres_slots[n] : 0;
     if (total[n].gres & ~all_gres) return fail(h, CNS_ERR_INVALID_ARG, "node GRES slot outside every class");
     if (total[n].gres || total[n].chi) big = true;
@@ -629,7 +623,7 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   for (const auto& m : members) h->eng_members.push_back((u32)m.size());
   h->node_slots = node_slots; h->slot_tag = slot_tag;
   P = PE;
-  h->N = N; h->P = P; h->S = S; h->max_np = max_np; h->big_nodes = big || wide; h->wide_cores = wide;
+  h->N = N; h->P = P; h->S = S; h->max_np = max_np; h->big_nodes = big;
   h->P_real = P; h->S_real = S; h->V = 0;
   h->part_off = part_off; h->slot_node = slot_node; h->node_slot = node_slot; h->orig_pos_slot = orig_pos_slot;
   h->node_total = total;
@@ -670,8 +664,6 @@ int cns_set_reservations(cns_handle* h, const cns_resv_soa* rv) {
       Res r;
       r.cpu = rv->alloc_cpu_raw[a]; r.mem = rv->alloc_mem[a]; r.clo = rv->alloc_core_lo[a];
       r.chi = rv->alloc_core_hi ? rv->alloc_core_hi[a] : 0;
-      r.c2 = rv->alloc_core_w2 ? rv->alloc_core_w2[a] : 0;
-      r.c3 = rv->alloc_core_w3 ? rv->alloc_core_w3[a] : 0;
       r.gres = rv->alloc_gres ? rv->alloc_gres[a] : 0;
       if (r.gres & ~all_gres) return fail(h, CNS_ERR_INVALID_ARG, "reservation GRES slot outside every class");
       if (r.cpu <= 0 || r.cpu >= 0x7FFFFFFEll) return fail(h, CNS_ERR_UNSUPPORTED, "reservation cpu share must be in (0, 2^31-2)");
@@ -759,8 +751,6 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
         r.mem = rn->alloc_mem[a];
         r.clo = rn->alloc_core_lo[a];
         r.chi = rn->alloc_core_hi ? rn->alloc_core_hi[a] : 0;
-        r.c2 = rn->alloc_core_w2 ? rn->alloc_core_w2[a] : 0;
-        r.c3 = rn->alloc_core_w3 ? rn->alloc_core_w3[a] : 0;
         r.gres = rn->alloc_gres ? rn->alloc_gres[a] : 0;
         for (u32 q : slots_of(j, rn->alloc_node[a])) {
           u32 d = cur[q]++;
@@ -909,10 +899,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   auto rsec = [&](size_t elem, u64 n) { size_t x = ro; ro = align16(ro + elem * (size_t)std::max<u64>(n, 1)); return x; };
   r.start = rsec(8, J); r.cpu = rsec(8, places); r.mem = rsec(8, places); r.clo = rsec(8, places);
   r.chi = rsec(8, places); r.gres = rsec(8, places); r.node = rsec(4, places); r.ntasks = rsec(4, places);
-  r.reason = rsec(1, J);
-  r.c2 = r.c3 = ro;   // the planes of core ids 128..255 exist only for a snapshot with such nodes (nothing more to ship otherwise)
-  if (h->wide_cores) { r.c2 = rsec(8, places); r.c3 = rsec(8, places); }
-  r.total = ro;
+  r.reason = rsec(1, J); r.total = ro;
   HIPCHK(h, h->d_results.ensure(ro));
   HIPCHK(h, hipEventRecord(e1, h->stream));
   HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1060,8 +1047,6 @@ int cns_download(cns_handle* h, cns_placement_soa* out) {
   if (!out->start_sec || !out->reason || !out->place_offsets || !out->node_idx || !out->ntasks || !out->cpu_raw ||
       !out->mem || !out->core_lo || !out->core_hi || !out->gres)
     return fail(h, CNS_ERR_INVALID_ARG, "cns_download: missing result array");
-  if (h->wide_cores && (!out->core_w2 || !out->core_w3))
-    return fail(h, CNS_ERR_INVALID_ARG, "cns_download: the snapshot has nodes with core ids above 127: core_w2 / core_w3 are required");
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
   const char* rb = h->d_results.as<char>();
@@ -1076,13 +1061,6 @@ int cns_download(cns_handle* h, cns_placement_soa* out) {
   HIPCHK(h, get(out->core_lo, h->ro.clo, 8 * pl));
   HIPCHK(h, get(out->core_hi, h->ro.chi, 8 * pl));
   HIPCHK(h, get(out->gres, h->ro.gres, 8 * pl));
-  if (h->wide_cores) {
-    HIPCHK(h, get(out->core_w2, h->ro.c2, 8 * pl));
-    HIPCHK(h, get(out->core_w3, h->ro.c3, 8 * pl));
-  } else {
-    if (out->core_w2 && pl) memset(out->core_w2, 0, 8 * pl);
-    if (out->core_w3 && pl) memset(out->core_w3, 0, 8 * pl);
-  }
   HIPCHK(h, get(out->node_idx, h->ro.node, 4 * pl));
   HIPCHK(h, get(out->ntasks, h->ro.ntasks, 4 * pl));
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
@@ -1357,23 +1335,6 @@ int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint
   for (u32 i = 0; i < m; ++i) {
     t[i] = e[i].t; cpu_raw[i] = e[i].r.cpu; mem[i] = e[i].r.mem; core_lo[i] = e[i].r.clo; core_hi[i] = e[i].r.chi; gres[i] = e[i].r.gres;
   }
-  return CNS_OK;
-}
-
-int cns_debug_get_timeline_cores(cns_handle* h, uint32_t node, uint32_t capacity, uint64_t* core_w2, uint64_t* core_w3) {
-  if (!h || !core_w2 || !core_w3) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_timeline_cores: null argument");
-  if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_timeline_cores before a successful run");
-  if (node >= h->N) return fail(h, CNS_ERR_INVALID_ARG, "cns_debug_get_timeline_cores: node out of range");
-  HIPCHK(h, hipSetDevice(h->device));
-  const u32 slot = h->node_slot[node];
-  if (slot == kNone) return CNS_OK;
-  const char* blk = h->d_blocks.as<char>() + (size_t)slot * kBlockStride;
-  NodeHdr hd;
-  HIPCHK(h, hipMemcpy(&hd, blk, sizeof hd, hipMemcpyDeviceToHost));
-  const u32 m = std::min(hd.len, capacity);
-  std::vector<TlEntry> e(std::max<u32>(m, 1));
-  if (m) HIPCHK(h, hipMemcpy(e.data(), blk + sizeof(NodeHdr), (size_t)m * sizeof(TlEntry), hipMemcpyDeviceToHost));
-  for (u32 i = 0; i < m; ++i) { core_w2[i] = e[i].r.c2; core_w3[i] = e[i].r.c3; }
   return CNS_OK;
 }
 

@@ -57,8 +57,8 @@ struct NodeHdr {
   Res avail0;
   Res total;
 };
-static_assert(sizeof(NodeHdr) == 128, "NodeHdr = 2 TlEntry slots");
-static_assert(sizeof(TlEntry) == 64, "TlEntry layout: one entry per 64-byte line segment");
+static_assert(sizeof(NodeHdr) == 96, "NodeHdr = 2 TlEntry slots");
+static_assert(sizeof(TlEntry) == 48, "TlEntry layout");
 constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * sizeof(TlEntry);
 
 // Job record: 64 dwords, lane-striped (lane i of a wave loads dword i: one VGPR while in flight).
@@ -176,8 +176,6 @@ struct KParams {
   u64* o_clo;
   u64* o_chi;
   u64* o_gres;
-  u64* o_c2;               // core ids 128..191 / 192..255 of the placement records; null unless a node of the snapshot has any
-  u64* o_c3;
   // ---- scratch ---------------------------------------------------------------------------
   HeapEnt* heap;           // [S + P] partition p uses [part_off[p] + p, ...) of size n_p + 1
   u32* bf_j;               // [S] backfill cursor per selected node

@@ -26,14 +26,12 @@ typedef uint32_t u32;
 constexpr int kMaxClasses = 8;
 constexpr int kMaxNames = 4;
 
-// ResourceInNodeV3 in mask form: cpu raw (x256), mem bytes, 256 core bits (ids 0..63, 64..127, 128..191, 192..255:
-// CpuSet::core_ids is an unbounded set, PublicHeader.h:555-573; 256 ids are what the engine carries), 64 GRES slot bits.
+// ResourceInNodeV3 in mask form: cpu raw (x256), mem bytes, 128 core bits, 64 GRES slot bits.
 struct Res {
   i64 cpu;
   u64 mem;
   u64 clo, chi;
   u64 gres;
-  u64 c2, c3;
 };
 
 // One entry of a node's time -> available-resource map (std::map<absl::Time, ResourceInNodeV3>,
@@ -77,18 +75,11 @@ CNS_HD u64 lowest_n(u64 x, int n) {
 }
 
 CNS_HD u32 byte_of(u64 v, int i) { return (u32)((v >> (8 * i)) & 0xFF); }
-CNS_HD bool cores_empty(const Res& r) { return (r.clo | r.chi | r.c2 | r.c3) == 0; }
-CNS_HD u32 cores_count(const Res& r) { return (u32)(popc64(r.clo) + popc64(r.chi) + popc64(r.c2) + popc64(r.c3)); }
-CNS_HD void cores_clear(Res& r) { r.clo = 0; r.chi = 0; r.c2 = 0; r.c3 = 0; }
-CNS_HD void cores_fill(Res& r) { r.clo = ~0ull; r.chi = ~0ull; r.c2 = ~0ull; r.c3 = ~0ull; }
-CNS_HD void cores_copy(Res& r, const Res& s) { r.clo = s.clo; r.chi = s.chi; r.c2 = s.c2; r.c3 = s.c3; }
-CNS_HD void cores_and(Res& r, const Res& s) { r.clo &= s.clo; r.chi &= s.chi; r.c2 &= s.c2; r.c3 &= s.c3; }
+CNS_HD bool cores_empty(const Res& r) { return (r.clo | r.chi) == 0; }
 
 CNS_HD void res_sub(Res& a, const Res& b) {  // PublicHeader.cpp:789-796,758-766 (tolerant core erase)
   a.clo &= ~b.clo;
   a.chi &= ~b.chi;
-  a.c2 &= ~b.c2;
-  a.c3 &= ~b.c3;
   a.cpu -= b.cpu;
   a.mem -= b.mem;
   a.gres &= ~b.gres;
@@ -96,8 +87,6 @@ CNS_HD void res_sub(Res& a, const Res& b) {  // PublicHeader.cpp:789-796,758-766
 CNS_HD void res_add(Res& a, const Res& b) {  // PublicHeader.cpp:781-787
   a.clo |= b.clo;
   a.chi |= b.chi;
-  a.c2 |= b.c2;
-  a.c3 |= b.c3;
   a.cpu += b.cpu;
   a.mem += b.mem;
   a.gres |= b.gres;
@@ -107,7 +96,10 @@ CNS_HD bool res_le(const Res& a, const Res& b) {  // PublicHeader.cpp:886-890 (c
 }
 CNS_HD void res_ckmin(Res& a, const Res& b) {  // PublicHeader.cpp:815-827
   a.cpu = a.cpu < b.cpu ? a.cpu : b.cpu;
-  if (!cores_empty(a) && !cores_empty(b)) cores_and(a, b);
+  if (!cores_empty(a) && !cores_empty(b)) {
+    a.clo &= b.clo;
+    a.chi &= b.chi;
+  }
   a.mem = a.mem < b.mem ? a.mem : b.mem;
   a.gres &= b.gres;
 }
@@ -127,17 +119,21 @@ CNS_HD bool feasible(const Req& q, const Res& a, Res& out, const GresDev& L) {
   Res c;
   c.cpu = q.cpu;
   c.mem = q.mem;
-  cores_clear(c);
+  c.clo = 0;
+  c.chi = 0;
   c.gres = 0;
   i64 req_int = q.cpu / 256;                                        // :528
   bool is_int = (req_int * 256 == q.cpu) && !cores_empty(a);        // :529-530
   if (is_int) {
-    if (cores_count(a) < (u32)req_int) return false;                // :534
-    int left = (int)req_int;                                        // the n lowest core ids (:536-541)
-    c.clo = lowest_n(a.clo, left); left -= popc64(c.clo);
-    if (left > 0) { c.chi = lowest_n(a.chi, left); left -= popc64(c.chi); }
-    if (left > 0) { c.c2 = lowest_n(a.c2, left); left -= popc64(c.c2); }
-    if (left > 0) c.c3 = lowest_n(a.c3, left);
+    int nlo = popc64(a.clo);
+    if ((u32)(nlo + popc64(a.chi)) < (u32)req_int) return false;    // :534
+    int n = (int)req_int;
+    if (n <= nlo) {
+      c.clo = lowest_n(a.clo, n);
+    } else {
+      c.clo = a.clo;
+      c.chi = lowest_n(a.chi, n - nlo);
+    }
   }
   if (q.gtot | q.gspec) {
     for (int name = 0; name < kMaxNames; ++name) {                  // :549

@@ -59,8 +59,6 @@ __device__ __forceinline__ Res rl_res(const Res& r, u32 idx) {
   o.clo = rl64(r.clo, idx);
   o.chi = rl64(r.chi, idx);
   o.gres = rl64(r.gres, idx);
-  o.c2 = rl64(r.c2, idx);
-  o.c3 = rl64(r.c3, idx);
   return o;
 }
 
@@ -69,7 +67,6 @@ __device__ __forceinline__ Res rl_res(const Res& r, u32 idx) {
 __device__ __forceinline__ Res uni_res(const Res& r) {
   Res o;
   o.cpu = (i64)uni64((u64)r.cpu); o.mem = uni64(r.mem); o.clo = uni64(r.clo); o.chi = uni64(r.chi); o.gres = uni64(r.gres);
-  o.c2 = uni64(r.c2); o.c3 = uni64(r.c3);
   return o;
 }
 
@@ -227,7 +224,7 @@ __device__ __forceinline__ u64 class_counts(u64 gres, const GresDev& L) {
 __device__ __forceinline__ void set_fault(const KParams& P, u32 code, u32 a, u32 b, u32 c) {
   if (atomicCAS(P.fault, 0u, code) == 0u) { P.fault[1] = a; P.fault[2] = b; P.fault[3] = c; }
 }
-__device__ __forceinline__ Res res_zero() { Res r; r.cpu = 0; r.mem = 0; cores_clear(r); r.gres = 0; return r; }
+__device__ __forceinline__ Res res_zero() { Res r; r.cpu = 0; r.mem = 0; r.clo = 0; r.chi = 0; r.gres = 0; return r; }
 
 // The NodeBlock of slot q.  When partitions share nodes (P.slot_block != null) every slot of a node points at the block
 // of the node's first slot: ONE time map per craned, whatever partition a job came through (JobScheduler.cpp:6563,6609-6617).
@@ -569,7 +566,7 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
   u64 tyok = 0;
   for (u32 t = 0; t < P.num_types; ++t) {
     const Res tt = P.type_total[t];
-    if (feasible_counts(mv, tt.cpu, tt.mem, cores_count(tt), class_counts(tt.gres, P.gres), P.gres))
+    if (feasible_counts(mv, tt.cpu, tt.mem, (u32)(popc64(tt.clo) + popc64(tt.chi)), class_counts(tt.gres, P.gres), P.gres))
       tyok |= 1ull << t;
   }
   rec[kJdMcpu] = (u32)(u64)mv.cpu; rec[kJdMcpu + 1] = (u32)((u64)mv.cpu >> 32);
@@ -615,8 +612,8 @@ __device__ __forceinline__ Res window_min_regs(const TlEntry& e, bool act, const
   const bool inw = act && e.t < E;
   i64 cpu = inw ? e.r.cpu : a0.cpu;
   u64 mem = inw ? e.r.mem : a0.mem;
-  const bool hasc = inw && !cores_empty(e.r);  // an empty core set is skipped by Ckmin
-  u64 clo = hasc ? e.r.clo : ~0ull, chi = hasc ? e.r.chi : ~0ull, c2 = hasc ? e.r.c2 : ~0ull, c3 = hasc ? e.r.c3 : ~0ull;
+  const bool hasc = inw && (e.r.clo | e.r.chi) != 0;  // an empty core set is skipped by Ckmin
+  u64 clo = hasc ? e.r.clo : ~0ull, chi = hasc ? e.r.chi : ~0ull;
   u64 g = inw ? e.r.gres : ~0ull;
   Res m;
   cpu = wave_min_i64(cpu);
@@ -626,16 +623,15 @@ __device__ __forceinline__ Res window_min_regs(const TlEntry& e, bool act, const
   clo = wave_and_u64(clo);
   chi = wave_and_u64(chi);
   m.gres = wave_and_u64(g) & a0.gres;
-  if (a0.c2 | a0.c3) { c2 = wave_and_u64(c2); c3 = wave_and_u64(c3); }   // (uniform: a node without core ids above 127 pays nothing)
-  if (!cores_empty(a0)) { m.clo = a0.clo & clo; m.chi = a0.chi & chi; m.c2 = a0.c2 & c2; m.c3 = a0.c3 & c3; }
-  else cores_clear(m);
+  if ((a0.clo | a0.chi) != 0) { m.clo = a0.clo & clo; m.chi = a0.chi & chi; }
+  else { m.clo = 0; m.chi = 0; }
   return m;
 }
 
 // General form for time maps longer than one chunk.
 __device__ __noinline__ Res window_min(const TlEntry* T, u32 len, const Res& a0, i64 E, u32 lane) {
   i64 cpu = a0.cpu;
-  u64 mem = a0.mem, clo = ~0ull, chi = ~0ull, c2 = ~0ull, c3 = ~0ull, g = a0.gres;
+  u64 mem = a0.mem, clo = ~0ull, chi = ~0ull, g = a0.gres;
   for (u32 base = 0; base < len; base += 64) {
     u32 i = base + lane;
     bool act = i < len;
@@ -646,7 +642,7 @@ __device__ __noinline__ Res window_min(const TlEntry* T, u32 len, const Res& a0,
     if (inw) {
       cpu = e.r.cpu < cpu ? e.r.cpu : cpu;
       mem = e.r.mem < mem ? e.r.mem : mem;
-      if (!cores_empty(e.r)) { clo &= e.r.clo; chi &= e.r.chi; c2 &= e.r.c2; c3 &= e.r.c3; }
+      if ((e.r.clo | e.r.chi) != 0) { clo &= e.r.clo; chi &= e.r.chi; }
       g &= e.r.gres;
     }
     if (__any(act && !inw)) break;  // sorted by time: nothing later is inside the window
@@ -656,11 +652,9 @@ __device__ __noinline__ Res window_min(const TlEntry* T, u32 len, const Res& a0,
   m.mem = wave_min_u64(mem);
   clo = wave_and_u64(clo);
   chi = wave_and_u64(chi);
-  c2 = wave_and_u64(c2);
-  c3 = wave_and_u64(c3);
   m.gres = wave_and_u64(g);
-  if (!cores_empty(a0)) { m.clo = a0.clo & clo; m.chi = a0.chi & chi; m.c2 = a0.c2 & c2; m.c3 = a0.c3 & c3; }
-  else cores_clear(m);
+  if ((a0.clo | a0.chi) != 0) { m.clo = a0.clo & clo; m.chi = a0.chi & chi; }
+  else { m.clo = 0; m.chi = 0; }
   return m;
 }
 
@@ -908,7 +902,6 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
     P.o_clo[o] = me.res.clo;
     P.o_chi[o] = me.res.chi;
     P.o_gres[o] = me.res.gres;
-    if (P.o_c2) { P.o_c2[o] = me.res.c2; P.o_c3[o] = me.res.c3; }
     if (P.pre.enabled) {   // UpdateNodeSelectorWithScheduledJob (h:636-642): the job joins its nodes' qos_job_map
       const u32 q = qbeg + slot_of_code_t<kS>(me.p);
       P.pre.rec_orig[o] = orig; P.pre.rec_slot[o] = q; P.pre.rec_gone[o] = 0;
@@ -967,7 +960,6 @@ __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 
     P.o_clo[poff] = alloc.clo;
     P.o_chi[poff] = alloc.chi;
     P.o_gres[poff] = alloc.gres;
-    if (P.o_c2) { P.o_c2[poff] = alloc.c2; P.o_c3[poff] = alloc.c3; }
     P.o_start[orig] = start;
     P.o_reason[orig] = (uint8_t)reason;
   }
@@ -1036,7 +1028,7 @@ __device__ __noinline__ bool distribute_and_alloc(const KParams& P, const JobCtx
 //                 W: allocations vs res_total, earliest start, commit -> verdict       B3
 // ---------------------------------------------------------------------------------------------
 struct AllocCacheEnt {  // (request shape, node type) -> allocation against res_total
-  i64 cpu; u64 gspec; u32 gtot; u32 type; u64 clo, chi, gres, c2, c3;
+  i64 cpu; u64 gspec; u32 gtot; u32 type; u64 clo, chi, gres;
 };
 constexpr int kAllocCache = 256;
 struct WorkerShared {
@@ -1350,7 +1342,6 @@ __device__ __forceinline__ void emit_placements(const KParams& P, const JobCtx& 
     P.o_node[o] = me.node; P.o_ntasks[o] = 1;
     P.o_cpu[o] = me.res.cpu; P.o_mem[o] = me.res.mem; P.o_clo[o] = me.res.clo; P.o_chi[o] = me.res.chi;
     P.o_gres[o] = me.res.gres;
-    if (P.o_c2) { P.o_c2[o] = me.res.c2; P.o_c3[o] = me.res.c3; }
   }
 }
 
@@ -1514,7 +1505,6 @@ __device__ __forceinline__ void helper_commit_regs(const KParams& P, const GresD
     const u64 o = J.poff + rank;
     P.o_node[o] = h.node; P.o_ntasks[o] = 1;
     P.o_cpu[o] = res.cpu; P.o_mem[o] = res.mem; P.o_clo[o] = res.clo; P.o_chi[o] = res.chi; P.o_gres[o] = res.gres;
-    if (P.o_c2) { P.o_c2[o] = res.c2; P.o_c3[o] = res.c3; }
   }
 }
 
@@ -1543,7 +1533,7 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const GresDev
     bool ok = feasible(J.min_view, m, f, G);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
     if (ok) {
       const i64 req_int = J.min_view.cpu / 256;
-      const u32 nc0 = cores_count(h.avail0);
+      const u32 nc0 = (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi));
       if (req_int * 256 == J.min_view.cpu && nc0 != 0 && nc0 < (u32)req_int) ok = false;   // :528-534 on res_avail
     }
     if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
@@ -1733,7 +1723,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 
   const Res ttot = lane < P.num_types ? P.type_total[lane] : res_zero();  // lane t holds node type t
   TypeLane tyl;
-  tyl.cpu = ttot.cpu; tyl.mem = ttot.mem; tyl.ncores = cores_count(ttot);
+  tyl.cpu = ttot.cpu; tyl.mem = ttot.mem; tyl.ncores = (u32)(popc64(ttot.clo) + popc64(ttot.chi));
   tyl.cnt = class_counts(ttot.gres, P.gres);
   int par = 0;
 
@@ -1829,7 +1819,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           ok = feasible(F.mv, m, f, P.gres);                             // get_max_tasks(min_res) > 0, :6285
           if (ok) {
             const i64 req_int = F.mv.cpu / 256;
-            const u32 nc0 = cores_count(h.avail0);
+            const u32 nc0 = (u32)(popc64(h.avail0.clo) + popc64(h.avail0.chi));
             if (req_int * 256 == F.mv.cpu && nc0 != 0 && nc0 < (u32)req_int) ok = false;   // :528-534 on res_avail
           }
           PROF_T(a2);
@@ -1883,14 +1873,13 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
                 if (hit) {
                   alloc.cpu = F.mv.cpu; alloc.mem = F.mv.mem;
                   alloc.clo = uni64(c.clo); alloc.chi = uni64(c.chi); alloc.gres = uni64(c.gres);
-                  alloc.c2 = uni64(c.c2); alloc.c3 = uni64(c.c3);
                 } else {
                   if (!feasible(F.mv, h.total, alloc, P.gres)) {  // :6354-6356; cannot fail: the T argmin only ranks nodes whose res_total fits
                     if (lane == 0) set_fault(P, 3, F.orig, h.node, 0);
                   } else if (lane == 0) {
                     AllocCacheEnt w;
                     w.cpu = F.mv.cpu; w.gspec = F.mv.gspec; w.gtot = F.mv.gtot; w.type = h.type;
-                    w.clo = alloc.clo; w.chi = alloc.chi; w.gres = alloc.gres; w.c2 = alloc.c2; w.c3 = alloc.c3;
+                    w.clo = alloc.clo; w.chi = alloc.chi; w.gres = alloc.gres;
                     s_ac[hs] = w;
                   }
                 }

@@ -5,7 +5,7 @@
 // first one that does not fit stops the queue), but jobs never share an allocation: ONE THREAD PER JOB, thousands of
 // independent chains.  The work per node is the exact bit-mask algebra of the node-selection path (res_dev.h:
 // GetFeasibleResourceInNode, -=), the top-k queue is libstdc++'s heap move for move (as in pq_emul.h, on an 8-byte
-// entry).  Availability lives in HBM as one 56-byte Res per (job, node), updated in place.
+// entry).  Availability lives in HBM as one 40-byte Res per (job, node), updated in place.
 //
 // Included by engine.hip (one translation unit, namespace cns).
 #pragma once

@@ -25,9 +25,7 @@
  *   cpu    : int64 raw fixed point, value*256   (cpu_t = fpm::fixed<int64,__int128,8>,
  *            src/Utilities/PublicHeader/include/crane/PublicHeader.h:44)
  *   mem    : uint64 bytes (mem_sw is never tested on this path and is not carried)
- *   cores  : 256-bit mask over core ids 0..255 (core_lo = ids 0..63, core_hi = 64..127, core_w2 = 128..191,
- *            core_w3 = 192..255; the last two are optional planes at the END of every struct that carries core ids:
- *            NULL = no core id above 127, the layout of ABI 2 is a prefix of ABI 3)
+ *   cores  : 128-bit mask over core ids 0..127 (core_lo = ids 0..63, core_hi = 64..127)
  *   gres   : 64-bit slot mask; class g = (name,type) owns bits
  *            [class_shift[g], class_shift[g]+class_width[g]); bit order inside a
  *            class = lexicographic order of the slot's device path (the order of
@@ -52,8 +50,7 @@
 extern "C" {
 #endif
 
-#define CNS_ABI_VERSION 3u /* 2: reservations (cns_resv_soa, `reservation` on running / pending jobs); 3: core ids 128..255
-                              (core_w2 / core_w3 planes appended to cns_node_soa, cns_running_soa, cns_resv_soa, cns_placement_soa) */
+#define CNS_ABI_VERSION 2u /* 2: reservations (cns_resv_soa, `reservation` on running / pending jobs) */
 #define CNS_MAX_GRES_CLASSES 8u
 #define CNS_MAX_GRES_NAMES 4u
 #define CNS_MAX_NODE_TYPES 64u /* distinct res_total records per cycle */
@@ -116,9 +113,6 @@ typedef struct cns_node_soa {
   const uint32_t* part_nodes;     /* node indices of each partition; a node may be listed by several partitions:
                                      one NodeState per node, one cost per (partition, node), JobScheduler.cpp:6585-6617 */
   cns_gres_layout gres;
-  const uint64_t* core_w2;        /* [num_nodes] core ids 128..191 (may be NULL = 0); CpuSet::core_ids is a set of
-                                     uint32 ids without a bound, PublicHeader.h:555-573: 256 ids are what the engine carries */
-  const uint64_t* core_w3;        /* [num_nodes] core ids 192..255 (may be NULL = 0) */
 } cns_node_soa;
 
 /* Running jobs' per-node allocations (RnJobInScheduler, JobScheduler.h:57-90;
@@ -136,8 +130,6 @@ typedef struct cns_running_soa {
   const uint64_t* alloc_core_hi;  /* may be NULL */
   const uint64_t* alloc_gres;     /* may be NULL */
   const uint32_t* reservation;    /* [num_jobs] reservation index the job runs in (JobScheduler.cpp:6692-6707) or CNS_RESV_NONE; NULL = none */
-  const uint64_t* alloc_core_w2;  /* core ids 128..191 / 192..255 of the allocation; may be NULL */
-  const uint64_t* alloc_core_w3;
 } cns_running_soa;
 
 /* Reservations of the cycle = what NodeSelect reads from g_meta_container->GetResvMetaMapPtr()
@@ -164,8 +156,6 @@ typedef struct cns_resv_soa {
   const uint64_t* alloc_core_lo;
   const uint64_t* alloc_core_hi;  /* may be NULL */
   const uint64_t* alloc_gres;     /* may be NULL */
-  const uint64_t* alloc_core_w2;  /* core ids 128..191 / 192..255 of the reserved share; may be NULL */
-  const uint64_t* alloc_core_w3;
 } cns_resv_soa;
 
 /* Pending jobs in priority order (PdJobInScheduler, JobScheduler.h:92-170).
@@ -211,8 +201,6 @@ typedef struct cns_placement_soa {
   uint64_t* core_lo;
   uint64_t* core_hi;
   uint64_t* gres;
-  uint64_t* core_w2;         /* allocated core ids 128..191 / 192..255; may be NULL unless a node of the snapshot has a  */
-  uint64_t* core_w3;         /* core id above 127 (then cns_download fails with CNS_ERR_INVALID_ARG)                      */
 } cns_placement_soa;
 
 /* Timing of the last cns_select / cns_run_resident (HIP events on the engine's stream). */
@@ -257,8 +245,6 @@ int cns_debug_get_costs(cns_handle* h, double* cost_by_part_slot /* [len(part_no
 int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint32_t* len,
                            int64_t* t, int64_t* cpu_raw, uint64_t* mem, uint64_t* core_lo,
                            uint64_t* core_hi, uint64_t* gres);
-/* ... and the core ids 128..255 of the same entries (0 for nodes without any). */
-int cns_debug_get_timeline_cores(cns_handle* h, uint32_t node, uint32_t capacity, uint64_t* core_w2, uint64_t* core_w3);
 
 /* Name of the selection kernel the last cns_run_resident launched ("k_pipe<16>", "k_select<19>", ...; "" before a run). */
 const char* cns_debug_last_kernel(const cns_handle* h);

@@ -46,8 +46,6 @@ typedef struct cns_step_job_soa {
   const uint64_t* avail_core_hi;   /* may be NULL = 0 */
   const uint64_t* avail_gres;      /* may be NULL = 0 */
   const uint32_t* step_offsets;    /* [num_jobs+1] CSR over cns_step_soa: pending_step_ids_ in queue order */
-  const uint64_t* avail_core_w2;   /* core ids 128..191 / 192..255 (ABI 3); may be NULL = 0 */
-  const uint64_t* avail_core_w3;
 } cns_step_job_soa;
 
 /* Pending steps (CommonStepInCtld fields read at CtldPublicDefs.cpp:2052-2125), grouped by job. */
@@ -97,13 +95,6 @@ typedef struct cns_step_result_soa {
   uint64_t* avail_core_lo;
   uint64_t* avail_core_hi;
   uint64_t* avail_gres;
-  /* core ids 128..191 / 192..255 of the three record kinds (ABI 3); each may be NULL when the input carried none */
-  uint64_t* node_core_w2;
-  uint64_t* node_core_w3;
-  uint64_t* task_core_w2;
-  uint64_t* task_core_w3;
-  uint64_t* avail_core_w2;
-  uint64_t* avail_core_w3;
 } cns_step_result_soa;
 
 /* One pass of SchedulePendingSteps over all the jobs.  Needs cns_set_nodes (GRES layout).  *kernel_ms (may be NULL):

@@ -14,7 +14,7 @@ from typing import Optional
 
 import numpy as np
 
-CNS_ABI_VERSION = 2
+CNS_ABI_VERSION = 3
 RESV_NONE = 0xFFFFFFFF
 MAX_GRES_CLASSES = 8
 MAX_GRES_NAMES = 4
@@ -54,19 +54,20 @@ class CnsNodeSoa(C.Structure):
     _fields_ = [("num_nodes", C.c_uint32), ("num_partitions", C.c_uint32),
                 ("cpu_total_raw", _P), ("mem_total", _P), ("core_lo", _P), ("core_hi", _P),
                 ("gres_slots", _P), ("schedulable", _P), ("part_offsets", _P), ("part_nodes", _P),
-                ("gres", CnsGresLayout)]
+                ("gres", CnsGresLayout), ("core_w2", _P), ("core_w3", _P)]
 
 
 class CnsRunningSoa(C.Structure):
     _fields_ = [("num_jobs", C.c_uint32), ("num_allocs", C.c_uint32), ("end_sec", _P),
                 ("alloc_offsets", _P), ("alloc_node", _P), ("alloc_cpu_raw", _P), ("alloc_mem", _P),
-                ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P), ("reservation", _P)]
+                ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P), ("reservation", _P),
+                ("alloc_core_w2", _P), ("alloc_core_w3", _P)]
 
 
 class CnsResvSoa(C.Structure):
     _fields_ = [("num_resv", C.c_uint32), ("num_allocs", C.c_uint32), ("start_sec", _P), ("end_sec", _P),
                 ("alloc_offsets", _P), ("alloc_node", _P), ("alloc_cpu_raw", _P), ("alloc_mem", _P),
-                ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P)]
+                ("alloc_core_lo", _P), ("alloc_core_hi", _P), ("alloc_gres", _P), ("alloc_core_w2", _P), ("alloc_core_w3", _P)]
 
 
 class CnsJobSoa(C.Structure):
@@ -81,7 +82,7 @@ class CnsJobSoa(C.Structure):
 class CnsPlacementSoa(C.Structure):
     _fields_ = [("place_capacity", C.c_uint64), ("start_sec", _P), ("reason", _P),
                 ("place_offsets", _P), ("node_idx", _P), ("ntasks", _P), ("cpu_raw", _P),
-                ("mem", _P), ("core_lo", _P), ("core_hi", _P), ("gres", _P)]
+                ("mem", _P), ("core_lo", _P), ("core_hi", _P), ("gres", _P), ("core_w2", _P), ("core_w3", _P)]
 
 
 class CnsTiming(C.Structure):
@@ -131,9 +132,15 @@ class Cluster:
     part_nodes: np.ndarray
     gres: GresLayout = field(default_factory=GresLayout)
     schedulable: Optional[np.ndarray] = None
+    core_w2: Optional[np.ndarray] = None    # core ids 128..191 / 192..255 (ABI 3); None = no node has any
+    core_w3: Optional[np.ndarray] = None
 
     def __post_init__(self):
         n = len(self.cpu_total_raw)
+        if self.core_w2 is not None:
+            self.core_w2 = _arr(self.core_w2, np.uint64, n)
+        if self.core_w3 is not None:
+            self.core_w3 = _arr(self.core_w3, np.uint64, n)
         self.cpu_total_raw = _arr(self.cpu_total_raw, np.int64)
         self.mem_total = _arr(self.mem_total, np.uint64, n)
         self.core_lo = _arr(self.core_lo, np.uint64, n)
@@ -152,6 +159,11 @@ class Cluster:
     def num_partitions(self):
         return len(self.part_offsets) - 1
 
+    @property
+    def wide_cores(self) -> bool:
+        """A node has a core id above 127: results carry the core_w2 / core_w3 planes (cns_placement_soa, packed buffer)."""
+        return bool((self.core_w2 is not None and self.core_w2.any()) or (self.core_w3 is not None and self.core_w3.any()))
+
     def to_c(self) -> CnsNodeSoa:
         s = CnsNodeSoa()
         s.num_nodes, s.num_partitions = self.num_nodes, self.num_partitions
@@ -160,6 +172,7 @@ class Cluster:
         s.schedulable = _ptr(self.schedulable)
         s.part_offsets, s.part_nodes = _ptr(self.part_offsets), _ptr(self.part_nodes)
         s.gres = self.gres.to_c()
+        s.core_w2, s.core_w3 = _ptr(self.core_w2), _ptr(self.core_w3)
         return s
 
 
@@ -175,6 +188,8 @@ class Running:
     alloc_core_hi: np.ndarray
     alloc_gres: np.ndarray
     reservation: Optional[np.ndarray] = None   # [R] reservation index or RESV_NONE
+    alloc_core_w2: Optional[np.ndarray] = None
+    alloc_core_w3: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.end_sec = _arr(self.end_sec, np.int64)
@@ -188,6 +203,10 @@ class Running:
         self.alloc_core_lo = _arr(self.alloc_core_lo, np.uint64, m)
         self.alloc_core_hi = _arr(self.alloc_core_hi, np.uint64, m)
         self.alloc_gres = _arr(self.alloc_gres, np.uint64, m)
+        if self.alloc_core_w2 is not None:
+            self.alloc_core_w2 = _arr(self.alloc_core_w2, np.uint64, m)
+        if self.alloc_core_w3 is not None:
+            self.alloc_core_w3 = _arr(self.alloc_core_w3, np.uint64, m)
 
     def to_c(self) -> CnsRunningSoa:
         s = CnsRunningSoa()
@@ -196,6 +215,7 @@ class Running:
         s.alloc_cpu_raw, s.alloc_mem = _ptr(self.alloc_cpu_raw), _ptr(self.alloc_mem)
         s.alloc_core_lo, s.alloc_core_hi, s.alloc_gres = _ptr(self.alloc_core_lo), _ptr(self.alloc_core_hi), _ptr(self.alloc_gres)
         s.reservation = _ptr(self.reservation)
+        s.alloc_core_w2, s.alloc_core_w3 = _ptr(self.alloc_core_w2), _ptr(self.alloc_core_w3)
         return s
 
 
@@ -211,6 +231,8 @@ class Reservations:
     alloc_core_lo: np.ndarray
     alloc_core_hi: np.ndarray
     alloc_gres: np.ndarray
+    alloc_core_w2: Optional[np.ndarray] = None
+    alloc_core_w3: Optional[np.ndarray] = None
 
     def __post_init__(self):
         self.start_sec = _arr(self.start_sec, np.int64)
@@ -224,6 +246,10 @@ class Reservations:
         self.alloc_core_lo = _arr(self.alloc_core_lo, np.uint64, m)
         self.alloc_core_hi = _arr(self.alloc_core_hi, np.uint64, m)
         self.alloc_gres = _arr(self.alloc_gres, np.uint64, m)
+        if self.alloc_core_w2 is not None:
+            self.alloc_core_w2 = _arr(self.alloc_core_w2, np.uint64, m)
+        if self.alloc_core_w3 is not None:
+            self.alloc_core_w3 = _arr(self.alloc_core_w3, np.uint64, m)
 
     @property
     def num_resv(self):
@@ -235,6 +261,7 @@ class Reservations:
         s.start_sec, s.end_sec, s.alloc_offsets = _ptr(self.start_sec), _ptr(self.end_sec), _ptr(self.alloc_offsets)
         s.alloc_node, s.alloc_cpu_raw, s.alloc_mem = _ptr(self.alloc_node), _ptr(self.alloc_cpu_raw), _ptr(self.alloc_mem)
         s.alloc_core_lo, s.alloc_core_hi, s.alloc_gres = _ptr(self.alloc_core_lo), _ptr(self.alloc_core_hi), _ptr(self.alloc_gres)
+        s.alloc_core_w2, s.alloc_core_w3 = _ptr(self.alloc_core_w2), _ptr(self.alloc_core_w3)
         return s
 
 
@@ -318,6 +345,8 @@ class Placements:
         self.core_lo = np.zeros(cap, np.uint64)
         self.core_hi = np.zeros(cap, np.uint64)
         self.gres = np.zeros(cap, np.uint64)
+        self.core_w2 = np.zeros(cap, np.uint64)
+        self.core_w3 = np.zeros(cap, np.uint64)
 
     def to_c(self) -> CnsPlacementSoa:
         s = CnsPlacementSoa()
@@ -327,7 +356,7 @@ class Placements:
         return s
 
     FIELDS = ("start_sec", "reason", "place_offsets", "node_idx", "ntasks", "cpu_raw", "mem",
-              "core_lo", "core_hi", "gres")
+              "core_lo", "core_hi", "gres", "core_w2", "core_w3")
 
     def trimmed(self):
         """Dict of result arrays cut to their logical lengths (for comparisons / hashing)."""
@@ -335,7 +364,8 @@ class Placements:
         return {"start_sec": self.start_sec[:j], "reason": self.reason[:j],
                 "place_offsets": self.place_offsets[:j + 1], "node_idx": self.node_idx[:c],
                 "ntasks": self.ntasks[:c], "cpu_raw": self.cpu_raw[:c], "mem": self.mem[:c],
-                "core_lo": self.core_lo[:c], "core_hi": self.core_hi[:c], "gres": self.gres[:c]}
+                "core_lo": self.core_lo[:c], "core_hi": self.core_hi[:c], "gres": self.gres[:c],
+                "core_w2": self.core_w2[:c], "core_w3": self.core_w3[:c]}
 
     def diff(self, other: "Placements"):
         """First differing (field, index) between two results, or None if bit-identical."""

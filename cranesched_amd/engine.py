@@ -26,7 +26,7 @@ _LIB = None
 # every symbol include/crane_gpu/node_select.h declares
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
                "cns_set_reservations", "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
-               "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline",
+               "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
                "cns_debug_last_kernel", "cns_debug_get_prof")
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
@@ -276,4 +276,7 @@ class GpuNodeSelector:
         self._check(self._L.cns_debug_get_timeline(self._h, C.c_uint32(node), C.c_uint32(cap), C.byref(n),
                                                    p(t), p(cpu), p(mem), p(lo), p(hi), p(g)))
         k = min(n.value, cap)
-        return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k]}
+        w2 = np.zeros(cap, np.uint64); w3 = np.zeros(cap, np.uint64)
+        self._check(self._L.cns_debug_get_timeline_cores(self._h, C.c_uint32(node), C.c_uint32(cap), p(w2), p(w3)))
+        return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k],
+                "core_w2": w2[:k], "core_w3": w3[:k]}

@@ -42,7 +42,7 @@ struct GpuNodeSelectionAlgo::Impl {
   // dense form (node indices, core / GRES masks) is kept per job id across cycles; a cycle costs one lookup per
   // running job instead of one string lookup + set -> mask conversion per allocated node.  Entries of jobs that did
   // not show up in a cycle are dropped; a new snapshot (new dense indices) drops everything.
-  struct AllocRec { uint32_t node; int64_t cpu; uint64_t mem, lo, hi, g; };
+  struct AllocRec { uint32_t node; int64_t cpu; uint64_t mem, lo, hi, g, w2, w3; };   // lo / hi / w2 / w3: core ids 0..255
   struct PackedAlloc {
     uint32_t resv;
     uint64_t gen;
@@ -51,7 +51,7 @@ struct GpuNodeSelectionAlgo::Impl {
   // the packed node table / reservations of the current snapshot, kept so that a state flip of one craned
   // (CranedUp / CranedDown / drain) re-sends them without touching a string
   std::vector<int64_t> n_cpu, v_start, v_end, v_cpu;
-  std::vector<uint64_t> n_mem, n_lo, n_hi, n_gres, v_mem, v_lo, v_hi, v_g;
+  std::vector<uint64_t> n_mem, n_lo, n_hi, n_gres, v_mem, v_lo, v_hi, v_g, n_w2, n_w3, v_w2, v_w3;
   std::vector<uint8_t> n_sched;
   std::vector<uint32_t> n_poff, n_pnodes, v_off, v_node;
   int push_tables(std::string& err) {   // cns_set_nodes + cns_set_reservations from the packed arrays
@@ -62,6 +62,7 @@ struct GpuNodeSelectionAlgo::Impl {
     nd.gres_slots = n_gres.data(); nd.schedulable = n_sched.data();
     nd.part_offsets = n_poff.data(); nd.part_nodes = n_pnodes.data();
     nd.gres = layout;
+    nd.core_w2 = n_w2.data(); nd.core_w3 = n_w3.data();
     int st = cns_set_nodes(h, &nd);
     if (st != 0) { err = cns_last_error(h); return st; }
     if (!v_start.empty()) {
@@ -69,7 +70,7 @@ struct GpuNodeSelectionAlgo::Impl {
       rv.num_resv = (uint32_t)v_start.size(); rv.num_allocs = (uint32_t)v_node.size();
       rv.start_sec = v_start.data(); rv.end_sec = v_end.data(); rv.alloc_offsets = v_off.data(); rv.alloc_node = v_node.data();
       rv.alloc_cpu_raw = v_cpu.data(); rv.alloc_mem = v_mem.data(); rv.alloc_core_lo = v_lo.data(); rv.alloc_core_hi = v_hi.data();
-      rv.alloc_gres = v_g.data();
+      rv.alloc_gres = v_g.data(); rv.alloc_core_w2 = v_w2.data(); rv.alloc_core_w3 = v_w3.data();
       st = cns_set_reservations(h, &rv);
       if (st != 0) { err = cns_last_error(h); return st; }
     }
@@ -96,7 +97,7 @@ struct GpuNodeSelectionAlgo::Impl {
   bool use_alloc_cache = true;
   std::vector<int64_t> r_end, r_cpu;
   std::vector<uint32_t> r_off, r_node, r_resv;
-  std::vector<uint64_t> r_mem, r_lo, r_hi, r_g;
+  std::vector<uint64_t> r_mem, r_lo, r_hi, r_g, r_w2, r_w3;
 
 
   // ---- pending jobs -> cns_job_soa arrays, and placements -> PdJobInScheduler.  The reference's structures — a
@@ -184,7 +185,7 @@ struct GpuNodeSelectionAlgo::Impl {
           p.craned_ids.push_back(cid);
           p.craned_id_to_task_num[cid] = o.ntasks[q];
           ResourceInNodeV3& res = p.allocated_res[cid];   // built in place (the map was cleared above)
-          fill_res(res, o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q]);
+          fill_res(res, o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q], o.core_w2 ? o.core_w2[q] : 0, o.core_w3 ? o.core_w3[q] : 0);
           // an exclusive job is allocated the node's whole res_total, memory_sw_bytes included (JobScheduler.cpp:6309-6310)
           res.memory_sw_bytes = p.exclusive ? node_mem_sw[o.node_idx[q]]
                                             : p.req_node_res_view.memory_sw_bytes + p.req_task_res_view.memory_sw_bytes * o.ntasks[q];
@@ -204,7 +205,7 @@ struct GpuNodeSelectionAlgo::Impl {
     r.packed.node = it->second;
     r.packed.cpu = r.res.cpu_set.cpu_count.raw;
     r.packed.mem = r.res.memory_bytes;
-    core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi);
+    core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi, r.packed.w2, r.packed.w3);
     r.packed.g = gres_mask(r.res.gres);
   }
   void repack_mirror() {   // after a new snapshot
@@ -212,7 +213,7 @@ struct GpuNodeSelectionAlgo::Impl {
       for (auto& r : mj.recs) pack_rec(r);
   }
   void pack_from_mirror() {
-    r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
+    r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear(); r_w2.clear(); r_w3.clear();
     r_src.clear();        // the mirror has no RnJobInScheduler objects: a cycle with preemption must be refused, never served from an
     r_src_valid = false;  // earlier explicit cycle's (freed) pointers that happen to match in number
     r_off.assign(1, 0);
@@ -229,7 +230,7 @@ struct GpuNodeSelectionAlgo::Impl {
         if (!r.known) continue;
         const AllocRec& a = r.packed;
         r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
-        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g);
+        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g); r_w2.push_back(a.w2); r_w3.push_back(a.w3);
       }
       r_off.push_back((uint32_t)r_node.size());
     }
@@ -241,7 +242,8 @@ struct GpuNodeSelectionAlgo::Impl {
     for (size_t j = 0; j + 1 < r_off.size(); ++j) {
       uint64_t s = h64((uint64_t)r_end[j]) ^ h64(r_resv[j] + 0x9e37ull);
       for (uint32_t a = r_off[j]; a < r_off[j + 1]; ++a)
-        s += h64(h64(r_node[a]) ^ h64((uint64_t)r_cpu[a] + 1) ^ h64(r_mem[a] + 2) ^ h64(r_lo[a] + 3) ^ h64(r_hi[a] + 4) ^ h64(r_g[a] + 5));
+        s += h64(h64(r_node[a]) ^ h64((uint64_t)r_cpu[a] + 1) ^ h64(r_mem[a] + 2) ^ h64(r_lo[a] + 3) ^ h64(r_hi[a] + 4) ^ h64(r_g[a] + 5) ^
+                 ((r_w2[a] | r_w3[a]) ? h64(r_w2[a] + 6) ^ h64(r_w3[a] + 7) : 0));
       acc = (acc ^ h64(s)) * 1099511628211ull;
     }
     return acc;
@@ -249,7 +251,7 @@ struct GpuNodeSelectionAlgo::Impl {
 
   // running jobs -> cns_running_soa arrays (JobScheduler.cpp:6681-6709); order = the caller's vector
   void pack_running(const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
-    r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear();
+    r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear(); r_w2.clear(); r_w3.clear();
     r_src.clear();
     r_src_valid = true;
     r_off.assign(1, 0);
@@ -278,7 +280,7 @@ struct GpuNodeSelectionAlgo::Impl {
           a.node = it->second;
           a.cpu = res.cpu_set.cpu_count.raw;
           a.mem = res.memory_bytes;
-          core_masks(res.cpu_set.core_ids, a.lo, a.hi);
+          core_masks(res.cpu_set.core_ids, a.lo, a.hi, a.w2, a.w3);
           a.g = gres_mask(res.gres);
           d.recs.push_back(a);
         }
@@ -290,7 +292,7 @@ struct GpuNodeSelectionAlgo::Impl {
       r_src.push_back(rn.get());
       for (const AllocRec& a : pa->recs) {
         r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
-        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g);
+        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g); r_w2.push_back(a.w2); r_w3.push_back(a.w3);
       }
       r_off.push_back((uint32_t)r_node.size());
     }
@@ -316,27 +318,31 @@ struct GpuNodeSelectionAlgo::Impl {
       }
     return m;
   }
-  // core ids as two 64-bit masks; an id >= 128 does not fit the engine's model: it is RECORDED (core_overflow) and the
+  // core ids as four 64-bit masks (ids 0..255, ABI 3); an id >= 256 does not fit the engine's model: it is RECORDED (core_overflow) and the
   // snapshot / cycle is refused — silently dropping it would make integer requests fail the `popc < n` test, or come back
   // without core ids, where ResourceView::GetFeasibleResourceInNode (PublicHeader.cpp:528-538) fits them
-  bool core_overflow = false;   // a core id >= 128 was met by the pack in progress (snapshot, running jobs or steps)
+  bool core_overflow = false;   // a core id >= 256 was met by the pack in progress (snapshot, running jobs or steps)
   bool snap_overflow = false;   // ... by the SNAPSHOT: it stays refused until the next SetClusterSnapshot
   std::string snap_error;       // why the last snapshot was refused (kept for the NodeSelect calls that follow it)
-  void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi) {
-    lo = hi = 0;
+  void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi, uint64_t& w2, uint64_t& w3) {
+    lo = hi = w2 = w3 = 0;
     for (uint32_t c : ids) {
       if (c < 64) lo |= 1ull << c;
       else if (c < 128) hi |= 1ull << (c - 64);
+      else if (c < 192) w2 |= 1ull << (c - 128);
+      else if (c < 256) w3 |= 1ull << (c - 192);
       else core_overflow = true;
     }
   }
   // fills `r` (a fresh or cleared ResourceInNodeV3) from the mask form; ids and slot paths arrive in ascending order,
   // so every set insertion is hinted at end()
-  void fill_res(ResourceInNodeV3& r, int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g) const {
+  void fill_res(ResourceInNodeV3& r, int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g, uint64_t w2 = 0, uint64_t w3 = 0) const {
     r.cpu_set.cpu_count = cpu_t::from_raw(cpu_raw);
     auto& ids = r.cpu_set.core_ids;
     for (uint64_t m = lo; m; m &= m - 1) ids.insert(ids.end(), (uint32_t)__builtin_ctzll(m));
     for (uint64_t m = hi; m; m &= m - 1) ids.insert(ids.end(), 64u + (uint32_t)__builtin_ctzll(m));
+    for (uint64_t m = w2; m; m &= m - 1) ids.insert(ids.end(), 128u + (uint32_t)__builtin_ctzll(m));
+    for (uint64_t m = w3; m; m &= m - 1) ids.insert(ids.end(), 192u + (uint32_t)__builtin_ctzll(m));
     r.memory_bytes = mem;
     r.memory_sw_bytes = mem;
     if (g)
@@ -348,9 +354,9 @@ struct GpuNodeSelectionAlgo::Impl {
         for (; bits; bits &= bits - 1) slots.insert(slots.end(), class_bit_slot[c][(uint32_t)__builtin_ctzll(bits)]);
       }
   }
-  ResourceInNodeV3 to_res(int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g) const {
+  ResourceInNodeV3 to_res(int64_t cpu_raw, uint64_t mem, uint64_t lo, uint64_t hi, uint64_t g, uint64_t w2 = 0, uint64_t w3 = 0) const {
     ResourceInNodeV3 r;
-    fill_res(r, cpu_raw, mem, lo, hi, g);
+    fill_res(r, cpu_raw, mem, lo, hi, g, w2, w3);
     return r;
   }
 
@@ -358,7 +364,7 @@ struct GpuNodeSelectionAlgo::Impl {
   struct PlacementStore {
     std::vector<int64_t> start, cpu;
     std::vector<uint8_t> reason, excl;
-    std::vector<uint64_t> off, mem, lo, hi, g, msw_node, msw_task;   // msw_*: the job's memory_sw request (node + per task)
+    std::vector<uint64_t> off, mem, lo, hi, g, w2, w3, msw_node, msw_task;   // msw_*: the job's memory_sw request (node + per task)
     std::vector<uint32_t> node, nt;
     size_t jobs = 0;
   } last;
@@ -412,15 +418,18 @@ struct GpuNodeSelectionAlgo::Impl {
   }
   // crane.grpc.ResourceInNodeV3 (PublicDefs.proto:63-69) of one packed allocation
   void append_res_wire(std::string& out, int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t lo, uint64_t hi, uint64_t g,
-                       std::string& t1, std::string& t2, std::string& t3, std::string& t4) const {
-    if (lo | hi) {   // repeated uint32 cpu_ids = 1, packed, ascending (std::set order)
+                       std::string& t1, std::string& t2, std::string& t3, std::string& t4, uint64_t w2 = 0, uint64_t w3 = 0) const {
+    if (lo | hi | w2 | w3) {   // repeated uint32 cpu_ids = 1, packed, ascending (std::set order)
       size_t n = 0;
       for (uint64_t m = lo; m; m &= m - 1) n += 1;                                       // ids 0..63: one byte each
       for (uint64_t m = hi; m; m &= m - 1) n += varint_size(64u + (uint32_t)__builtin_ctzll(m));
+      n += 2 * (size_t)(__builtin_popcountll(w2) + __builtin_popcountll(w3));            // ids 128..255: two bytes each
       out.push_back((char)0x0A);
       put_varint(out, n);
       for (uint64_t m = lo; m; m &= m - 1) out.push_back((char)__builtin_ctzll(m));
       for (uint64_t m = hi; m; m &= m - 1) put_varint(out, 64u + (uint32_t)__builtin_ctzll(m));
+      for (uint64_t m = w2; m; m &= m - 1) put_varint(out, 128u + (uint32_t)__builtin_ctzll(m));
+      for (uint64_t m = w3; m; m &= m - 1) put_varint(out, 192u + (uint32_t)__builtin_ctzll(m));
     }
     if (cpu_raw != 0) {   // double cpu_count = 2: static_cast<double>(cpu_t) = raw / 2^8, exact
       const double d = (double)cpu_raw / 256.0;
@@ -483,7 +492,7 @@ void GpuNodeSelectionAlgo::PendingCycleForBench(const std::vector<std::unique_pt
   *write_back_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   {  // the same placements as "the last cycle" of the wire emission (EmitWireForBench)
     Impl::PlacementStore& S = I.last;
-    S.start = st; S.cpu = cpu; S.reason = rs; S.off = off; S.mem = mem; S.lo = lo; S.hi = hi; S.g = g; S.node = node; S.nt = ntk;
+    S.start = st; S.cpu = cpu; S.reason = rs; S.off = off; S.mem = mem; S.lo = lo; S.hi = hi; S.g = g; S.node = node; S.nt = ntk; S.w2.assign(J, 0); S.w3.assign(J, 0);
     S.excl.assign(J, 0); S.msw_node.assign(J, 0); S.msw_task.assign(J, 0);
     S.jobs = J;
     I.last_ord.assign(ord.begin(), ord.end());
@@ -511,6 +520,10 @@ size_t GpuNodeSelectionAlgo::PackRunningForBench(const std::vector<std::unique_p
     mix(I.r_end.data(), I.r_end.size() * 8); mix(I.r_off.data(), I.r_off.size() * 4); mix(I.r_node.data(), I.r_node.size() * 4);
     mix(I.r_cpu.data(), I.r_cpu.size() * 8); mix(I.r_mem.data(), I.r_mem.size() * 8); mix(I.r_lo.data(), I.r_lo.size() * 8);
     mix(I.r_hi.data(), I.r_hi.size() * 8); mix(I.r_g.data(), I.r_g.size() * 8); mix(I.r_resv.data(), I.r_resv.size() * 4);
+    // (the planes of core ids 128..255 only when any is set: the checksums of runs without such nodes stay what they were)
+    bool anyw = false;
+    for (size_t i = 0; i < I.r_w2.size(); ++i) anyw = anyw || (I.r_w2[i] | I.r_w3[i]) != 0;
+    if (anyw) { mix(I.r_w2.data(), I.r_w2.size() * 8); mix(I.r_w3.data(), I.r_w3.size() * 8); }
     *checksum = hsh;
   }
   return I.r_node.size();
@@ -571,9 +584,10 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   }
   I.layout.num_classes = (uint32_t)I.classes.size();
 
-  auto &cpu = I.n_cpu; auto &mem = I.n_mem, &lo = I.n_lo, &hi = I.n_hi, &gres = I.n_gres;
+  auto &cpu = I.n_cpu; auto &mem = I.n_mem, &lo = I.n_lo, &hi = I.n_hi, &gres = I.n_gres, &w2 = I.n_w2, &w3 = I.n_w3;
   auto &sched = I.n_sched;
   cpu.assign(N, 0); mem.assign(N, 0); lo.assign(N, 0); hi.assign(N, 0); gres.assign(N, 0); sched.assign(N, 0);
+  w2.assign(N, 0); w3.assign(N, 0);
   for (uint32_t n = 0; n < N; ++n) {
     const CranedMeta& m = snap.craned_metas[n];
     I.node_name.push_back(m.craned_id);
@@ -581,7 +595,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     I.node_idx[m.craned_id] = n;
     cpu[n] = m.res_total.cpu_set.cpu_count.raw;
     mem[n] = m.res_total.memory_bytes;
-    I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n]);
+    I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n], w2[n], w3[n]);
     gres[n] = I.gres_mask(m.res_total.gres);
     sched[n] = m.alive && !m.drain;  // JobScheduler.cpp:6595
   }
@@ -599,7 +613,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   I.resv_idx.clear();
   const uint32_t V = (uint32_t)snap.reservations.size();
   I.v_start.assign(V, 0); I.v_end.assign(V, 0);
-  I.v_off.assign(1, 0); I.v_node.clear(); I.v_cpu.clear(); I.v_mem.clear(); I.v_lo.clear(); I.v_hi.clear(); I.v_g.clear();
+  I.v_off.assign(1, 0); I.v_node.clear(); I.v_cpu.clear(); I.v_mem.clear(); I.v_lo.clear(); I.v_hi.clear(); I.v_g.clear(); I.v_w2.clear(); I.v_w3.clear();
   for (uint32_t v = 0; v < V; ++v) {
     const ResvMeta& m = snap.reservations[v];
     I.resv_idx[m.name] = v;
@@ -610,9 +624,9 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
       I.v_node.push_back(it->second);
       I.v_cpu.push_back(res.cpu_set.cpu_count.raw);
       I.v_mem.push_back(res.memory_bytes);
-      uint64_t l, hh;
-      I.core_masks(res.cpu_set.core_ids, l, hh);
-      I.v_lo.push_back(l); I.v_hi.push_back(hh);
+      uint64_t l, hh, x2, x3;
+      I.core_masks(res.cpu_set.core_ids, l, hh, x2, x3);
+      I.v_lo.push_back(l); I.v_hi.push_back(hh); I.v_w2.push_back(x2); I.v_w3.push_back(x3);
       I.v_g.push_back(I.gres_mask(res.gres));
     }
     I.v_off.push_back((uint32_t)I.v_node.size());
@@ -622,7 +636,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   I.snap_error.clear();
   if (I.core_overflow) {
     status_ = CNS_ERR_UNSUPPORTED;
-    error_ = I.snap_error = "a node or reservation lists a core id >= 128 (the engine keeps core ids in two 64-bit masks); keep the CPU SchedulerAlgo";
+    error_ = I.snap_error = "a node or reservation lists a core id >= 256 (the engine keeps core ids in four 64-bit masks); keep the CPU SchedulerAlgo";
     return;
   }
   if (!I.h) return;   // no device: the dictionaries above still serve PackRunningForBench
@@ -703,7 +717,7 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   }
   if (I.core_overflow) {
     I.core_overflow = false;   // per pack: the next cycle's running set is judged on its own
-    return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 128");
+    return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 256");
   }
   const auto &r_end = I.r_end, &r_cpu = I.r_cpu;
   const auto &r_off = I.r_off, &r_node = I.r_node, &r_resv = I.r_resv;
@@ -713,6 +727,7 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   rs.end_sec = r_end.data(); rs.alloc_offsets = r_off.data(); rs.alloc_node = r_node.data();
   rs.alloc_cpu_raw = r_cpu.data(); rs.alloc_mem = r_mem.data(); rs.alloc_core_lo = r_lo.data();
   rs.alloc_core_hi = r_hi.data(); rs.alloc_gres = r_g.data(); rs.reservation = r_resv.data();
+  rs.alloc_core_w2 = I.r_w2.data(); rs.alloc_core_w3 = I.r_w3.data();
   int st = cns_set_running(I.h, rs.num_jobs ? &rs : nullptr);
   if (st != 0) return fail_all(st, cns_last_error(I.h));
 
@@ -774,6 +789,7 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   S.jobs = 0;
   S.start.assign(J + 1, 0); S.cpu.assign(places + 1, 0); S.reason.assign(J + 1, 0); S.off.assign(J + 1, 0);
   S.mem.assign(places + 1, 0); S.lo.assign(places + 1, 0); S.hi.assign(places + 1, 0); S.g.assign(places + 1, 0);
+  S.w2.assign(places + 1, 0); S.w3.assign(places + 1, 0);
   S.node.assign(places + 1, 0); S.nt.assign(places + 1, 0);
   S.excl.resize(J); S.msw_node.resize(J); S.msw_task.resize(J);
   for (size_t j = 0; j < J; ++j) {
@@ -785,7 +801,7 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   out.place_capacity = places;
   out.start_sec = S.start.data(); out.reason = S.reason.data(); out.place_offsets = S.off.data();
   out.node_idx = S.node.data(); out.ntasks = S.nt.data(); out.cpu_raw = S.cpu.data(); out.mem = S.mem.data();
-  out.core_lo = S.lo.data(); out.core_hi = S.hi.data(); out.gres = S.g.data();
+  out.core_lo = S.lo.data(); out.core_hi = S.hi.data(); out.gres = S.g.data(); out.core_w2 = S.w2.data(); out.core_w3 = S.w3.data();
   I.last_index.clear();
   I.last_ord.clear();
   I.cancelled.clear();
@@ -857,7 +873,7 @@ size_t GpuNodeSelectionAlgo::EmitStartedResourcesWire(WireBatch* out) const {
     for (uint64_t q = S.off[j]; q < S.off[j + 1]; ++q) {
       if (S.node[q] == CNS_NODE_NONE) continue;
       const size_t at = out->bytes.size();
-      I.append_res_wire(out->bytes, S.cpu[q], S.mem[q], I.mem_sw_of(j, q), S.lo[q], S.hi[q], S.g[q], t1, t2, t3, t4);
+      I.append_res_wire(out->bytes, S.cpu[q], S.mem[q], I.mem_sw_of(j, q), S.lo[q], S.hi[q], S.g[q], t1, t2, t3, t4, S.w2[q], S.w3[q]);
       out->recs.push_back({(uint32_t)j, S.node[q], (uint32_t)at, (uint32_t)(out->bytes.size() - at)});
     }
   }
@@ -881,7 +897,7 @@ bool GpuNodeSelectionAlgo::AppendResourceInNodeV3Wire(const PdJobInScheduler& jo
   std::string t1, t2, t3, t4;
   for (uint64_t q = S.off[j]; q < S.off[j + 1]; ++q)
     if (S.node[q] == ni->second) {
-      I.append_res_wire(*out, S.cpu[q], S.mem[q], I.mem_sw_of(j, q), S.lo[q], S.hi[q], S.g[q], t1, t2, t3, t4);
+      I.append_res_wire(*out, S.cpu[q], S.mem[q], I.mem_sw_of(j, q), S.lo[q], S.hi[q], S.g[q], t1, t2, t3, t4, S.w2[q], S.w3[q]);
       return true;
     }
   return false;
@@ -914,12 +930,12 @@ bool GpuNodeSelectionAlgo::AppendJobToDWire(const PdJobInScheduler& job, uint32_
 }
 
 void GpuNodeSelectionAlgo::WireOfPackedForTest(int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t core_lo, uint64_t core_hi,
-                                               uint64_t gres, std::string* wire, ResourceInNodeV3* obj) const {
+                                               uint64_t gres, std::string* wire, ResourceInNodeV3* obj, uint64_t core_w2, uint64_t core_w3) const {
   const Impl& I = *impl_;
   std::string t1, t2, t3, t4;
-  I.append_res_wire(*wire, cpu_raw, mem, mem_sw, core_lo, core_hi, gres, t1, t2, t3, t4);
+  I.append_res_wire(*wire, cpu_raw, mem, mem_sw, core_lo, core_hi, gres, t1, t2, t3, t4, core_w2, core_w3);
   *obj = ResourceInNodeV3{};
-  I.fill_res(*obj, cpu_raw, mem, core_lo, core_hi, gres);
+  I.fill_res(*obj, cpu_raw, mem, core_lo, core_hi, gres, core_w2, core_w3);
   obj->memory_sw_bytes = mem_sw;
 }
 
@@ -1202,7 +1218,7 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
   if (!I.have_snapshot) { status_ = CNS_ERR_STATE; error_ = "SchedulePendingSteps before SetClusterSnapshot"; return; }
   std::vector<uint32_t> noff{0}, nidx, soff{0};
   std::vector<int64_t> acpu;
-  std::vector<uint64_t> amem, alo, ahi, ag;
+  std::vector<uint64_t> amem, alo, ahi, ag, aw2, aw3;
   std::vector<StepInScheduler*> flat;
   for (const JobStepQueue& jq : jobs) {
     std::vector<std::pair<uint32_t, const ResourceInNodeV3*>> nodes;   // canonical walk order: ascending dense index
@@ -1216,9 +1232,9 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
       nidx.push_back(n);
       acpu.push_back(res->cpu_set.cpu_count.raw);
       amem.push_back(res->memory_bytes);
-      uint64_t lo, hi;
-      I.core_masks(res->cpu_set.core_ids, lo, hi);
-      alo.push_back(lo); ahi.push_back(hi);
+      uint64_t lo, hi, x2, x3;
+      I.core_masks(res->cpu_set.core_ids, lo, hi, x2, x3);
+      alo.push_back(lo); ahi.push_back(hi); aw2.push_back(x2); aw3.push_back(x3);
       ag.push_back(I.gres_mask(res->gres));
     }
     noff.push_back((uint32_t)nidx.size());
@@ -1259,13 +1275,14 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
   const size_t Nn = nidx.size();
   std::vector<uint8_t> sch(S + 1);
   std::vector<uint64_t> poff(S + 1), toff(S + 1), o_mem(places + 1), o_lo(places + 1), o_hi(places + 1), o_g(places + 1),
-      t_mem(tasks + 1), t_lo(tasks + 1), t_hi(tasks + 1), t_g(tasks + 1), r_mem(Nn + 1), r_lo(Nn + 1), r_hi(Nn + 1), r_g(Nn + 1);
+      t_mem(tasks + 1), t_lo(tasks + 1), t_hi(tasks + 1), t_g(tasks + 1), r_mem(Nn + 1), r_lo(Nn + 1), r_hi(Nn + 1), r_g(Nn + 1),
+      o_w2(places + 1), o_w3(places + 1), t_w2(tasks + 1), t_w3(tasks + 1), r_w2(Nn + 1), r_w3(Nn + 1);
   std::vector<uint32_t> o_node(places + 1), o_nt(places + 1), t_node(tasks + 1);
   std::vector<int64_t> o_cpu(places + 1), t_cpu(tasks + 1), r_cpu(Nn + 1);
   cns_step_job_soa cj{};
   cj.num_jobs = (uint32_t)jobs.size(); cj.num_nodes = (uint32_t)Nn; cj.node_offsets = noff.data(); cj.node_idx = nidx.data();
   cj.avail_cpu_raw = acpu.data(); cj.avail_mem = amem.data(); cj.avail_core_lo = alo.data(); cj.avail_core_hi = ahi.data();
-  cj.avail_gres = ag.data(); cj.step_offsets = soff.data();
+  cj.avail_gres = ag.data(); cj.step_offsets = soff.data(); cj.avail_core_w2 = aw2.data(); cj.avail_core_w3 = aw3.data();
   cns_step_soa cs{};
   cs.num_steps = (uint32_t)S; cs.node_cpu_raw = ncpu.data(); cs.node_mem = nmem.data(); cs.node_gres_total = ngt.data(); cs.node_gres_spec = ngs.data();
   cs.task_cpu_raw = tcpu.data(); cs.task_mem = tmem.data(); cs.task_gres_total = tgt.data(); cs.task_gres_spec = tgs.data();
@@ -1279,6 +1296,8 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
   co.task_offsets = toff.data(); co.task_node = t_node.data(); co.task_cpu_raw = t_cpu.data(); co.task_mem = t_mem.data();
   co.task_core_lo = t_lo.data(); co.task_core_hi = t_hi.data(); co.task_gres = t_g.data();
   co.avail_cpu_raw = r_cpu.data(); co.avail_mem = r_mem.data(); co.avail_core_lo = r_lo.data(); co.avail_core_hi = r_hi.data(); co.avail_gres = r_g.data();
+  co.node_core_w2 = o_w2.data(); co.node_core_w3 = o_w3.data(); co.task_core_w2 = t_w2.data(); co.task_core_w3 = t_w3.data();
+  co.avail_core_w2 = r_w2.data(); co.avail_core_w3 = r_w3.data();
   const int st = cns_schedule_steps(I.h, &cj, &cs, &co, nullptr);
   if (st != 0) { status_ = st; error_ = cns_last_error(I.h); return; }
   status_ = 0;
@@ -1292,13 +1311,13 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
     for (uint64_t p = poff[s]; p < poff[s + 1]; ++p) {
       const CranedId& cid = I.node_name[o_node[p]];
       x.craned_ids.push_back(cid);
-      x.allocated_res[cid] = I.to_res(o_cpu[p], o_mem[p], o_lo[p], o_hi[p], o_g[p]);
+      x.allocated_res[cid] = I.to_res(o_cpu[p], o_mem[p], o_lo[p], o_hi[p], o_g[p], o_w2[p], o_w3[p]);
     }
     for (uint64_t t = toff[s]; t < toff[s + 1]; ++t) {
       if (t_node[t] == CNS_NODE_NONE) continue;   // ntasks > what was handed out cannot happen for a scheduled step
       const uint32_t tid = (uint32_t)(t - toff[s]);
       x.craned_task_map[I.node_name[t_node[t]]].insert(tid);
-      x.task_res_map[tid] = I.to_res(t_cpu[t], t_mem[t], t_lo[t], t_hi[t], t_g[t]);
+      x.task_res_map[tid] = I.to_res(t_cpu[t], t_mem[t], t_lo[t], t_hi[t], t_g[t], t_w2[t], t_w3[t]);
     }
   }
   for (size_t j = 0; j < jobs.size(); ++j) {
@@ -1306,7 +1325,7 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
     for (uint32_t n = noff[j]; n < noff[j + 1]; ++n) {
       ResourceInNodeV3& dst = (*jobs[j].step_res_avail)[I.node_name[nidx[n]]];
       const uint64_t sw = dst.memory_sw_bytes;
-      dst = I.to_res(r_cpu[n], r_mem[n], r_lo[n], r_hi[n], r_g[n]);
+      dst = I.to_res(r_cpu[n], r_mem[n], r_lo[n], r_hi[n], r_g[n], r_w2[n], r_w3[n]);
       dst.memory_sw_bytes = sw;   // not touched by this path in the canonical model
     }
   }

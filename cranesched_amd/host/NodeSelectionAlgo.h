@@ -387,7 +387,7 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
                                 const ArrayTaskIdentity* array_task = nullptr);
   // test / bench hook (no device): the wire bytes and the ResourceInNodeV3 object of one packed allocation
   void WireOfPackedForTest(int64_t cpu_raw, uint64_t mem, uint64_t mem_sw, uint64_t core_lo, uint64_t core_hi, uint64_t gres,
-                           std::string* wire, ResourceInNodeV3* obj) const;
+                           std::string* wire, ResourceInNodeV3* obj, uint64_t core_w2 = 0, uint64_t core_w3 = 0) const;
   // ... and the emission of PendingCycleForBench's synthetic placements (ms per call)
   double EmitWireForBench(size_t* records, size_t* bytes);
 

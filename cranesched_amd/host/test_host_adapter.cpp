@@ -229,10 +229,14 @@ static int wire_dump(const char* path, int n, bool jobtod) {
     if (mode == 2) g = 0;
     if (mode == 3) { g &= 0xFF; }                                            // one type only
     if (mode == 4) { lo = hi = 0; cpu = 0; mem = 0; msw = 0; g = 0; }       // all defaults
-    if (mode == 5) { hi = ~0ull; lo = ~0ull; cpu = 128 * 256; }
+    uint64_t w2 = 0, w3 = 0;   // core ids 128..255 (two-byte varints on the wire)
+    if (mode == 5) {
+      hi = ~0ull; lo = ~0ull; w2 = rnd() | rnd(); w3 = (i % 12 == 5) ? ~0ull : rnd() & rnd();
+      cpu = 256 * (int64_t)(128 + __builtin_popcountll(w2) + __builtin_popcountll(w3));
+    }
     std::string wire;
     ResourceInNodeV3 obj;
-    algo.WireOfPackedForTest(cpu, mem, msw, lo, hi, g, &wire, &obj);
+    algo.WireOfPackedForTest(cpu, mem, msw, lo, hi, g, &wire, &obj, w2, w3);
     fprintf(f, "REC %zu\nHEX ", wire.size());
     for (unsigned char c : wire) fprintf(f, "%02x", c);
     fprintf(f, "\nCPU %.17g\nMEM %llu %llu\nIDS", (double)obj.cpu_set.cpu_count.raw / 256.0, (unsigned long long)obj.memory_bytes,
@@ -285,7 +289,10 @@ int main(int argc, char** argv) {
     CHECK(algo.LastStatus() != -4 /* CNS_ERR_UNSUPPORTED */ && algo.LastError().find("preemption") == std::string::npos);
     snap.preempt_enabled = false;
     snap.partitions.pop_back();
-    snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: id >= 128
+    snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: ids 128..255 are carried (ABI 3)
+    algo.SetClusterSnapshot(snap);
+    CHECK(algo.LastStatus() != -4 && algo.LastError().find("core id") == std::string::npos);
+    snap.craned_metas[1].res_total.cpu_set.core_ids.insert(300);   // beyond the four mask words: refused, not dropped
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);
     printf("%s\n", g_fail ? "FAIL" : "ok");

@@ -65,12 +65,14 @@ def _align16(x: int) -> int:
     return (x + 15) & ~15
 
 
-def results_layout(num_jobs: int, places: int) -> dict:
-    """Byte offsets of the packed result buffer (mirror of cns_upload_jobs in csrc/engine.hip)."""
+def results_layout(num_jobs: int, places: int, wide_cores: bool = False) -> dict:
+    """Byte offsets of the packed result buffer (mirror of cns_upload_jobs in csrc/engine.hip).  `wide_cores`: the snapshot has
+    a node with a core id above 127 (abi.Cluster.wide_cores) — only then the buffer ends with the core_w2 / core_w3 planes."""
     off, lay = 0, {}
     for name, elem, n in (("start_sec", 8, num_jobs), ("cpu_raw", 8, places), ("mem", 8, places),
                           ("core_lo", 8, places), ("core_hi", 8, places), ("gres", 8, places),
-                          ("node_idx", 4, places), ("ntasks", 4, places), ("reason", 1, num_jobs)):
+                          ("node_idx", 4, places), ("ntasks", 4, places), ("reason", 1, num_jobs)) + \
+                         ((("core_w2", 8, places), ("core_w3", 8, places)) if wide_cores else ()):
         lay[name] = (off, elem, n)
         off = _align16(off + elem * max(n, 1))
     lay["total"] = off
@@ -78,15 +80,17 @@ def results_layout(num_jobs: int, places: int) -> dict:
 
 
 _DT = {"start_sec": np.int64, "cpu_raw": np.int64, "mem": np.uint64, "core_lo": np.uint64, "core_hi": np.uint64,
-       "gres": np.uint64, "node_idx": np.uint32, "ntasks": np.uint32, "reason": np.uint8}
+       "gres": np.uint64, "node_idx": np.uint32, "ntasks": np.uint32, "reason": np.uint8, "core_w2": np.uint64, "core_w3": np.uint64}
 
 
-def unpack_results(buf: np.ndarray, jobs: abi.Jobs) -> abi.Placements:
+def unpack_results(buf: np.ndarray, jobs: abi.Jobs, wide_cores: bool = False) -> abi.Placements:
     """Packed result bytes of one shard -> Placements (host side of the merge)."""
     J, places = jobs.num_jobs, jobs.total_places()
-    lay = results_layout(J, places)
+    lay = results_layout(J, places, wide_cores)
     out = abi.Placements(J, places)
     for name, dt in _DT.items():
+        if name not in lay:
+            continue
         off, elem, n = lay[name]
         getattr(out, name)[:n] = np.frombuffer(buf, dtype=dt, count=n, offset=off)
     out.place_offsets[:] = np.concatenate([[0], np.cumsum(jobs.node_num.astype(np.uint64))])
@@ -110,7 +114,7 @@ def merge(jobs: abi.Jobs, shards: list[tuple[abi.Placements, np.ndarray]]) -> ab
         # destination record index of every shard record
         starts = goff[idx].astype(np.int64)
         rep = np.repeat(starts - np.concatenate([[0], np.cumsum(k)[:-1]]), k) + np.arange(int(k.sum()))
-        for f in ("node_idx", "ntasks", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+        for f in ("node_idx", "ntasks", "cpu_raw", "mem", "core_lo", "core_hi", "gres", "core_w2", "core_w3"):
             getattr(out, f)[rep] = getattr(pl, f)[:len(rep)]
     return out
 

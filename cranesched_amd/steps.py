@@ -20,7 +20,7 @@ _P = C.c_void_p
 class CnsStepJobSoa(C.Structure):
     _fields_ = [("num_jobs", C.c_uint32), ("num_nodes", C.c_uint32), ("node_offsets", _P), ("node_idx", _P),
                 ("avail_cpu_raw", _P), ("avail_mem", _P), ("avail_core_lo", _P), ("avail_core_hi", _P),
-                ("avail_gres", _P), ("step_offsets", _P)]
+                ("avail_gres", _P), ("step_offsets", _P), ("avail_core_w2", _P), ("avail_core_w3", _P)]
 
 
 class CnsStepSoa(C.Structure):
@@ -36,7 +36,8 @@ class CnsStepResultSoa(C.Structure):
                 ("node_mem", _P), ("node_core_lo", _P), ("node_core_hi", _P), ("node_gres", _P), ("task_offsets", _P),
                 ("task_node", _P), ("task_cpu_raw", _P), ("task_mem", _P), ("task_core_lo", _P), ("task_core_hi", _P),
                 ("task_gres", _P), ("avail_cpu_raw", _P), ("avail_mem", _P), ("avail_core_lo", _P),
-                ("avail_core_hi", _P), ("avail_gres", _P)]
+                ("avail_core_hi", _P), ("avail_gres", _P), ("node_core_w2", _P), ("node_core_w3", _P), ("task_core_w2", _P),
+                ("task_core_w3", _P), ("avail_core_w2", _P), ("avail_core_w3", _P)]
 
 
 def _a(x, dt):
@@ -49,18 +50,20 @@ def _p(a):
 
 class StepJobs:
     def __init__(self, node_offsets, node_idx, avail_cpu_raw, avail_mem, avail_core_lo, avail_core_hi, avail_gres,
-                 step_offsets):
+                 step_offsets, avail_core_w2=None, avail_core_w3=None):
         self.node_offsets, self.node_idx = _a(node_offsets, np.uint32), _a(node_idx, np.uint32)
         self.avail_cpu_raw, self.avail_mem = _a(avail_cpu_raw, np.int64), _a(avail_mem, np.uint64)
         self.avail_core_lo, self.avail_core_hi = _a(avail_core_lo, np.uint64), _a(avail_core_hi, np.uint64)
         self.avail_gres, self.step_offsets = _a(avail_gres, np.uint64), _a(step_offsets, np.uint32)
+        self.avail_core_w2 = None if avail_core_w2 is None else _a(avail_core_w2, np.uint64)   # core ids 128..255 (ABI 3)
+        self.avail_core_w3 = None if avail_core_w3 is None else _a(avail_core_w3, np.uint64)
         self.num_jobs, self.num_nodes = len(self.node_offsets) - 1, len(self.node_idx)
         assert self.node_offsets[-1] == self.num_nodes and len(self.step_offsets) == self.num_jobs + 1
 
     def to_c(self) -> CnsStepJobSoa:
         return CnsStepJobSoa(self.num_jobs, self.num_nodes, _p(self.node_offsets), _p(self.node_idx),
                              _p(self.avail_cpu_raw), _p(self.avail_mem), _p(self.avail_core_lo), _p(self.avail_core_hi),
-                             _p(self.avail_gres), _p(self.step_offsets))
+                             _p(self.avail_gres), _p(self.step_offsets), _p(self.avail_core_w2), _p(self.avail_core_w3))
 
 
 class Steps:
@@ -88,7 +91,8 @@ class Steps:
 class StepResults:
     FIELDS = ("scheduled", "place_offsets", "node_idx", "node_ntasks", "node_cpu_raw", "node_mem", "node_core_lo",
               "node_core_hi", "node_gres", "task_offsets", "task_node", "task_cpu_raw", "task_mem", "task_core_lo",
-              "task_core_hi", "task_gres", "avail_cpu_raw", "avail_mem", "avail_core_lo", "avail_core_hi", "avail_gres")
+              "task_core_hi", "task_gres", "avail_cpu_raw", "avail_mem", "avail_core_lo", "avail_core_hi", "avail_gres",
+              "node_core_w2", "node_core_w3", "task_core_w2", "task_core_w3", "avail_core_w2", "avail_core_w3")
 
     def __init__(self, jobs: StepJobs, steps: Steps):
         S, places, tasks, n = steps.num_steps, int(steps.node_num.sum()), int(steps.ntasks.sum()), jobs.num_nodes
@@ -103,6 +107,9 @@ class StepResults:
         self.task_core_lo, self.task_core_hi, self.task_gres = z(tasks, np.uint64), z(tasks, np.uint64), z(tasks, np.uint64)
         self.avail_cpu_raw, self.avail_mem = z(n, np.int64), z(n, np.uint64)
         self.avail_core_lo, self.avail_core_hi, self.avail_gres = z(n, np.uint64), z(n, np.uint64), z(n, np.uint64)
+        self.node_core_w2, self.node_core_w3 = z(places, np.uint64), z(places, np.uint64)
+        self.task_core_w2, self.task_core_w3 = z(tasks, np.uint64), z(tasks, np.uint64)
+        self.avail_core_w2, self.avail_core_w3 = z(n, np.uint64), z(n, np.uint64)
 
     def to_c(self) -> CnsStepResultSoa:
         return CnsStepResultSoa(*[_p(getattr(self, f)) for f in self.FIELDS])

@@ -54,6 +54,8 @@ void emit(O& orc, std::vector<PdJob>& jobs, cns_placement_soa* out) {
       out->mem[q] = r.mem;
       out->core_lo[q] = r.clo;
       out->core_hi[q] = r.chi;
+      if (out->core_w2) out->core_w2[q] = r.c2;
+      if (out->core_w3) out->core_w3[q] = r.c3;
       out->gres[q] = r.gres;
     }
     for (; k < job.node_num; ++k) {
@@ -63,6 +65,8 @@ void emit(O& orc, std::vector<PdJob>& jobs, cns_placement_soa* out) {
       out->cpu_raw[q] = 0;
       out->mem[q] = 0;
       out->core_lo[q] = out->core_hi[q] = out->gres[q] = 0;
+      if (out->core_w2) out->core_w2[q] = 0;
+      if (out->core_w3) out->core_w3[q] = 0;
     }
     off += job.node_num;
   }
@@ -74,11 +78,11 @@ void emit(O& orc, std::vector<PdJob>& jobs, cns_placement_soa* out) {
 
 extern "C" {
 
-struct ora_res { int64_t cpu; uint64_t mem, clo, chi, gres; };
+struct ora_res { int64_t cpu; uint64_t mem, clo, chi, gres, c2, c3; };
 struct ora_req { int64_t cpu; uint64_t mem; uint8_t gtot[CNS_MAX_GRES_NAMES]; uint8_t gspec[CNS_MAX_GRES_CLASSES]; };
 
-static MaskRes to_m(const ora_res& r) { MaskRes m; m.cpu = r.cpu; m.mem = r.mem; m.clo = r.clo; m.chi = r.chi; m.gres = r.gres; return m; }
-static ora_res from_m(const MaskRes& m) { return ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres}; }
+static MaskRes to_m(const ora_res& r) { MaskRes m; m.cpu = r.cpu; m.mem = r.mem; m.clo = r.clo; m.chi = r.chi; m.gres = r.gres; m.c2 = r.c2; m.c3 = r.c3; return m; }
+static ora_res from_m(const MaskRes& m) { return ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres, m.c2, m.c3}; }
 static ReqView to_v(const ora_req& q) {
   ReqView v; v.cpu = q.cpu; v.mem = q.mem;
   memcpy(v.gtot, q.gtot, sizeof v.gtot); memcpy(v.gspec, q.gspec, sizeof v.gspec);
@@ -156,6 +160,8 @@ static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
     total[n].mem = nodes->mem_total[n];
     total[n].clo = nodes->core_lo ? nodes->core_lo[n] : 0;
     total[n].chi = nodes->core_hi ? nodes->core_hi[n] : 0;
+    total[n].c2 = nodes->core_w2 ? nodes->core_w2[n] : 0;
+    total[n].c3 = nodes->core_w3 ? nodes->core_w3[n] : 0;
     total[n].gres = nodes->gres_slots ? nodes->gres_slots[n] : 0;
     if (nodes->schedulable) sched[n] = nodes->schedulable[n];
   }
@@ -175,6 +181,8 @@ static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
         m.mem = running->alloc_mem[a];
         m.clo = running->alloc_core_lo ? running->alloc_core_lo[a] : 0;
         m.chi = running->alloc_core_hi ? running->alloc_core_hi[a] : 0;
+        m.c2 = running->alloc_core_w2 ? running->alloc_core_w2[a] : 0;
+        m.c3 = running->alloc_core_w3 ? running->alloc_core_w3[a] : 0;
         m.gres = running->alloc_gres ? running->alloc_gres[a] : 0;
         rn[r].allocs.push_back({running->alloc_node[a], m});
       }
@@ -193,6 +201,8 @@ static int ora_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
         m.mem = resv->alloc_mem[a];
         m.clo = resv->alloc_core_lo ? resv->alloc_core_lo[a] : 0;
         m.chi = resv->alloc_core_hi ? resv->alloc_core_hi[a] : 0;
+        m.c2 = resv->alloc_core_w2 ? resv->alloc_core_w2[a] : 0;
+        m.c3 = resv->alloc_core_w3 ? resv->alloc_core_w3[a] : 0;
         m.gres = resv->alloc_gres ? resv->alloc_gres[a] : 0;
         rv[v].allocs.push_back({resv->alloc_node[a], m});
       }
@@ -314,6 +324,23 @@ int ora_get_timeline(void* h, uint32_t node, uint32_t capacity, uint32_t* len, i
   return run->mask ? dump(*run->mask) : dump(*run->lit);
 }
 
+// ... and the core ids 128..255 of the same entries
+int ora_get_timeline_cores(void* h, uint32_t node, uint32_t capacity, uint64_t* core_w2, uint64_t* core_w3) {
+  auto* run = static_cast<OracleRun*>(h);
+  auto dump = [&](auto& orc) {
+    if (!orc.HasNode(node)) return 0;
+    uint32_t i = 0;
+    for (const auto& [time, res] : orc.Timeline(node)) {
+      if (i >= capacity) break;
+      MaskRes m = orc.alg().to_mask(res);
+      core_w2[i] = m.c2; core_w3[i] = m.c3;
+      ++i;
+    }
+    return 0;
+  };
+  return run->mask ? dump(*run->mask) : dump(*run->lit);
+}
+
 void ora_free(void* h) { delete static_cast<OracleRun*>(h); }
 
 
@@ -390,8 +417,12 @@ static int run_steps(const Alg& alg, const cns_step_job_soa* jb, const cns_step_
     po += st->node_num[s]; to += st->ntasks[s];
   }
   out->place_offsets[st->num_steps] = po; out->task_offsets[st->num_steps] = to;
-  for (u64 i = 0; i < po; ++i) { out->node_idx[i] = CNS_NODE_NONE; out->node_ntasks[i] = 0; out->node_cpu_raw[i] = 0; out->node_mem[i] = 0; out->node_core_lo[i] = 0; out->node_core_hi[i] = 0; out->node_gres[i] = 0; }
-  for (u64 i = 0; i < to; ++i) { out->task_node[i] = CNS_NODE_NONE; out->task_cpu_raw[i] = 0; out->task_mem[i] = 0; out->task_core_lo[i] = 0; out->task_core_hi[i] = 0; out->task_gres[i] = 0; }
+  for (u64 i = 0; i < po; ++i) { out->node_idx[i] = CNS_NODE_NONE; out->node_ntasks[i] = 0; out->node_cpu_raw[i] = 0; out->node_mem[i] = 0; out->node_core_lo[i] = 0; out->node_core_hi[i] = 0; out->node_gres[i] = 0;
+    if (out->node_core_w2) out->node_core_w2[i] = 0;
+    if (out->node_core_w3) out->node_core_w3[i] = 0; }
+  for (u64 i = 0; i < to; ++i) { out->task_node[i] = CNS_NODE_NONE; out->task_cpu_raw[i] = 0; out->task_mem[i] = 0; out->task_core_lo[i] = 0; out->task_core_hi[i] = 0; out->task_gres[i] = 0;
+    if (out->task_core_w2) out->task_core_w2[i] = 0;
+    if (out->task_core_w3) out->task_core_w3[i] = 0; }
   for (u32 j = 0; j < jb->num_jobs; ++j) {
     std::vector<u32> nodes;
     std::vector<typename Alg::Res> avail;
@@ -400,6 +431,7 @@ static int run_steps(const Alg& alg, const cns_step_job_soa* jb, const cns_step_
       MaskRes m;
       m.cpu = jb->avail_cpu_raw[n]; m.mem = jb->avail_mem[n]; m.clo = jb->avail_core_lo[n];
       m.chi = jb->avail_core_hi ? jb->avail_core_hi[n] : 0; m.gres = jb->avail_gres ? jb->avail_gres[n] : 0;
+      m.c2 = jb->avail_core_w2 ? jb->avail_core_w2[n] : 0; m.c3 = jb->avail_core_w3 ? jb->avail_core_w3[n] : 0;
       avail.push_back(alg.from_mask(m));
     }
     std::vector<ora::StepReq> steps;
@@ -429,16 +461,22 @@ static int run_steps(const Alg& alg, const cns_step_job_soa* jb, const cns_step_
         const MaskRes& m = res[k].node_alloc[i];
         out->node_idx[p] = res[k].node[i]; out->node_ntasks[p] = res[k].node_ntasks[i];
         out->node_cpu_raw[p] = m.cpu; out->node_mem[p] = m.mem; out->node_core_lo[p] = m.clo; out->node_core_hi[p] = m.chi; out->node_gres[p] = m.gres;
+        if (out->node_core_w2) out->node_core_w2[p] = m.c2;
+        if (out->node_core_w3) out->node_core_w3[p] = m.c3;
       }
       for (size_t i = 0; i < res[k].task_node.size(); ++i, ++t) {
         const MaskRes& m = res[k].task_alloc[i];
         out->task_node[t] = res[k].task_node[i];
         out->task_cpu_raw[t] = m.cpu; out->task_mem[t] = m.mem; out->task_core_lo[t] = m.clo; out->task_core_hi[t] = m.chi; out->task_gres[t] = m.gres;
+        if (out->task_core_w2) out->task_core_w2[t] = m.c2;
+        if (out->task_core_w3) out->task_core_w3[t] = m.c3;
       }
     }
     for (u32 n = jb->node_offsets[j], i = 0; n < jb->node_offsets[j + 1]; ++n, ++i) {
       const MaskRes m = alg.to_mask(avail[i]);
       out->avail_cpu_raw[n] = m.cpu; out->avail_mem[n] = m.mem; out->avail_core_lo[n] = m.clo; out->avail_core_hi[n] = m.chi; out->avail_gres[n] = m.gres;
+      if (out->avail_core_w2) out->avail_core_w2[n] = m.c2;
+      if (out->avail_core_w3) out->avail_core_w3[n] = m.c3;
     }
   }
   return 0;

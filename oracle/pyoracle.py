@@ -22,10 +22,10 @@ MASK, LITERAL = 0, 1
 
 class OraRes(C.Structure):
     _fields_ = [("cpu", C.c_int64), ("mem", C.c_uint64), ("clo", C.c_uint64), ("chi", C.c_uint64),
-                ("gres", C.c_uint64)]
+                ("gres", C.c_uint64), ("c2", C.c_uint64), ("c3", C.c_uint64)]   # c2 / c3: core ids 128..255
 
     def tup(self):
-        return (self.cpu, self.mem, self.clo, self.chi, self.gres)
+        return (self.cpu, self.mem, self.clo, self.chi, self.gres, self.c2, self.c3)
 
 
 class OraReq(C.Structure):
@@ -119,8 +119,8 @@ def make_req(cpu=0, mem=0, gtot=(), gspec=()) -> OraReq:
     return q
 
 
-def make_res(cpu=0, mem=0, clo=0, chi=0, gres=0) -> OraRes:
-    return OraRes(cpu, mem, clo, chi, gres)
+def make_res(cpu=0, mem=0, clo=0, chi=0, gres=0, c2=0, c3=0) -> OraRes:
+    return OraRes(cpu, mem, clo, chi, gres, c2, c3)
 
 
 def feasible(layout: abi.GresLayout, algebra: int, req: OraReq, avail: OraRes, backend: str = "oracle"):
@@ -166,7 +166,10 @@ class OracleRun:
         lib(self._backend).ora_get_timeline(self._h, C.c_uint32(node), C.c_uint32(cap), C.byref(n), p(t), p(cpu), p(mem),
                                p(lo), p(hi), p(g))
         k = n.value
-        return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k]}
+        w2 = np.zeros(cap, np.uint64); w3 = np.zeros(cap, np.uint64)
+        lib(self._backend).ora_get_timeline_cores(self._h, C.c_uint32(node), C.c_uint32(cap), p(w2), p(w3))
+        return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k],
+                "core_w2": w2[:k], "core_w3": w3[:k]}
 
     def close(self):
         if self._h:

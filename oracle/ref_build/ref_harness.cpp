@@ -68,7 +68,7 @@ using Ctld::SchedulerAlgo;
 using NodeState = SchedulerAlgo::NodeState;
 using LocalScheduler = SchedulerAlgo::LocalScheduler;
 
-struct MaskRes { int64_t cpu = 0; uint64_t mem = 0, clo = 0, chi = 0, gres = 0; };
+struct MaskRes { int64_t cpu = 0; uint64_t mem = 0, clo = 0, chi = 0, gres = 0, c2 = 0, c3 = 0; };
 
 struct Layout {
   cns_gres_layout g{};
@@ -94,6 +94,8 @@ ResourceInNodeV3 to_ref(const Layout& L, const MaskRes& m) {
   for (int b = 0; b < 64; ++b) {
     if ((m.clo >> b) & 1) r.GetCpuSet().core_ids.insert((uint32_t)b);
     if ((m.chi >> b) & 1) r.GetCpuSet().core_ids.insert((uint32_t)(64 + b));
+    if ((m.c2 >> b) & 1) r.GetCpuSet().core_ids.insert((uint32_t)(128 + b));
+    if ((m.c3 >> b) & 1) r.GetCpuSet().core_ids.insert((uint32_t)(192 + b));
   }
   r.SetMemoryBytes(m.mem);
   for (int b = 0; b < 64; ++b)
@@ -111,7 +113,9 @@ MaskRes from_ref(const ResourceInNodeV3& r) {
   for (uint32_t c : r.GetCpuSet().core_ids) {
     if (c < 64) m.clo |= 1ull << c;
     else if (c < 128) m.chi |= 1ull << (c - 64);
-    else throw std::invalid_argument("core id >= 128");
+    else if (c < 192) m.c2 |= 1ull << (c - 128);
+    else if (c < 256) m.c3 |= 1ull << (c - 192);
+    else throw std::invalid_argument("core id >= 256");
   }
   for (const auto& [name, tsm] : r.GetGres().name_type_slots_map)
     for (const auto& [type, slots] : tsm.type_slots_map)
@@ -189,7 +193,7 @@ int reason_code(const std::string& r, bool failed) {
 
 extern "C" {
 
-struct ora_res { int64_t cpu; uint64_t mem, clo, chi, gres; };
+struct ora_res { int64_t cpu; uint64_t mem, clo, chi, gres, c2, c3; };
 struct ora_req { int64_t cpu; uint64_t mem; uint8_t gtot[CNS_MAX_GRES_NAMES]; uint8_t gspec[CNS_MAX_GRES_CLASSES]; };
 
 const char* ref_last_error(void) { return g_last_error.c_str(); }
@@ -207,18 +211,18 @@ int ora_feasible(const cns_gres_layout* gl, int, const ora_req* req, const ora_r
   try {
     Layout L; L.g = *gl;
     const ResourceView v = view_of(L, req->cpu, req->mem, req->gtot, req->gspec);
-    const ResourceInNodeV3 a = to_ref(L, MaskRes{avail->cpu, avail->mem, avail->clo, avail->chi, avail->gres});
+    const ResourceInNodeV3 a = to_ref(L, MaskRes{avail->cpu, avail->mem, avail->clo, avail->chi, avail->gres, avail->c2, avail->c3});
     ResourceInNodeV3 f;
     const bool ok = v.GetFeasibleResourceInNode(a, &f);   // PublicHeader.cpp:519-599
-    if (ok) { const MaskRes m = from_ref(f); *out = ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres}; }
+    if (ok) { const MaskRes m = from_ref(f); *out = ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres, m.c2, m.c3}; }
     return ok;
   } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
 int ora_binop(const cns_gres_layout* gl, int, int op, const ora_res* a, const ora_res* b, ora_res* out) {
   try {
     Layout L; L.g = *gl;
-    ResourceInNodeV3 x = to_ref(L, MaskRes{a->cpu, a->mem, a->clo, a->chi, a->gres});
-    const ResourceInNodeV3 y = to_ref(L, MaskRes{b->cpu, b->mem, b->clo, b->chi, b->gres});
+    ResourceInNodeV3 x = to_ref(L, MaskRes{a->cpu, a->mem, a->clo, a->chi, a->gres, a->c2, a->c3});
+    const ResourceInNodeV3 y = to_ref(L, MaskRes{b->cpu, b->mem, b->clo, b->chi, b->gres, b->c2, b->c3});
     int ret = 0;
     switch (op) {
 #pragma GCC diagnostic push
@@ -229,7 +233,7 @@ int ora_binop(const cns_gres_layout* gl, int, int op, const ora_res* a, const or
       case 2: x -= y; break;              // :789-796
       case 3: ret = (x <= y); break;      // :886-890
     }
-    if (out) { const MaskRes m = from_ref(x); *out = ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres}; }
+    if (out) { const MaskRes m = from_ref(x); *out = ora_res{m.cpu, m.mem, m.clo, m.chi, m.gres, m.c2, m.c3}; }
     return ret;
   } catch (const std::exception& e) { g_last_error = e.what(); return -1; }
 }
@@ -267,6 +271,7 @@ static int ref_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
       MaskRes t;
       t.cpu = nodes->cpu_total_raw[n]; t.mem = nodes->mem_total[n];
       t.clo = nodes->core_lo ? nodes->core_lo[n] : 0; t.chi = nodes->core_hi ? nodes->core_hi[n] : 0;
+      t.c2 = nodes->core_w2 ? nodes->core_w2[n] : 0; t.c3 = nodes->core_w3 ? nodes->core_w3[n] : 0;
       t.gres = nodes->gres_slots ? nodes->gres_slots[n] : 0;
       cm.res_total = to_ref(L, t);
     }
@@ -278,9 +283,11 @@ static int ref_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
         run->part_nodes[p].push_back(nodes->part_nodes[i]);
       }
     }
-    auto alloc_of = [&](const int64_t* cpu, const uint64_t* mem, const uint64_t* lo, const uint64_t* hi, const uint64_t* g, uint32_t a) {
+    auto alloc_of = [&](const int64_t* cpu, const uint64_t* mem, const uint64_t* lo, const uint64_t* hi, const uint64_t* g, uint32_t a,
+                        const uint64_t* w2, const uint64_t* w3) {
       MaskRes m;
       m.cpu = cpu[a]; m.mem = mem[a]; m.clo = lo ? lo[a] : 0; m.chi = hi ? hi[a] : 0; m.gres = g ? g[a] : 0;
+      m.c2 = w2 ? w2[a] : 0; m.c3 = w3 ? w3[a] : 0;
       return to_ref(L, m);
     };
     if (resv)
@@ -291,7 +298,7 @@ static int ref_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
         for (uint32_t a = resv->alloc_offsets[v]; a < resv->alloc_offsets[v + 1]; ++a) {
           rm.craned_ids.push_back(node_name(resv->alloc_node[a]));
           rm.res_total.AddResourceInNode(node_name(resv->alloc_node[a]),
-                                         alloc_of(resv->alloc_cpu_raw, resv->alloc_mem, resv->alloc_core_lo, resv->alloc_core_hi, resv->alloc_gres, a));
+                                         alloc_of(resv->alloc_cpu_raw, resv->alloc_mem, resv->alloc_core_lo, resv->alloc_core_hi, resv->alloc_gres, a, resv->alloc_core_w2, resv->alloc_core_w3));
         }
       }
     // ---- running and pending jobs through the reference's own constructors (JobScheduler.h:75-90,143-170) ----
@@ -309,7 +316,7 @@ static int ref_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
       if (running->reservation && running->reservation[r] != CNS_RESV_NONE) j.reservation = resv_name(running->reservation[r]);
       for (uint32_t a = running->alloc_offsets[r]; a < running->alloc_offsets[r + 1]; ++a)
         j.allocated_res.AddResourceInNode(node_name(running->alloc_node[a]),
-                                          alloc_of(running->alloc_cpu_raw, running->alloc_mem, running->alloc_core_lo, running->alloc_core_hi, running->alloc_gres, a));
+                                          alloc_of(running->alloc_cpu_raw, running->alloc_mem, running->alloc_core_lo, running->alloc_core_hi, running->alloc_gres, a, running->alloc_core_w2, running->alloc_core_w3));
       rn_arena.make(&j);
     }
     for (uint64_t i = 0; i < J; ++i) {
@@ -409,12 +416,16 @@ static int ref_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
             out->node_idx[q] = nid;
             out->ntasks[q] = job.craned_id_to_task_num.at(node_name(nid));
             out->cpu_raw[q] = m.cpu; out->mem[q] = m.mem; out->core_lo[q] = m.clo; out->core_hi[q] = m.chi; out->gres[q] = m.gres;
+            if (out->core_w2) out->core_w2[q] = m.c2;
+            if (out->core_w3) out->core_w3[q] = m.c3;
           }
         }
         for (; k < job.node_num; ++k) {
           const uint64_t q = off + k;
           out->node_idx[q] = CNS_NODE_NONE; out->ntasks[q] = 0; out->cpu_raw[q] = 0; out->mem[q] = 0;
           out->core_lo[q] = out->core_hi[q] = out->gres[q] = 0;
+          if (out->core_w2) out->core_w2[q] = 0;
+          if (out->core_w3) out->core_w3[q] = 0;
         }
         off += job.node_num;
       }
@@ -483,6 +494,18 @@ int ora_get_timeline(void* h, uint32_t node, uint32_t capacity, uint32_t* len, i
   for (const auto& [time, m] : it->second) {
     if (i >= capacity) break;
     t[i] = time; cpu_raw[i] = m.cpu; mem[i] = m.mem; core_lo[i] = m.clo; core_hi[i] = m.chi; gres[i] = m.gres;
+    ++i;
+  }
+  return 0;
+}
+int ora_get_timeline_cores(void* h, uint32_t node, uint32_t capacity, uint64_t* core_w2, uint64_t* core_w3) {
+  auto* run = static_cast<RefRun*>(h);
+  auto it = run->timeline.find(node);
+  if (it == run->timeline.end()) return 0;
+  uint32_t i = 0;
+  for (const auto& [time, m] : it->second) {
+    if (i >= capacity) break;
+    core_w2[i] = m.c2; core_w3[i] = m.c3;
     ++i;
   }
   return 0;

@@ -84,11 +84,15 @@ struct GresLayout {
 struct MaskRes {
   i64 cpu = 0;
   u64 mem = 0;
-  u64 clo = 0, chi = 0;
+  u64 clo = 0, chi = 0;     // core ids 0..63, 64..127
   u64 gres = 0;
+  u64 c2 = 0, c3 = 0;       // core ids 128..191, 192..255 (ABI 3)
   bool operator==(const MaskRes& o) const {
-    return cpu == o.cpu && mem == o.mem && clo == o.clo && chi == o.chi && gres == o.gres;
+    return cpu == o.cpu && mem == o.mem && clo == o.clo && chi == o.chi && c2 == o.c2 && c3 == o.c3 && gres == o.gres;
   }
+  bool any_core() const { return (clo | chi | c2 | c3) != 0; }
+  u64 core_word(int w) const { return w == 0 ? clo : w == 1 ? chi : w == 2 ? c2 : c3; }
+  u64& core_word(int w) { return w == 0 ? clo : w == 1 ? chi : w == 2 ? c2 : c3; }
 };
 
 // ----------------------------------------------------------------------------------
@@ -110,7 +114,7 @@ struct MaskAlgebra {
   MaskRes to_mask(const Res& r) const { return r; }
   void set_zero(Res& r) const { r = Res{}; }
   // ResourceInNodeV3::IsZero, PublicHeader.cpp:798-801 (memory_sw is not modelled on this path)
-  bool is_zero(const Res& r) const { return r.cpu == 0 && (r.clo | r.chi) == 0 && r.mem == 0 && r.gres == 0; }
+  bool is_zero(const Res& r) const { return r.cpu == 0 && !r.any_core() && r.mem == 0 && r.gres == 0; }
 
   // ResourceView::GetFeasibleResourceInNode, PublicHeader.cpp:519-599
   bool feasible(const ReqView& q, const Res& a, Res* out) const {
@@ -118,16 +122,14 @@ struct MaskAlgebra {
     if (q.mem > a.mem) return false;  // :523
     Res c;
     i64 req_int = q.cpu / 256;  // static_cast<int64_t>(cpu_t) :528
-    bool is_int = (req_int * 256 == q.cpu) && (a.clo | a.chi) != 0;  // :529-530
+    bool is_int = (req_int * 256 == q.cpu) && a.any_core();  // :529-530
     if (is_int) {
       u32 n = static_cast<u32>(req_int);
-      if (static_cast<u32>(popc(a.clo) + popc(a.chi)) < n) return false;  // :534
-      int nlo = popc(a.clo);
-      if ((int)n <= nlo) {
-        c.clo = lowest_n(a.clo, (int)n);
-      } else {
-        c.clo = a.clo;
-        c.chi = lowest_n(a.chi, (int)n - nlo);
+      if (static_cast<u32>(popc(a.clo) + popc(a.chi) + popc(a.c2) + popc(a.c3)) < n) return false;  // :534
+      int left = (int)n;   // the n lowest core ids (:536-541: the first n of an ordered set)
+      for (int w = 0; w < 4 && left > 0; ++w) {
+        c.core_word(w) = lowest_n(a.core_word(w), left);
+        left -= popc(c.core_word(w));
       }
     }
     c.cpu = q.cpu;
@@ -173,9 +175,11 @@ struct MaskAlgebra {
   // ResourceInNodeV3::Ckmin, PublicHeader.cpp:815-827
   void ckmin(Res& a, const Res& b) const {
     a.cpu = std::min(a.cpu, b.cpu);
-    if ((a.clo | a.chi) != 0 && (b.clo | b.chi) != 0) {
+    if (a.any_core() && b.any_core()) {
       a.clo &= b.clo;
       a.chi &= b.chi;
+      a.c2 &= b.c2;
+      a.c3 &= b.c3;
     }
     a.mem = std::min(a.mem, b.mem);
     a.gres &= b.gres;
@@ -190,6 +194,8 @@ struct MaskAlgebra {
   void add(Res& a, const Res& b) const {
     a.clo |= b.clo;
     a.chi |= b.chi;
+    a.c2 |= b.c2;
+    a.c3 |= b.c3;
     a.cpu += b.cpu;
     a.mem += b.mem;
     a.gres |= b.gres;
@@ -197,6 +203,8 @@ struct MaskAlgebra {
   void sub(Res& a, const Res& b) const {
     a.clo &= ~b.clo;  // tolerant erase :758-762
     a.chi &= ~b.chi;
+    a.c2 &= ~b.c2;
+    a.c3 &= ~b.c3;
     a.cpu -= b.cpu;
     a.mem -= b.mem;
     a.gres &= ~b.gres;
@@ -229,6 +237,8 @@ struct LitAlgebra {
     for (int b = 0; b < 64; ++b) {
       if ((m.clo >> b) & 1) r.cores.insert((u32)b);
       if ((m.chi >> b) & 1) r.cores.insert((u32)(64 + b));
+      if ((m.c2 >> b) & 1) r.cores.insert((u32)(128 + b));
+      if ((m.c3 >> b) & 1) r.cores.insert((u32)(192 + b));
       if ((m.gres >> b) & 1) {
         int g = L->class_of_bit(b);
         assert(g >= 0);
@@ -242,8 +252,7 @@ struct LitAlgebra {
     m.cpu = r.cpu;
     m.mem = r.mem;
     for (u32 c : r.cores) {
-      if (c < 64) m.clo |= 1ull << c;
-      else m.chi |= 1ull << (c - 64);
+      m.core_word((int)(c >> 6)) |= 1ull << (c & 63);
     }
     for (const auto& [name, tm] : r.gres)
       for (const auto& [type, slots] : tm)

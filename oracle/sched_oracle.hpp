@@ -923,7 +923,7 @@ class SchedOracle {
     std::map<u32, MaskRes> m;
     for (const auto& al : (*rn_)[ri].allocs) {
       MaskRes& d = m[al.node];
-      d.cpu += al.res.cpu; d.mem += al.res.mem; d.clo |= al.res.clo; d.chi |= al.res.chi; d.gres |= al.res.gres;
+      d.cpu += al.res.cpu; d.mem += al.res.mem; d.clo |= al.res.clo; d.chi |= al.res.chi; d.c2 |= al.res.c2; d.c3 |= al.res.c3; d.gres |= al.res.gres;
     }
     return m;
   }
@@ -936,7 +936,7 @@ class SchedOracle {
   static void add_alloc(PdJob* job, u32 nid, const MaskRes& r) {
     // ResourceV3::AddResourceInNode (PublicHeader.cpp:915-919): += into a fresh entry.
     MaskRes& d = job->allocated_res[nid];
-    d.cpu += r.cpu; d.mem += r.mem; d.clo |= r.clo; d.chi |= r.chi; d.gres |= r.gres;
+    d.cpu += r.cpu; d.mem += r.mem; d.clo |= r.clo; d.chi |= r.chi; d.c2 |= r.c2; d.c3 |= r.c3; d.gres |= r.gres;
   }
 
   A A_;

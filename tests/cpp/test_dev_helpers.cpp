@@ -46,6 +46,8 @@ int main() {
     a.mem = rng() % 64;
     a.clo = (rng() % 4 == 0) ? 0 : (rng() & rng() & 0xFFFF);
     a.chi = (rng() % 8 == 0) ? (rng() & 0xF) : 0;
+    a.c2 = (rng() % 8 == 0) ? (rng() & 0x3F) : 0;      // core ids 128..255 (ABI 3)
+    a.c3 = (rng() % 16 == 0) ? (rng() & 0x7) : 0;
     a.gres = rng() & rng() & 0xFFFF;
     Req q;
     q.cpu = (i64)(rng() % 12) * 128;
@@ -59,16 +61,16 @@ int main() {
     v.cpu = q.cpu; v.mem = q.mem;
     for (int i = 0; i < 4; ++i) v.gtot[i] = (q.gtot >> (8 * i)) & 0xFF;
     for (int i = 0; i < 8; ++i) v.gspec[i] = (q.gspec >> (8 * i)) & 0xFF;
-    ora::MaskRes am; am.cpu = a.cpu; am.mem = a.mem; am.clo = a.clo; am.chi = a.chi; am.gres = a.gres;
+    ora::MaskRes am; am.cpu = a.cpu; am.mem = a.mem; am.clo = a.clo; am.chi = a.chi; am.gres = a.gres; am.c2 = a.c2; am.c3 = a.c3;
     ora::MaskRes om;
     Res od;
     bool r1 = A.feasible(v, am, &om);
     bool r2 = feasible(q, a, od, D);
     u64 cnt = 0;
     for (int g = 0; g < 3; ++g) cnt |= (u64)__builtin_popcountll(a.gres & D.class_mask[g]) << (8 * g);
-    bool r3 = feasible_counts(q, a.cpu, a.mem, (u32)(__builtin_popcountll(a.clo) + __builtin_popcountll(a.chi)), cnt, D);
+    bool r3 = feasible_counts(q, a.cpu, a.mem, cores_count(a), cnt, D);
     if (r1 != r2 || r1 != r3) { printf("FAIL feasible truth it=%d %d %d %d\n", it, r1, r2, r3); return 1; }
-    if (r1 && !(om.cpu == od.cpu && om.mem == od.mem && om.clo == od.clo && om.chi == od.chi && om.gres == od.gres)) {
+    if (r1 && !(om.cpu == od.cpu && om.mem == od.mem && om.clo == od.clo && om.chi == od.chi && om.c2 == od.c2 && om.c3 == od.c3 && om.gres == od.gres)) {
       printf("FAIL feasible alloc it=%d\n", it);
       return 1;
     }

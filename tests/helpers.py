@@ -119,6 +119,26 @@ def random_case(seed: int, N: int = 96, J: int = 600, P: int = 2, running: int =
     return cluster, jobs, now, run
 
 
+def widen_cores(cluster: abi.Cluster, seed: int = 0) -> abi.Cluster:
+    """The same cluster with its 128-core nodes (and every fourth smaller one) grown to 192 or 256 cores — core ids 128..255
+    in the core_w2 / core_w3 planes of ABI 3 (CpuSet::core_ids has no bound, PublicHeader.h:555-573).  Running allocations of a
+    case stay valid: they hold low core ids."""
+    rng = np.random.default_rng(9000 + seed)
+    n = cluster.num_nodes
+    cores = (cluster.cpu_total_raw // 256).astype(np.int64)
+    grow = (cores == 128) | (rng.random(n) < 0.25)
+    target = np.where(rng.random(n) < 0.5, 192, 256)
+    new = np.where(grow, target, cores)
+    full = np.uint64(0xFFFFFFFFFFFFFFFF)
+    lo = np.where(grow, full, cluster.core_lo).astype(np.uint64)
+    hi = np.where(grow, full, cluster.core_hi).astype(np.uint64)
+    w2 = np.where(grow, full, np.uint64(0)).astype(np.uint64)
+    w3 = np.where(grow & (new == 256), full, np.uint64(0)).astype(np.uint64)
+    return abi.Cluster((new * 256).astype(np.int64), (new.astype(np.uint64) * np.uint64(4 * GIB)), lo, hi, cluster.gres_slots,
+                       cluster.part_offsets, cluster.part_nodes, gres=cluster.gres, schedulable=cluster.schedulable,
+                       core_w2=w2, core_w3=w3)
+
+
 def assert_same(eng, got: abi.Placements, ref, cluster: abi.Cluster, sample_nodes: int = 24, tag: str = ""):
     """Placements, fp64 cost bit patterns and a sample of final time maps must be identical."""
     d = got.diff(ref.placements)
@@ -141,5 +161,5 @@ def assert_same(eng, got: abi.Placements, ref, cluster: abi.Cluster, sample_node
             assert len(eng.timeline(int(n))["t"]) == 0
             continue
         a, b = eng.timeline(int(n)), ref.timeline(int(n))
-        for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+        for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres", "core_w2", "core_w3"):
             assert np.array_equal(a[f], b[f]), f"{tag}: time map of node {n} differs in {f}:\n{a[f]}\n{b[f]}"

@@ -18,13 +18,16 @@ def cluster(cores, mem_gib=None, gres=None, layout=None, parts=None):
     n = len(cores)
     cores = np.asarray(cores, np.int64)
     mem = np.asarray(mem_gib if mem_gib is not None else [16] * n, np.uint64) * np.uint64(GIB)
-    lo = np.array([(1 << min(c, 64)) - 1 if c < 64 else 0xFFFFFFFFFFFFFFFF for c in cores], np.uint64)
-    hi = np.array([(1 << (c - 64)) - 1 if c > 64 else 0 for c in cores], np.uint64)
+    W = 0xFFFFFFFFFFFFFFFF
+    word = lambda c, w: np.array([(((1 << int(x)) - 1) >> (64 * w)) & W for x in c], np.uint64)   # core ids 0..c-1, word w
+    lo, hi, w2, w3 = (word(cores, w) for w in range(4))
     g = np.asarray(gres if gres is not None else [0] * n, np.uint64)
     parts = parts or [list(range(n))]
     off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint32)
     pn = np.concatenate([np.asarray(p, np.uint32) for p in parts])
-    return abi.Cluster(cores * 256, mem, lo, hi, g, off, pn, gres=layout or abi.GresLayout())
+    wide = bool(w2.any() or w3.any())
+    return abi.Cluster(cores * 256, mem, lo, hi, g, off, pn, gres=layout or abi.GresLayout(),
+                       core_w2=w2 if wide else None, core_w3=w3 if wide else None)
 
 
 def jobs(specs):
@@ -149,6 +152,26 @@ def scenarios():
         "costs": [150.0, 50.0, 70.0, 100.0],   # per (partition, node): [p0/n0, p0/n1, p1/n1, p1/n2]
         "timeline": {0: [(NOW, 0, 0x0), (1100, 512, 0x3), (1200, 1024, 0xF), (INF, 0, 0)],
                      1: [(NOW, 0, 0x0), (1040, 512, 0xC), (1100, 0, 0x0), (1150, 1024, 0xF), (INF, 0, 0)]}}))
+    # K. a node with 192 cores (core ids above 127: the core_w2 / core_w3 planes; CpuSet::core_ids is an unbounded ordered set,
+    #    PublicHeader.h:555-573, GetFeasibleResourceInNode takes the n LOWEST free ids, PublicHeader.cpp:536-541).
+    #    Job 0 (100 cpus): both costs 0, tie -> node 0, ids 0..99.  Job 1 (60 cpus): node 1 is cheaper (0 < 100*100/192), ids 0..59
+    #    there.  Job 2 (70 cpus, 50 s): node 0 (52.08 < 93.75) has 92 free -> ids 100..169, across the 128 boundary.  Job 3 (30 cpus):
+    #    node 0 has 22 free, node 1 has 4 -> backfilled; node 0 is free enough at 1050 (job 2 ends), node 1 only at 1100 -> node 0
+    #    at 1050, allocated against res_total (ids 0..29, :6353-6361), "Priority".  Job 4 (22 cpus, 40 s): fits node 0 now
+    #    (ids 170..191) and ends before 1050.
+    ids = lambda a, b: ((1 << b) - 1) ^ ((1 << a) - 1)    # core ids a..b-1 as one 256-bit mask
+    c = cluster([192, 64], [1024, 1024])
+    j = jobs([dict(cpu=100, L=100), dict(cpu=60, L=100), dict(cpu=70, L=50), dict(cpu=30, L=100), dict(cpu=22, L=40)])
+    out.append(("node_with_192_cores", c, j, {}, {
+        0: (0, NOW, [(0, 1, 100 * 256, ids(0, 100), 0)]), 1: (0, NOW, [(1, 1, 60 * 256, ids(0, 60), 0)]),
+        2: (0, NOW, [(0, 1, 70 * 256, ids(100, 170), 0)]), 3: (1, 1050, [(0, 1, 30 * 256, ids(0, 30), 0)]),
+        4: (0, NOW, [(0, 1, 22 * 256, ids(170, 192), 0)]),
+        "costs": [100 * (100 / 192) + 50 * (70 / 192) + 100 * (30 / 192) + 40 * (22 / 192), 100 * (60 / 64)],
+        # node 0: [1000, 1040) nothing free; at 1040 job 4 returns 170..191; at 1050 job 2 returns 100..169 and job 3 takes 30 cpus
+        # (its ids 0..29 are still job 0's: the erase is tolerant, PublicHeader.cpp:758-762); at 1100 job 0 returns 0..99, of which
+        # job 3 holds 0..29 until 1150
+        "timeline": {0: [(NOW, 0, 0), (1040, 22 * 256, ids(170, 192)), (1050, 62 * 256, ids(100, 192)),
+                         (1100, 162 * 256, ids(30, 192)), (1150, 192 * 256, ids(0, 192)), (INF, 0, 0)]}}))
     return out
 
 
@@ -162,7 +185,8 @@ def check(name, cluster_, jobs_, pl: abi.Placements, expect, costs=None, timelin
         assert pl.start_sec[ji] == start, f"{name}: job {ji} start {pl.start_sec[ji]} != {start}"
         o = int(pl.place_offsets[ji])
         k = int(jobs_.node_num[ji])
-        got = [(int(pl.node_idx[o + i]), int(pl.ntasks[o + i]), int(pl.cpu_raw[o + i]), int(pl.core_lo[o + i]),
+        core = lambda i: int(pl.core_lo[i]) | int(pl.core_hi[i]) << 64 | int(pl.core_w2[i]) << 128 | int(pl.core_w3[i]) << 192
+        got = [(int(pl.node_idx[o + i]), int(pl.ntasks[o + i]), int(pl.cpu_raw[o + i]), core(o + i),
                 int(pl.gres[o + i])) for i in range(k) if pl.node_idx[o + i] != abi.NODE_NONE]
         assert got == recs, f"{name}: job {ji} placements {got} != {recs}"
         if recs:
@@ -176,5 +200,7 @@ def check(name, cluster_, jobs_, pl: abi.Placements, expect, costs=None, timelin
     if "timeline" in expect and timeline is not None:
         for node, rows in expect["timeline"].items():
             tl = timeline(node)
-            got = list(zip(tl["t"].tolist(), tl["cpu_raw"].tolist(), tl["core_lo"].tolist()))
+            cores = [int(a) | int(b) << 64 | int(c2) << 128 | int(c3) << 192
+                     for a, b, c2, c3 in zip(tl["core_lo"], tl["core_hi"], tl["core_w2"], tl["core_w3"])]
+            got = list(zip(tl["t"].tolist(), tl["cpu_raw"].tolist(), cores))
             assert got == rows, f"{name}: timeline of node {node}: {got} != {rows}"

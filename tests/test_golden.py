@@ -16,6 +16,9 @@ def compare(name, placements, costs):
     g = load(name)
     t = placements.trimmed()
     for k in t:
+        if k not in g.files:   # fixtures made before ABI 3 (core ids 128..255): the cases have no such core, the planes are zero
+            assert k in ("core_w2", "core_w3") and not t[k].any(), f"{name}: {k} is not in the golden fixture"
+            continue
         assert np.array_equal(g[k], t[k]), f"{name}: {k} differs from the golden fixture"
     assert np.array_equal(g["costs"], costs.view(np.uint64)), f"{name}: fp64 costs differ"
 
@@ -39,6 +42,9 @@ def test_oracle_matches_golden_run_limits(name):
     out = limit_outputs(LIMIT_CASES[name]())
     g = load(name)
     for k, v in out.items():
+        if k not in g.files:   # (as above)
+            assert k.endswith(("core_w2", "core_w3")) and not v.any(), f"{name}: {k} is not in the golden fixture"
+            continue
         assert np.array_equal(g[k], v), f"{name}: {k} differs from the golden fixture"
 
 
@@ -47,4 +53,7 @@ def test_oracle_matches_golden_steps(name):
     out = step_outputs(STEP_CASES[name])
     g = load(name)
     for k, v in out.items():
+        if k not in g.files:   # (as above)
+            assert k.endswith(("core_w2", "core_w3")) and not v.any(), f"{name}: {k} is not in the golden fixture"
+            continue
         assert np.array_equal(g[k], v), f"{name}: {k} differs from the golden fixture"

@@ -53,6 +53,18 @@ def test_random_heterogeneous(engine_cls, seed):
     _run(engine_cls, c, j, now, running=run, tag=f"random{seed}")
 
 
+@pytest.mark.parametrize("seed,N,J", [(40, 96, 900), (41, 160, 2500), (42, 48, 2500), (43, 400, 4000)])
+def test_nodes_with_192_and_256_cores(engine_cls, seed, N, J):
+    """Core ids 128..255 (ABI 3: core_w2 / core_w3 through cns_node_soa, the running allocations, the time maps in HBM and the
+    placement records): every feature of the heterogeneous cases on clusters whose big nodes have 192 or 256 cores; allocations
+    cross the id-127 boundary, deep queues backfill into maps whose entries carry all four mask words."""
+    c, j, now, run = helpers.random_case(seed, N=N, J=J, P=1 + seed % 3, running=N // 2)
+    c = helpers.widen_cores(c, seed)
+    got, _ = _run(engine_cls, c, j, now, running=run, tag=f"wide cores {seed}")
+    assert (got.core_w2 != 0).any() and (got.core_w3 != 0).any(), "case must allocate core ids above 127 and above 191"
+    assert (got.reason[:j.num_jobs] == 1).sum() > 20, "case must backfill"
+
+
 @pytest.mark.parametrize("seed", [100, 101])
 def test_random_tight_limits(engine_cls, seed):
     # kAlgoMaxJobNumPerNode and kAlgoMaxTimeWindow reached: nodes drop out (:6194), backfill gives up (h:815)

@@ -250,6 +250,26 @@ def test_engine_preempt_larger_cases(built, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(4))
+def test_engine_preempt_on_nodes_with_192_and_256_cores(built, seed):
+    """Preemption (releases, the segment trees' Res records, the placement records read back at a release) with core ids 128..255."""
+    from oracle import pyoracle
+    from tests import helpers
+    c, j, now, run, pre = random_preempt_case(1300 + seed, N=24 + 8 * seed, J=400, P=1 + seed % 2, running=60)
+    c = helpers.widen_cores(c, seed)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    if pyoracle.ref_available():   # ... and the reference's own code agrees with the oracle on this case
+        r2 = pyoracle.select(c, j, now, running=run, preempt=pre, backend="ref")
+        assert r2.placements.diff(ref.placements) is None and r2.preempt_out.lists() == ref.preempt_out.lists()
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        compare_engine(f"preempt wide cores {seed}", c, j, ref, eng, pl, po)
+        assert sum(len(x) for x in po.lists()) > 0 and (pl.core_w2 != 0).any()
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
 def test_engine_preempt_disabled_is_the_plain_cycle(built):
     from oracle import pyoracle
     c, j, now, run, pre = random_preempt_case(777, N=12, J=80, P=1, running=16)

@@ -47,7 +47,7 @@ def same_run(tag, c, a, b, preempt=False, jobs=None):
         if jobs is not None and not live[n]:
             assert len(y["t"]) == 0, f"{tag}: the reference has a NodeState for node {n}, which no partition with pending jobs lists"
             continue
-        for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres"):
+        for f in ("t", "cpu_raw", "mem", "core_lo", "core_hi", "gres", "core_w2", "core_w3"):
             assert np.array_equal(x[f], y[f]), f"{tag}: final time map of node {n} differs in {f}:\n{x[f]}\n{y[f]}"
     if preempt:
         assert a.preempt_out.lists() == b.preempt_out.lists(), f"{tag}: preempted_jobs lists differ"
@@ -102,6 +102,19 @@ def test_reference_code_on_hand_derived_reservation_scenarios():
 def test_selection_random_small(seed):
     c, j, now, run = helpers.random_case(300 + seed, N=20 + seed % 13, J=160, P=1 + seed % 3, running=8 + seed % 9)
     both(f"random {seed}", c, j, now, running=run)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_selection_random_on_nodes_with_192_and_256_cores(seed):
+    """Core ids 128..255 (ABI 3: the core_w2 / core_w3 planes): CpuSet::core_ids is an unbounded std::set<uint32_t>
+    (PublicHeader.h:555-573); jobs of up to 16 cpus x several tasks fill the wide nodes far beyond core id 127."""
+    c, j, now, run = helpers.random_case(500 + seed, N=20 + seed % 13, J=400, P=1 + seed % 3, running=8 + seed % 9)
+    c = helpers.widen_cores(c, seed)
+    a, b = both(f"wide cores {seed}", c, j, now, running=run)
+    assert (a.placements.core_w2 != 0).any(), "case must allocate core ids above 127"
+    if seed % 4 == 0:
+        l = pyoracle.select(c, j, now, running=run, algebra=pyoracle.LITERAL)
+        assert l.placements.diff(a.placements) is None
 
 
 @pytest.mark.parametrize("seed", range(12))
@@ -181,28 +194,31 @@ def test_benchmark_configs_scaled(cfg):
 # ---------------------------------------------------------------------------------------------------------------------
 # the resource algebra by itself: GetFeasibleResourceInNode, Ckmin, +=, -=, <= of the reference vs both oracle algebras
 # ---------------------------------------------------------------------------------------------------------------------
-def _rand_res(rng, lay):
-    cores = int(rng.integers(0, 129))
+def _rand_res(rng, lay, max_cores=128):
+    cores = int(rng.integers(0, max_cores + 1))
     m = (1 << cores) - 1
-    keep = int(rng.integers(0, 1 << 30)) | (int(rng.integers(0, 1 << 30)) << 30) | (int(rng.integers(0, 1 << 30)) << 60) | (int(rng.integers(0, 1 << 30)) << 90)
+    keep = 0
+    for sh in range(0, 256, 30):
+        keep |= int(rng.integers(0, 1 << 30)) << sh
     m &= keep if rng.random() < 0.7 else m
     g = int(rng.integers(0, 1 << 16)) if rng.random() < 0.8 else 0
     cpu = int(bin(m).count("1")) * 256 + (128 if rng.random() < 0.2 else 0)
-    return pyoracle.make_res(cpu, int(rng.integers(0, 64)) << 30, m & (2**64 - 1), m >> 64, g)
+    w = 2**64 - 1
+    return pyoracle.make_res(cpu, int(rng.integers(0, 64)) << 30, m & w, (m >> 64) & w, g, (m >> 128) & w, (m >> 192) & w)
 
 
-@pytest.mark.parametrize("seed", range(4))
-def test_algebra_random_against_the_reference_code(seed):
+@pytest.mark.parametrize("seed,max_cores", [(0, 128), (1, 128), (2, 128), (3, 128), (4, 256), (5, 256), (6, 192)])
+def test_algebra_random_against_the_reference_code(seed, max_cores):
     rng = np.random.default_rng(99 + seed)
     lay = helpers.multi_type_layout()
     for _ in range(1500):
-        a, b = _rand_res(rng, lay), _rand_res(rng, lay)
+        a, b = _rand_res(rng, lay, max_cores), _rand_res(rng, lay, max_cores)
         for op in ("ckmin", "add", "le"):
             want = pyoracle.binop(lay, 0, op, a, b, backend="ref")
             for alg in (pyoracle.MASK, pyoracle.LITERAL):
                 assert pyoracle.binop(lay, alg, op, a, b) == want, (op, a.tup(), b.tup())
         # -= of a subset (what every caller on the path does): b := a AND b
-        sub = pyoracle.make_res(min(a.cpu, b.cpu), min(a.mem, b.mem), a.clo & b.clo, a.chi & b.chi, a.gres & b.gres)
+        sub = pyoracle.make_res(min(a.cpu, b.cpu), min(a.mem, b.mem), a.clo & b.clo, a.chi & b.chi, a.gres & b.gres, a.c2 & b.c2, a.c3 & b.c3)
         want = pyoracle.binop(lay, 0, "sub", a, sub, backend="ref")
         for alg in (pyoracle.MASK, pyoracle.LITERAL):
             assert pyoracle.binop(lay, alg, "sub", a, sub) == want
@@ -214,7 +230,8 @@ def test_algebra_random_against_the_reference_code(seed):
         elif s == 3: v = int(rng.integers(1, 4)); gtot[0] = v + 1; gspec[1] = v
         elif s == 4: gtot[1] = int(rng.integers(1, 9))
         elif s == 5: gspec[0] = 1; gspec[1] = 1; gtot[0] = int(rng.integers(2, 5))
-        req = pyoracle.make_req(int(rng.choice([128, 256, 384, 512, 1024, 4096])), int(rng.integers(0, 32)) << 30, gtot, gspec)
+        req = pyoracle.make_req(int(rng.choice([128, 256, 384, 512, 1024, 4096] + ([130 * 256, 150 * 256, 200 * 256] if max_cores > 128 else []))),
+                                int(rng.integers(0, 32)) << 30, gtot, gspec)
         want = pyoracle.feasible(lay, 0, req, a, backend="ref")
         for alg in (pyoracle.MASK, pyoracle.LITERAL):
             assert pyoracle.feasible(lay, alg, req, a) == want, (req.cpu, gtot, gspec, a.tup())

@@ -21,7 +21,11 @@ def _jobs(job_nodes, job_steps):
         for n, c, m, l, gr in nodes:
             idx.append(n); cpu.append(int(c * 256)); mem.append(m * GIB); lo.append(l); g.append(gr)
         off.append(len(idx))
-    return st.StepJobs(off, idx, cpu, mem, lo, [0] * len(idx), g, np.cumsum([0] + list(job_steps)))
+    W = (1 << 64) - 1   # `core_lo` may be a mask of up to 256 core ids: split into the four planes of the ABI
+    wide = any(l >> 128 for l in lo)
+    return st.StepJobs(off, idx, cpu, mem, [l & W for l in lo], [(l >> 64) & W for l in lo], g, np.cumsum([0] + list(job_steps)),
+                       avail_core_w2=[(l >> 128) & W for l in lo] if wide else None,
+                       avail_core_w3=[(l >> 192) & W for l in lo] if wide else None)
 
 
 def _steps(specs):
@@ -86,7 +90,8 @@ def test_oracle_kat(name, algebra):
     _check(pyoracle.schedule_steps(abi.GresLayout(), jobs, steps, algebra), exp)
 
 
-def random_step_case(seed, J=300):
+def random_step_case(seed, J=300, wide=False):
+    """wide: some nodes' free core ids lie above 127 (ABI 3: the avail_core_w2 / _w3 planes)"""
     rng = np.random.default_rng(seed + 4100)
     lay = helpers.multi_type_layout()
     job_nodes, nsteps = [], []
@@ -96,6 +101,8 @@ def random_step_case(seed, J=300):
         rows = []
         for n in nodes:
             cores = int(rng.integers(0, 1 << 16)) | (int(rng.integers(0, 2)) << 16)     # random free core ids
+            if wide and rng.random() < 0.5:   # the low ids are taken, what is free sits around the 128 and 192 boundaries
+                cores = (int(rng.integers(0, 1 << 10)) << 122) | (int(rng.integers(0, 1 << 8)) << 188) | (cores & 0x3)
             frac = int(rng.integers(0, 3)) * 64                                           # some fractional cpu left over
             g = int(rng.choice([0, 0, 0x0F, 0xF3, 0xFF00, 0x3C5A]))
             rows.append((n, bin(cores).count("1") + frac / 256, int(rng.integers(1, 64)), cores, g))
@@ -192,6 +199,23 @@ def test_gpu_kat(engine_default, name):
 def test_gpu_random(engine_default, seed):
     lay, jobs, steps = random_step_case(seed, J=2000 if seed == 3 else 300)
     _gpu(engine_default, lay, jobs, steps)
+
+
+@pytest.mark.parametrize("seed", [10, 11])
+def test_oracle_random_core_ids_above_127(seed):
+    lay, jobs, steps = random_step_case(seed, wide=True)
+    a = pyoracle.schedule_steps(lay, jobs, steps, pyoracle.MASK)
+    b = pyoracle.schedule_steps(lay, jobs, steps, pyoracle.LITERAL)
+    assert a.diff(b) is None
+    assert a.task_core_w2.any() and a.task_core_w3.any() and a.node_core_w2.any(), "case must hand out core ids above 127"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [10, 11])
+def test_gpu_random_core_ids_above_127(engine_default, seed):
+    lay, jobs, steps = random_step_case(seed, J=600, wide=True)
+    res = _gpu(engine_default, lay, jobs, steps)
+    assert res.task_core_w2.any() and res.task_core_w3.any()
 
 
 @pytest.mark.gpu
