@@ -12,7 +12,7 @@ from tests.test_overlap import overlap_case
 
 def _bits(x):
     x = int(x)
-    return {i for i in range(64) if (x >> i) & 1}
+    return {i for i in range(x.bit_length()) if (x >> i) & 1}
 
 
 def _res(layout, cpu, mem, lo, hi, g):
@@ -36,7 +36,10 @@ def run_pyref(c: abi.Cluster, j: abi.Jobs, now, run=None, max_job_num_per_node=0
     N = c.num_nodes
     chi = c.core_hi if c.core_hi is not None else np.zeros(N, np.uint64)
     gs = c.gres_slots if c.gres_slots is not None else np.zeros(N, np.uint64)
-    totals = [_res(lay, c.cpu_total_raw[n], c.mem_total[n], c.core_lo[n], chi[n], gs[n]) for n in range(N)]
+    # (core ids 128..255, ABI 3: the restatement keeps a set of ids, so they ride in `hi` as bits 64.. of one Python int)
+    w2 = c.core_w2 if c.core_w2 is not None else np.zeros(N, np.uint64)
+    w3 = c.core_w3 if c.core_w3 is not None else np.zeros(N, np.uint64)
+    totals = [_res(lay, c.cpu_total_raw[n], c.mem_total[n], c.core_lo[n], int(chi[n]) | int(w2[n]) << 64 | int(w3[n]) << 128, gs[n]) for n in range(N)]
     parts = [list(map(int, c.part_nodes[c.part_offsets[p]:c.part_offsets[p + 1]])) for p in range(c.num_partitions)]
     types_of = lambda name: [g for g in range(len(lay.class_name)) if lay.class_name[g] == name]
     cyc = pr.Cycle(now, totals, parts, schedulable=None if c.schedulable is None else list(c.schedulable), types_of=types_of,
@@ -80,7 +83,7 @@ def compare(tag, c, j, ref, cyc, out):
         assert int(pl.start_sec[i]) == start, f"{tag}: job {i} start {pl.start_sec[i]} vs {start}"
         o = int(pl.place_offsets[i])
         got = [(int(pl.node_idx[o + x]), int(pl.ntasks[o + x]), int(pl.cpu_raw[o + x]), int(pl.mem[o + x]), int(pl.core_lo[o + x]),
-                int(pl.core_hi[o + x]), int(pl.gres[o + x])) for x in range(int(j.node_num[i])) if pl.node_idx[o + x] != abi.NODE_NONE]
+                int(pl.core_hi[o + x]) | int(pl.core_w2[o + x]) << 64 | int(pl.core_w3[o + x]) << 128, int(pl.gres[o + x])) for x in range(int(j.node_num[i])) if pl.node_idx[o + x] != abi.NODE_NONE]
         want = [(n, t, a.cpu, a.mem) + _mask(lay, a) for n, t, a in picks]
         assert got == want, f"{tag}: job {i} placements {got} (oracle) vs {want} (python)"
     costs = ref.costs().view(np.uint64)
