@@ -182,6 +182,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   memset(&K, 0, sizeof K);
   K.num_nodes = h->N; K.num_parts = h->P; K.num_slots = h->S; K.num_types = h->T;
   K.tl_cap = kTlCap;
+  K.wide_cores = h->wide_cores ? 1u : 0u;
   K.max_jobs_per_node = h->cfg.max_job_num_per_node;
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
@@ -937,6 +938,7 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
   HIPCHK(h, hipMemsetAsync(rb + h->ro.start, 0, h->ro.node - h->ro.start, h->stream));  // start + 8-byte records
   HIPCHK(h, hipMemsetAsync(rb + h->ro.node, 0xFF, 4 * pl, h->stream));                  // CNS_NODE_NONE
   HIPCHK(h, hipMemsetAsync(rb + h->ro.ntasks, 0, 4 * pl, h->stream));
+  if (h->wide_cores) HIPCHK(h, hipMemsetAsync(rb + h->ro.c2, 0, h->ro.total - h->ro.c2, h->stream));   // core ids 128..255 of the records
   HIPCHK(h, hipMemcpyAsync(rb + h->ro.reason, h->d_reason_init.p, J, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_fault.p, 0, 16, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, ((size_t)h->P * (32 + 8) + 2048) * sizeof(u64), h->stream));   // cycle counters + the always-on protocol counters
@@ -1352,10 +1354,10 @@ int cns_debug_get_timeline(cns_handle* h, uint32_t node, uint32_t capacity, uint
   const u32 n = hd.len;
   *len = n;
   u32 m = std::min(n, capacity);
-  std::vector<TlEntry> e(std::max<u32>(m, 1));
-  if (m) HIPCHK(h, hipMemcpy(e.data(), blk + sizeof(NodeHdr), (size_t)m * sizeof(TlEntry), hipMemcpyDeviceToHost));
+  std::vector<TlMem> e(std::max<u32>(m, 1));
+  if (m) HIPCHK(h, hipMemcpy(e.data(), blk + sizeof(NodeHdr), (size_t)m * sizeof(TlMem), hipMemcpyDeviceToHost));
   for (u32 i = 0; i < m; ++i) {
-    t[i] = e[i].t; cpu_raw[i] = e[i].r.cpu; mem[i] = e[i].r.mem; core_lo[i] = e[i].r.clo; core_hi[i] = e[i].r.chi; gres[i] = e[i].r.gres;
+    t[i] = e[i].t; cpu_raw[i] = e[i].cpu; mem[i] = e[i].mem; core_lo[i] = e[i].clo; core_hi[i] = e[i].chi; gres[i] = e[i].gres;
   }
   return CNS_OK;
 }
@@ -1371,9 +1373,11 @@ int cns_debug_get_timeline_cores(cns_handle* h, uint32_t node, uint32_t capacity
   NodeHdr hd;
   HIPCHK(h, hipMemcpy(&hd, blk, sizeof hd, hipMemcpyDeviceToHost));
   const u32 m = std::min(hd.len, capacity);
-  std::vector<TlEntry> e(std::max<u32>(m, 1));
-  if (m) HIPCHK(h, hipMemcpy(e.data(), blk + sizeof(NodeHdr), (size_t)m * sizeof(TlEntry), hipMemcpyDeviceToHost));
-  for (u32 i = 0; i < m; ++i) { core_w2[i] = e[i].r.c2; core_w3[i] = e[i].r.c3; }
+  for (u32 i = 0; i < m; ++i) core_w2[i] = core_w3[i] = 0;
+  if (!h->wide_cores) return CNS_OK;   // (the TlExt array of a block is live only for snapshots with such core ids)
+  std::vector<TlExt> e(std::max<u32>(m, 1));
+  if (m) HIPCHK(h, hipMemcpy(e.data(), blk + sizeof(NodeHdr) + (size_t)kTlCap * sizeof(TlMem), (size_t)m * sizeof(TlExt), hipMemcpyDeviceToHost));
+  for (u32 i = 0; i < m; ++i) { core_w2[i] = e[i].c2; core_w3[i] = e[i].c3; }
   return CNS_OK;
 }
 

@@ -58,8 +58,8 @@ struct NodeHdr {
   Res total;
 };
 static_assert(sizeof(NodeHdr) == 128, "NodeHdr = 2 TlEntry slots");
-static_assert(sizeof(TlEntry) == 64, "TlEntry layout: one entry per 64-byte line segment");
-constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * sizeof(TlEntry);
+static_assert(sizeof(TlMem) == 48 && sizeof(TlExt) == 16, "time-map records in HBM");
+constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * (sizeof(TlMem) + sizeof(TlExt));   // header, kTlCap TlMem, kTlCap TlExt
 
 // Job record: 64 dwords, lane-striped (lane i of a wave loads dword i: one VGPR while in flight).
 // Dwords 0..29 are packed by the host (cns_upload_jobs); dwords 32.. are derived per cycle by the
@@ -125,6 +125,7 @@ struct KParams {
   // ---- cluster -------------------------------------------------------------------------
   u32 num_nodes, num_parts, num_slots, num_types;
   u32 tl_cap, max_jobs_per_node;
+  u32 wide_cores;          // a node of the snapshot has a core id above 127: the TlExt arrays and the o_c2 / o_c3 planes are live
   u32 wide_inject_stall;   // test hook (CNS_WIDE_INJECT_STALL=<job>): job index + 1 of partition 0 whose exchange the leader scanner of k_wide
                            // never publishes — every other wave's wait then runs out (fault 28) and the cycle is re-run on k_pipe / k_select
   u32 reserved1;

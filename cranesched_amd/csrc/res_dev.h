@@ -37,10 +37,55 @@ struct Res {
 };
 
 // One entry of a node's time -> available-resource map (std::map<absl::Time, ResourceInNodeV3>,
-// src/CraneCtld/JobScheduler.h:245), stored as a sorted array in HBM.
+// src/CraneCtld/JobScheduler.h:245) — the REGISTER form.
 struct TlEntry {
   i64 t;
   Res r;
+};
+// ... and how it sits in HBM: a sorted array of 48-byte records (time, cpu, mem, core ids 0..127, GRES) plus, behind it, a
+// parallel array of 16-byte records with core ids 128..255 that is read and written ONLY when the snapshot has a node with
+// such ids (TlMap::wide): clusters without them move exactly the bytes they moved before ABI 3.
+struct TlMem {
+  i64 t;
+  i64 cpu;
+  u64 mem;
+  u64 clo, chi;
+  u64 gres;
+};
+struct TlExt {
+  u64 c2, c3;
+};
+struct TlSlot {
+  TlMem* m;
+  TlExt* x;
+  u32 wide;
+  CNS_HD TlEntry get() const {
+    const TlMem v = *m;
+    TlEntry e;
+    e.t = v.t; e.r.cpu = v.cpu; e.r.mem = v.mem; e.r.clo = v.clo; e.r.chi = v.chi; e.r.gres = v.gres;
+    e.r.c2 = 0; e.r.c3 = 0;
+    if (wide) { const TlExt w = *x; e.r.c2 = w.c2; e.r.c3 = w.c3; }
+    return e;
+  }
+  CNS_HD operator TlEntry() const { return get(); }
+  CNS_HD i64 t() const { return m->t; }
+  CNS_HD Res r() const { return get().r; }
+  CNS_HD void operator=(const TlEntry& e) const {
+    TlMem v;
+    v.t = e.t; v.cpu = e.r.cpu; v.mem = e.r.mem; v.clo = e.r.clo; v.chi = e.r.chi; v.gres = e.r.gres;
+    *m = v;
+    if (wide) { TlExt w; w.c2 = e.r.c2; w.c3 = e.r.c3; *x = w; }
+  }
+  CNS_HD void operator=(const TlSlot& o) const { *this = o.get(); }
+  CNS_HD void set_t(i64 t) const { m->t = t; }
+  CNS_HD void set_r(const Res& r) const { TlEntry e; e.t = m->t; e.r = r; *this = e; }
+};
+struct TlMap {
+  TlMem* m;
+  TlExt* x;
+  u32 wide;
+  CNS_HD TlSlot operator[](u32 i) const { return TlSlot{m + i, x + i, wide}; }
+  CNS_HD TlMap operator+(u32 k) const { return TlMap{m + k, x + k, wide}; }
 };
 
 // ResourceView of a request: cpu raw, mem, per-name GresCount.total (4 x u8) and per-class

@@ -236,7 +236,10 @@ __device__ __forceinline__ NodeHdr* hdr_of(const KParams& P, u32 q) {
   if (P.slot_block) q = P.slot_block[q];
   return hdr_raw(P, q);
 }
-__device__ __forceinline__ TlEntry* tl_of(NodeHdr* h) { return (TlEntry*)((char*)h + sizeof(NodeHdr)); }
+__device__ __forceinline__ TlMap tl_of(const KParams& P, const NodeHdr* h) {
+  TlMem* m = (TlMem*)((char*)h + sizeof(NodeHdr));
+  return TlMap{m, (TlExt*)(m + P.tl_cap), P.wide_cores};
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_init_nodes — prologue
@@ -255,8 +258,8 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
   Res a0 = tot;
   double cost = 0.0;
   NodeHdr* hd = hdr_raw(P, q);      // (a secondary slot of a shared node builds a private copy nobody reads: same values)
-  TlEntry* T = tl_of(hd);           // T[i].t / T[i].r: change times and what is RELEASED there
-  TlEntry* A2 = T + kTlCap / 2;     // A2[i].r: what is ALLOCATED at T[i].t (only with reservations; host bounds the count)
+  const TlMap T = tl_of(P, hd);       // T[i].t / T[i].r: change times and what is RELEASED there
+  const TlMap A2 = T + kTlCap / 2;     // A2[i].r: what is ALLOCATED at T[i].t (only with reservations; host bounds the count)
   u32 len = 1;  // T[0] reserved for {now, avail0}
   const double tcpu = (double)tot.cpu / 256.0;
   const u32 rvb = P.rv_off[q], rve = P.rv_off[q + 1];
@@ -265,15 +268,18 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
   // at one time releases apply before allocations (h:315-320)
   auto put = [&](i64 time, const Res& r, int kind) {
     u32 i = 1;
-    while (i < len && T[i].t < time) ++i;
-    if (!(i < len && T[i].t == time)) {
+    while (i < len && T[i].t() < time) ++i;
+    if (!(i < len && T[i].t() == time)) {
       for (u32 m = len; m > i; --m) { T[m] = T[m - 1]; if (has_rv) A2[m] = A2[m - 1]; }
-      T[i].t = time;
-      T[i].r = res_zero();
-      if (has_rv) A2[i].r = res_zero();
+      TlEntry z; z.t = time; z.r = res_zero();
+      T[i] = z;
+      if (has_rv) A2[i] = z;
       ++len;
     }
-    if (kind == 0) res_add(T[i].r, r); else res_add(A2[i].r, r);
+    const TlSlot dst = kind == 0 ? T[i] : A2[i];
+    Res acc = dst.r();
+    res_add(acc, r);
+    dst.set_r(acc);
   };
   i64 first = kInf;
   for (u32 a = rvb; a < rve; ++a) {  // NodeRater: reserved_res first (h:502-506)
@@ -309,23 +315,21 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
     cost += (double)(end - P.now) * ratio;
     put(end, r, 0);                        // release {end, r}; equal end times accumulate (JobScheduler.h:325-335)
   }
-  T[0].t = P.now;
-  T[0].r = a0;
+  { TlEntry e0; e0.t = P.now; e0.r = a0; T[0] = e0; }
   for (u32 i = 1; i < len; ++i) {  // value at a change time = previous value + releases - allocations
-    Res v = T[i - 1].r;
-    res_add(v, T[i].r);
-    if (has_rv) res_sub(v, A2[i].r);
-    T[i].r = v;
+    Res v = T[i - 1].r();
+    res_add(v, T[i].r());
+    if (has_rv) res_sub(v, A2[i].r());
+    T[i].set_r(v);
   }
   {  // time_avail_res_map[end].SetToZero(), JobScheduler.h:337 (end = InfiniteFuture, or the reservation's end)
     u32 i = 1;
-    while (i < len && T[i].t < end_h) ++i;
-    if (!(i < len && T[i].t == end_h)) {
+    while (i < len && T[i].t() < end_h) ++i;
+    if (!(i < len && T[i].t() == end_h)) {
       for (u32 m = len; m > i; --m) T[m] = T[m - 1];
-      T[i].t = end_h;
       ++len;
     }
-    T[i].r = res_zero();
+    { TlEntry z; z.t = end_h; z.r = res_zero(); T[i] = z; }
   }
   hd->len = len;
   hd->node = n;
@@ -340,8 +344,9 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
   {  // the earliest entry below the front (a pending reservation's dip; the zero entry at the end of a reservation's own map)
     u32 dt = 0xFFFFFFFFu, dcm = 0, dg = 0;
     for (u32 i = 1; i < len; ++i) {
-      if (T[i].t == kInf || T[i].t - P.now >= 0xFFFFFFFFll) break;
-      if (dip_below(T[i].r, a0, P.gres)) { dt = (u32)(T[i].t - P.now); dcm = dip_cm_of(T[i].r); dg = nibbles_of(class_counts(T[i].r.gres, P.gres)); break; }
+      const TlEntry ei = T[i];
+      if (ei.t == kInf || ei.t - P.now >= 0xFFFFFFFFll) break;
+      if (dip_below(ei.r, a0, P.gres)) { dt = (u32)(ei.t - P.now); dcm = dip_cm_of(ei.r); dg = nibbles_of(class_counts(ei.r.gres, P.gres)); break; }
     }
     P.dip_t[q] = dt; P.dip_cm[q] = dcm; P.dip_g[q] = dg;
   }
@@ -633,7 +638,7 @@ __device__ __forceinline__ Res window_min_regs(const TlEntry& e, bool act, const
 }
 
 // General form for time maps longer than one chunk.
-__device__ __noinline__ Res window_min(const TlEntry* T, u32 len, const Res& a0, i64 E, u32 lane) {
+__device__ __noinline__ Res window_min(const TlMap T, u32 len, const Res& a0, i64 E, u32 lane) {
   i64 cpu = a0.cpu;
   u64 mem = a0.mem, clo = ~0ull, chi = ~0ull, c2 = ~0ull, c3 = ~0ull, g = a0.gres;
   for (u32 base = 0; base < len; base += 64) {
@@ -665,7 +670,7 @@ __device__ __noinline__ Res window_min(const TlEntry* T, u32 len, const Res& a0,
 }
 
 // Exclusive job: every entry with time < E must still hold the whole node (JobScheduler.cpp:6249-6257).
-__device__ __noinline__ bool window_all_total(const TlEntry* T, u32 len, const Res& tot, i64 E, u32 lane) {
+__device__ __noinline__ bool window_all_total(const TlMap T, u32 len, const Res& tot, i64 E, u32 lane) {
   bool bad = false;
   for (u32 base = 0; base < len; base += 64) {
     u32 i = base + lane;
@@ -684,7 +689,7 @@ __device__ __noinline__ bool window_all_total(const TlEntry* T, u32 len, const R
 // Entries with start <= t < end lose `res`; boundaries at start / end are inserted when missing (the
 // end boundary copies the un-subtracted value of the entry covering `end`).
 // Register form: lane i holds entry i of a map with len <= 64.  Returns the new length.
-__device__ __forceinline__ u32 tl_commit_regs(const KParams& P, NodeHdr* hd, TlEntry* T, TlEntry e, u32 len,
+__device__ __forceinline__ u32 tl_commit_regs(const KParams& P, NodeHdr* hd, const TlMap T, TlEntry e, u32 len,
                                               i64 start, i64 end, const Res& res, u32 lane, u32 job) {
   const bool act = lane < len;
   const i64 t = act ? e.t : kInf;
@@ -722,18 +727,18 @@ __device__ __forceinline__ u32 tl_commit_regs(const KParams& P, NodeHdr* hd, TlE
 // never overwrites an entry that has not been read yet.
 template <bool kRelease = false>   // kRelease: UpdateResourceInNode(..., is_release = true): += instead of -=
 __device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, i64 end, const Res& res, u32 lane, u32 job) {
-  TlEntry* T = tl_of(hd);
+  const TlMap T = tl_of(P, hd);
   const u32 len = hd->len;
   u32 c_start = 0, c_end = 0;  // #entries with t <= start / t <= end
   for (u32 base = 0; base < len; base += 64) {
     u32 i = base + lane;
     bool act = i < len;
-    i64 t = act ? T[i].t : kInf;
+    i64 t = act ? T[i].t() : kInf;
     c_start += __popcll(__ballot(act && t <= start));
     c_end += __popcll(__ballot(act && t <= end));
     if (__any(act && t > end)) break;
   }
-  if (c_start == 0 || c_end > len || (c_end == len && T[len - 1].t != end) || len + 2 > P.tl_cap) {
+  if (c_start == 0 || c_end > len || (c_end == len && T[len - 1].t() != end) || len + 2 > P.tl_cap) {
     if (lane == 0) set_fault(P, 1, job, hd->node, len);
     return len;
   }
@@ -766,7 +771,7 @@ __device__ __noinline__ u32 tl_commit(const KParams& P, NodeHdr* hd, i64 start, 
 
 // Wave-parallel form for time maps of any length: 64 entries per step, "alloc fits" ballot per chunk, run
 // state (inside a satisfied run? its start) carried across chunks.  All lanes return the same value.
-__device__ __noinline__ i64 next_fit_wave(const TlEntry* T, u32 len, const Res* alloc_p, i64 L, i64 t0) {
+__device__ __noinline__ i64 next_fit_wave(const TlMap T, u32 len, const Res* alloc_p, i64 L, i64 t0) {
   const u32 lane = threadIdx.x & 63u;
   const Res alloc = *alloc_p;
   bool in_run = false;
@@ -785,7 +790,7 @@ __device__ __noinline__ i64 next_fit_wave(const TlEntry* T, u32 len, const Res* 
     const u32 c = (u32)__popcll(__ballot(act && e.t <= t0));
     u32 pos = 0;  // first bit of this chunk still to be looked at
     if (c != 0) {
-      if (c == n && base + 64 < len && T[base + 64].t <= t0) continue;  // the covering entry is further on
+      if (c == n && base + 64 < len && T[base + 64].t() <= t0) continue;  // the covering entry is further on
       pos = c - 1;
     }
     while (pos < n) {
@@ -855,7 +860,7 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
     const u32 q = qbeg + slot_of_code_t<kS>(ent.p);
     NodeHdr* hd = hdr_of(P, q);
     const Res tot = hd->total;
-    const Res e0 = tl_of(hd)[0].r;
+    const Res e0 = tl_of(P, hd)[0].r();
     u32 newlen = tl_commit(P, hd, start, end, ent.res, lane, orig);
     // MinCpuTimeRatioFirst::UpdateCost, JobScheduler.h:47-53 — ratio first, then x seconds, then +=
     double ratio = ((double)ent.res.cpu / 256.0) / ((double)tot.cpu / 256.0);
@@ -937,7 +942,7 @@ __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 
                                                    const Res& alloc, i64 start, int reason, u32 lane, UpdRec* s_upd,
                                                    int* s_nupd, NodeSum& ns) {
   const i64 end = start + L;
-  const u32 newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, alloc, lane, orig);
+  const u32 newlen = tl_commit_regs(P, hd, tl_of(P, hd), e, h.len, start, end, alloc, lane, orig);
   const double ratio = ((double)alloc.cpu / 256.0) / ((double)h.total.cpu / 256.0);
   const double delta = (double)(end - start) * ratio;
   const double ncost = cost + delta;
@@ -1091,7 +1096,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   while (wcode != kNone) {
     const u32 q = qbeg + slot_of_code_t<kS>(wcode);
     NodeHdr* const hd = hdr_of(P, q);
-    TlEntry* const T = tl_of(hd);
+    const TlMap T = tl_of(P, hd);
     int code = 0;
     const u32 len = hd->len;
     const u32 n = hd->node;
@@ -1255,7 +1260,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       for (u32 i = 0; i < J.k; ++i) {
         const HeapEnt x = H[i];
         NodeHdr* hd = hdr_of(P, qbeg + slot_of_code_t<kS>(x.p));
-        const i64 sx = next_fit_wave(tl_of(hd), hd->len, &H[i].res, J.L, t);
+        const i64 sx = next_fit_wave(tl_of(P, hd), hd->len, &H[i].res, J.L, t);
         Tm = sx > Tm ? sx : Tm;
       }
       if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
@@ -1292,7 +1297,7 @@ __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, No
   drain_stores();
   hd = hdr_of(P, q);
   h = *hd;
-  e = tl_of(hd)[lane];
+  e = tl_of(P, hd)[lane];
   h.len = uni32(h.len); h.node = uni32(h.node); h.type = uni32(h.type);
   h.avail0 = uni_res(h.avail0); h.total = uni_res(h.total);
 }
@@ -1322,7 +1327,7 @@ __device__ __forceinline__ void commit_pick(const KParams& P, const JobCtx& J, c
   const i64 end = start + J.L;
   const Res e0 = rl_res(e.r, 0);  // entry at `now`
   u32 newlen;
-  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, x.res, lane, orig);
+  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(P, hd), e, h.len, start, end, x.res, lane, orig);
   else newlen = tl_commit(P, hd, start, end, x.res, lane, orig);
   const double ratio = ((double)x.res.cpu / 256.0) / ((double)h.total.cpu / 256.0);
   const double ncost = x.cost + (double)(end - start) * ratio;
@@ -1375,7 +1380,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
     bool ok = false;
     if (feasible(J.min_view, h.avail0, f, P.gres)) {
       m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
-                              : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));
+                              : window_min(tl_of(P, hd), h.len, h.avail0, J.E, lane));
       ok = feasible(J.min_view, m, f, P.gres);
     }
     if (ok) {
@@ -1456,7 +1461,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
         load_block(P, qbeg + slot_of_code(x.p), lane, hd, h, e);
         i64 s;
         if (h.len <= 64) s = next_fit_regs(e, h.len, x.res, J.L, t, lane);
-        else s = next_fit_wave(tl_of(hd), h.len, &x.res, J.L, t);
+        else s = next_fit_wave(tl_of(P, hd), h.len, &x.res, J.L, t);
         Tm = s > Tm ? s : Tm;
       }
       if (Tm == kInf || Tm - P.now > P.max_window) break;  // kAlgoMaxTimeWindow, JobScheduler.h:815
@@ -1494,7 +1499,7 @@ __device__ __forceinline__ void helper_commit_regs(const KParams& P, const GresD
   const i64 end = start + J.L;
   const Res e0 = rl_res(e.r, 0);  // entry at `now`
   u32 newlen;
-  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(hd), e, h.len, start, end, res, lane, J.orig);
+  if (h.len <= 64) newlen = tl_commit_regs(P, hd, tl_of(P, hd), e, h.len, start, end, res, lane, J.orig);
   else newlen = tl_commit(P, hd, start, end, res, lane, J.orig);
   // MinCpuTimeRatioFirst::UpdateCost, JobScheduler.h:47-53 — ratio first, then x seconds, then +=
   const double ratio = ((double)res.cpu / 256.0) / ((double)h.total.cpu / 256.0);
@@ -1539,7 +1544,7 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const GresDev
     load_block(P, q, lane, hd, h, e);
     // :6285 first; it implies :6274 except for the core-id count of res_avail (see the single-node fast path)
     const Res m = uni_res(h.len <= 64 ? window_min_regs(e, lane < h.len, h.avail0, J.E)
-                                      : window_min(tl_of(hd), h.len, h.avail0, J.E, lane));    // :6278-6283
+                                      : window_min(tl_of(P, hd), h.len, h.avail0, J.E, lane));    // :6278-6283
     bool ok = feasible(J.min_view, m, f, G);  // tpn_min == 1: f is the 1-task allocation (:6285, :6312-6320)
     if (ok) {
       const i64 req_int = J.min_view.cpu / 256;
@@ -1594,7 +1599,7 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const GresDev* 
   int par2 = 0;
   for (u32 iter = 0; iter < (1u << 20); ++iter) {
     if (active) {
-      const i64 sx = h.len <= 64 ? next_fit_regs(e, h.len, alloc, J.L, t, lane) : next_fit_wave(tl_of(hd), h.len, &alloc, J.L, t);
+      const i64 sx = h.len <= 64 ? next_fit_regs(e, h.len, alloc, J.L, t, lane) : next_fit_wave(tl_of(P, hd), h.len, &alloc, J.L, t);
       if (lane == 0) nf[par2 * kMultiK + (int)i] = sx;
     }
     wg_barrier();
