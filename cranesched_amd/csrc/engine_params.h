@@ -5,6 +5,7 @@
 //   job table    : SoA, grouped by partition, queue order preserved inside a partition
 //   results      : SoA in the caller's original job order
 #pragma once
+#include <cstddef>
 #include "pq_emul.h"
 #include "res_dev.h"
 
@@ -52,12 +53,13 @@ constexpr u32 kNone = 0xFFFFFFFFu;
 //   header : time-map length, dense node index, node type, cycle-start res_avail (JobScheduler.h:287,313)
 //            and res_total
 //   entries: sorted-array form of NodeState::time_avail_res_map (JobScheduler.h:245,291)
-struct NodeHdr {
+struct alignas(16) NodeHdr {
   u32 len, node, type, pad;
   Res avail0;
   Res total;
 };
-static_assert(sizeof(NodeHdr) == 128, "NodeHdr = 2 TlEntry slots");
+static_assert(sizeof(NodeHdr) == 128 && offsetof(NodeHdr, avail0) == 16 && offsetof(NodeHdr, total) == 72 && offsetof(Res, gres) == 32 &&
+              offsetof(Res, c2) == 40, "NodeHdr layout (load_block<false> reads the words of its first 96 + 8 bytes by offset)");
 static_assert(sizeof(TlMem) == 48 && sizeof(TlExt) == 16, "time-map records in HBM");
 constexpr u64 kBlockStride = sizeof(NodeHdr) + (u64)kTlCap * (sizeof(TlMem) + sizeof(TlExt));   // header, kTlCap TlMem, kTlCap TlExt
 

@@ -45,14 +45,14 @@ struct TlEntry {
 // ... and how it sits in HBM: a sorted array of 48-byte records (time, cpu, mem, core ids 0..127, GRES) plus, behind it, a
 // parallel array of 16-byte records with core ids 128..255 that is read and written ONLY when the snapshot has a node with
 // such ids (TlMap::wide): clusters without them move exactly the bytes they moved before ABI 3.
-struct TlMem {
+struct alignas(16) TlMem {
   i64 t;
   i64 cpu;
   u64 mem;
   u64 clo, chi;
   u64 gres;
 };
-struct TlExt {
+struct alignas(16) TlExt {
   u64 c2, c3;
 };
 struct TlSlot {

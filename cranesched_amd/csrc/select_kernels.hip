@@ -236,9 +236,10 @@ __device__ __forceinline__ NodeHdr* hdr_of(const KParams& P, u32 q) {
   if (P.slot_block) q = P.slot_block[q];
   return hdr_raw(P, q);
 }
+template <bool kW = true>   // kW = false: the caller knows that the snapshot has no core id above 127 (see load_block)
 __device__ __forceinline__ TlMap tl_of(const KParams& P, const NodeHdr* h) {
   TlMem* m = (TlMem*)((char*)h + sizeof(NodeHdr));
-  return TlMap{m, (TlExt*)(m + P.tl_cap), P.wide_cores};
+  return TlMap{m, (TlExt*)(m + P.tl_cap), kW ? P.wide_cores : 0u};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1292,12 +1293,30 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   return par;
 }
 
+// kW = false instantiations of the tester / commit functions of k_pipe and k_wide serve snapshots WITHOUT core ids above 127
+// (KParams::wide_cores == 0, chosen once per call by a scalar branch): every Res that enters them from memory has its upper
+// two core words replaced by the constant 0, so the compiler folds their arithmetic, their registers and their loads away —
+// those clusters run the code they ran before ABI 3 (the 4-word Res cost the testers of C4 +26 % per test otherwise).
+template <bool kW> __device__ __forceinline__ Res narrow(Res r) { if (!kW) { r.c2 = 0; r.c3 = 0; } return r; }
 // Loads the node block of slot q the way the fast paths want it: header scalarised, lane i <- entry i.
+template <bool kW = true>
 __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, NodeHdr*& hd, NodeHdr& h, TlEntry& e) {
   drain_stores();
   hd = hdr_of(P, q);
-  h = *hd;
-  e = tl_of(P, hd)[lane];
+  if (kW) {
+    h = *hd;
+    e = tl_of(P, hd)[lane];
+  } else {   // the header's first 112 bytes as seven 16-byte loads (one cache line), the 48-byte record as three
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* hq = (const u64x2*)hd;
+    const u64x2 q0 = hq[0], q1 = hq[1], q2 = hq[2], q3 = hq[3], q4 = hq[4], q5 = hq[5], q6 = hq[6];
+    h.len = (u32)q0.x; h.node = (u32)(q0.x >> 32); h.type = (u32)q0.y; h.pad = 0;
+    h.avail0.cpu = (i64)q1.x; h.avail0.mem = q1.y; h.avail0.clo = q2.x; h.avail0.chi = q2.y; h.avail0.gres = q3.x;
+    h.total.cpu = (i64)q4.y; h.total.mem = q5.x; h.total.clo = q5.y; h.total.chi = q6.x; h.total.gres = q6.y;
+    h.avail0.c2 = 0; h.avail0.c3 = 0; h.total.c2 = 0; h.total.c3 = 0;
+    const TlMem v = tl_of<false>(P, hd).m[lane];
+    e.t = v.t; e.r.cpu = v.cpu; e.r.mem = v.mem; e.r.clo = v.clo; e.r.chi = v.chi; e.r.gres = v.gres; e.r.c2 = 0; e.r.c3 = 0;
+  }
   h.len = uni32(h.len); h.node = uni32(h.node); h.type = uni32(h.type);
   h.avail0 = uni_res(h.avail0); h.total = uni_res(h.total);
 }
