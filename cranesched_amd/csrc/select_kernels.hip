@@ -64,6 +64,21 @@ __device__ __forceinline__ Res rl_res(const Res& r, u32 idx) {
   return o;
 }
 
+// A kernel's by-value KParams must not have its address taken: handed by reference to an out-of-line routine it becomes a copy in
+// SCRATCH for the WHOLE kernel — every `P.field`, also in the inlined hot loops, then is a load from private memory, and every
+// pointer read from it a generic pointer whose dereference is a flat access with a full `s_waitcnt vmcnt(0) lgkmcnt(0)`.  The
+// out-of-line routines therefore take the block's copy in HBM (KParams* Pg, uploaded before the launch; C4 296 -> 276 ms when
+// the testers of k_wide followed that rule too).  What they read through it are generic pointers all the same: as_global() says
+// where such a pointer points (global_load with counted waits instead of flat_load).
+#ifndef CNS_NO_AS_GLOBAL
+template <class T>
+__device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(const T* p) {
+  return (const __attribute__((address_space(1))) T*)p;
+}
+#else   // (A/B builds)
+template <class T> __device__ __forceinline__ const T* as_global(const T* p) { return p; }
+#endif
+
 // wave-uniform values -> SGPRs, so that the worker's GetFeasibleResourceInNode arithmetic runs on the
 // scalar unit and does not compete for vector registers
 __device__ __forceinline__ Res uni_res(const Res& r) {
@@ -444,7 +459,7 @@ __global__ __launch_bounds__(256) void k_pack_jobs(const PackParams P) {
 }
 
 __device__ __forceinline__ u32 fetch_job(const KParams& P, u64 ji) {
-  return P.jobrec[ji * kJobRecDwords + (threadIdx.x & (kJobRecDwords - 1))];
+  return *as_global(P.jobrec + (ji * kJobRecDwords + (threadIdx.x & (kJobRecDwords - 1))));
 }
 __device__ __forceinline__ u64 jr64(u32 raw, u32 f) { return ((u64)rl32(raw, f + 1) << 32) | rl32(raw, f); }
 __device__ __forceinline__ JobCtx make_job(const KParams& P, u64 ji, u32 raw) {
@@ -1308,14 +1323,16 @@ __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, No
     e = tl_of(P, hd)[lane];
   } else {   // the header's first 112 bytes as seven 16-byte loads (one cache line), the 48-byte record as three
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2* hq = (const u64x2*)hd;
+    const auto* hq = as_global((const u64x2*)hd);
+    const auto* vq = as_global((const u64x2*)(tl_of<false>(P, hd).m + lane));
+    asm volatile("" : "+v"(hq), "+v"(vq));   // (both addresses exist before the first load is issued: no address arithmetic between the loads)
     const u64x2 q0 = hq[0], q1 = hq[1], q2 = hq[2], q3 = hq[3], q4 = hq[4], q5 = hq[5], q6 = hq[6];
     h.len = (u32)q0.x; h.node = (u32)(q0.x >> 32); h.type = (u32)q0.y; h.pad = 0;
     h.avail0.cpu = (i64)q1.x; h.avail0.mem = q1.y; h.avail0.clo = q2.x; h.avail0.chi = q2.y; h.avail0.gres = q3.x;
     h.total.cpu = (i64)q4.y; h.total.mem = q5.x; h.total.clo = q5.y; h.total.chi = q6.x; h.total.gres = q6.y;
     h.avail0.c2 = 0; h.avail0.c3 = 0; h.total.c2 = 0; h.total.c3 = 0;
-    const TlMem v = tl_of<false>(P, hd).m[lane];
-    e.t = v.t; e.r.cpu = v.cpu; e.r.mem = v.mem; e.r.clo = v.clo; e.r.chi = v.chi; e.r.gres = v.gres; e.r.c2 = 0; e.r.c3 = 0;
+    const u64x2 v0 = vq[0], v1 = vq[1], v2 = vq[2];
+    e.t = (i64)v0.x; e.r.cpu = (i64)v0.y; e.r.mem = v1.x; e.r.clo = v1.y; e.r.chi = v2.x; e.r.gres = v2.y; e.r.c2 = 0; e.r.c3 = 0;
   }
   h.len = uni32(h.len); h.node = uni32(h.node); h.type = uni32(h.type);
   h.avail0 = uni_res(h.avail0); h.total = uni_res(h.total);
@@ -1325,16 +1342,20 @@ __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, No
 // holds less.  The first such entry that by itself cannot host the job (cpu, memory, GRES counts) becomes the slot's dip
 // (KParams::dip_*): when the scanners reload their tile they stop proposing the node to jobs whose windows reach it.  Written
 // where the misprediction is found — nothing on the path of a prediction that holds.  Register maps (<= 64 entries) only.
-__device__ __forceinline__ void record_dip(const KParams& P, u32 q, const TlEntry& e, u32 len, const Req& mv, i64 E, u32 lane) {
+// (G: the GRES layout — P.gres, or the caller's own copy of it when P is a scalar copy of the block: kparams_scalar)
+__device__ __forceinline__ void record_dip(const KParams& P, const GresDev& G, u32 q, const TlEntry& e, u32 len, const Req& mv, i64 E, u32 lane) {
   if (len > 64) return;
   const bool cand = lane >= 1 && lane < len && e.t < E && e.t - P.now < 0xFFFFFFFFll &&
-                    !feasible_counts(mv, e.r.cpu, e.r.mem, 0u, class_counts(e.r.gres, P.gres), P.gres);
+                    !feasible_counts(mv, e.r.cpu, e.r.mem, 0u, class_counts(e.r.gres, G), G);
   const u64 b = __ballot(cand);
   if (!b) return;
   const u32 i = (u32)__builtin_ctzll(b);
   const Res r = rl_res(e.r, i);
   const i64 t = (i64)rl64((u64)e.t, i);
-  if (lane == 0) { P.dip_t[q] = (u32)(t - P.now); P.dip_cm[q] = dip_cm_of(r); P.dip_g[q] = nibbles_of(class_counts(r.gres, P.gres)); }
+  if (lane == 0) { P.dip_t[q] = (u32)(t - P.now); P.dip_cm[q] = dip_cm_of(r); P.dip_g[q] = nibbles_of(class_counts(r.gres, G)); }
+}
+__device__ __forceinline__ void record_dip(const KParams& P, u32 q, const TlEntry& e, u32 len, const Req& mv, i64 E, u32 lane) {
+  record_dip(P, P.gres, q, e, len, mv, E, lane);
 }
 
 // Commit pick i of a multi-node selection (time map, cost, owner update i); H[i].res = its allocation.

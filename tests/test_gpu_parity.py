@@ -128,6 +128,7 @@ def test_wide_protocol_fault_is_retried_on_the_single_workgroup_kernels(built, m
     from cranesched_amd.engine import GpuNodeSelector
     from oracle import pyoracle
     monkeypatch.setenv("CNS_SELECT_KERNEL", "wide")
+    monkeypatch.setenv("CNS_WIDE_NO_RETRY", "0")   # (conftest turns the retry off for every other test)
     c, j, now = synth.make_config("C4", J=6000, N=1024, P=8)
     ref = pyoracle.select(c, j, now)
     eng = GpuNodeSelector(device=0)

@@ -1,13 +1,9 @@
+#!/bin/bash
+# A/B on ONE box: tools/gpu_ab_widen.sh "<configs>" <lib>... — k_wide runs (no retry on a fault) with the always-on protocol counters
 export TMPDIR=/tmp
-for cfg in C4 C5 C2; do
-for lib in build_var/v_base.so cranesched_amd/libcrane_gpu_nodeselect.so; do
+cfgs=$1; shift
+for cfg in $cfgs; do
+for lib in "$@"; do
   echo "== $cfg wide $lib"
-  CNS_SELECT_KERNEL=wide CNS_ENGINE_LIB=$lib timeout 120 python tools/prof_wide.py $cfg 2>&1 | head -2
+  CNS_WIDE_NO_RETRY=1 CNS_SELECT_KERNEL=wide CNS_ENGINE_LIB=$lib timeout 200 python tools/prof_wide.py $cfg 2>&1 | grep -v amdgpu.ids | grep "us/job\|always-on\|rror" | cut -c1-330
 done; done
-for k in pipe legacy; do
-for lib in build_var/v_base.so cranesched_amd/libcrane_gpu_nodeselect.so; do
-  echo "== C4 $k $lib"
-  CNS_SELECT_KERNEL=$k CNS_ENGINE_LIB=$lib timeout 120 python tools/prof_wide.py C4 2>&1 | head -1
-done; done
-echo "== parity"
-timeout 500 python -m pytest tests/test_gpu_fullrun.py -q -m gpu -x -k "c4 or c2 or tile" 2>&1 | tail -3
