@@ -230,6 +230,7 @@ def main():
                        "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else
                                    (("single GPU, 1 + 16 workgroups per partition (k_wide, 64 scanner waves)" if kernel.endswith("x64") else "single GPU, 1 + 8 workgroups per partition (k_wide)") if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
                        "selection_kernel": kernel,
+                       "served_by_retry": "retry after" in kernel,   # (cns_run_resident re-runs a cycle on k_pipe / k_select after a k_wide protocol fault: such a line is not a k_wide number)
                        "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),
                                          "resource": int((r == 2).sum())},
                        "kernel_ms": {kernel: avg_sel_ms, "k_init_nodes+k_prep_jobs+fill": float(np.mean(init_ms))},
