@@ -42,6 +42,15 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def _wide_shape(kernel: str) -> str:
+    """'k_wide<2> x64' -> the workgroup shape of that build (scanner waves / 4 scanner workgroups + the home workgroup)."""
+    try:
+        waves = int(kernel.split(" + ")[0].rsplit(" x", 1)[1].split()[0])
+    except (IndexError, ValueError):
+        return "single GPU, k_wide"
+    return f"single GPU, 1 + {waves // 4} workgroups per partition (k_wide, {waves} scanner waves)"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -228,7 +237,7 @@ def main():
                                    (f"; loaded cluster: {len(running.end_sec)} running jobs, {len(running.alloc_node)} allocations (synth.make_running)" if running is not None else ""),
                        "jobs": jobs.num_jobs, "nodes": cluster.num_nodes, "partitions": cluster.num_partitions,
                        "sharding": "partition p -> rank p % n_gpus; RCCL all-gather of packed placements" if world > 1 else
-                                   (("single GPU, 1 + 16 workgroups per partition (k_wide, 64 scanner waves)" if kernel.endswith("x64") else "single GPU, 1 + 8 workgroups per partition (k_wide)") if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
+                                   (_wide_shape(kernel) if kernel.startswith("k_wide") else "single GPU, one workgroup per partition"),
                        "selection_kernel": kernel,
                        "served_by_retry": "retry after" in kernel,   # (cns_run_resident re-runs a cycle on k_pipe / k_select after a k_wide protocol fault: such a line is not a k_wide number)
                        "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),

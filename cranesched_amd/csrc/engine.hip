@@ -296,7 +296,7 @@ int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string
   const KParams* dparams = L.dparams;
   void* args[2] = {(void*)&K2, (void*)&dparams};
   if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, L.stream) != hipSuccess) return 1;
-  *name = std::string(kname) + (W::waves == 64 ? " x64" : " x32");   // (x64: cns::w64::k_wide in a profile, x32: cns::w32::k_wide)
+  *name = std::string(kname) + " x" + std::to_string(W::waves);   // (x64: cns::w64::k_wide in a profile, x32: cns::w32::k_wide, ...)
   return 0;
 }
 // Which selection kernel runs: k_pipe (decoupled test / commit pipeline) for partitions its tile covers, k_select
@@ -308,28 +308,35 @@ int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string
 #define CNS_DEFAULT_WIDE 1
 #endif
 // k_wide (many CUs per partition) when every workgroup of the launch can be resident at once and the partitions fit its tile:
-// 64 scanner waves per partition (17 workgroups) for up to 8 partitions, 32 (9 workgroups) for up to 24.  Returns 0 / 32 / 64.
-// CNS_SELECT_KERNEL=wide32 forces the 32-wave build (A/B measurements, and the parity tests run both).
+// 64 scanner waves per partition (17 workgroups) for up to 8 partitions, 32 (9 workgroups) for up to 24, 16 (5) for up to 48,
+// 8 (3) for up to 80 — the widest build that fits.  Returns 0 / 8 / 16 / 32 / 64.
+// CNS_SELECT_KERNEL=wide32 | wide16 | wide8 caps the build (A/B measurements, and the parity tests run them).
 // (for a launch over partitions that neither share nodes nor run with preemption: the others go to k_select)
 u32 use_wide_kernel(const cns_engine* h, const LaunchCtx& L) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_WIDE != 0;
   if (e && (!strcmp(e, "legacy") || !strcmp(e, "pipe"))) want = false;
-  const bool only32 = e && !strcmp(e, "wide32");
-  if (e && (!strcmp(e, "wide") || only32)) want = true;
+  u32 cap = 64;
+  if (e && !strcmp(e, "wide32")) cap = 32;
+  if (e && !strcmp(e, "wide16")) cap = 16;
+  if (e && !strcmp(e, "wide8")) cap = 8;
+  if (e && (!strcmp(e, "wide") || cap != 64)) want = true;
   if (!want || h->wide_off) return 0;
   // every workgroup of the launch must be resident at once, one per CU (a partitioned or smaller device falls to k_pipe)
   const u32 groups = (L.nparts + 7u) / 8u;
   auto fits = [&](u32 wgs_per_part) { return h->num_cus != 0 && 8u * groups * wgs_per_part + L.other_blocks <= h->num_cus; };   // (unknown CU count: no proof of co-residency, no k_wide)
-  if (!only32 && L.nparts <= w64::WideInfo::max_parts && L.max_np <= w64::WideInfo::lanes * w64::WideInfo::npl_max && fits(w64::WideInfo::group)) return 64;
-  if (L.nparts <= w32::WideInfo::max_parts && L.max_np <= w32::WideInfo::lanes * w32::WideInfo::npl_max && fits(w32::WideInfo::group)) return 32;
+  auto serves = [&](u32 waves, u32 max_parts, u32 slots, u32 group) { return cap >= waves && L.nparts <= max_parts && L.max_np <= slots && fits(group); };
+  if (serves(64, w64::WideInfo::max_parts, w64::WideInfo::lanes * w64::WideInfo::npl_max, w64::WideInfo::group)) return 64;
+  if (serves(32, w32::WideInfo::max_parts, w32::WideInfo::lanes * w32::WideInfo::npl_max, w32::WideInfo::group)) return 32;
+  if (serves(16, w16::WideInfo::max_parts, w16::WideInfo::lanes * w16::WideInfo::npl_max, w16::WideInfo::group)) return 16;
+  if (serves(8, w8::WideInfo::max_parts, w8::WideInfo::lanes * w8::WideInfo::npl_max, w8::WideInfo::group)) return 8;
   return 0;
 }
 bool use_pipe_kernel(const cns_engine* h, const LaunchCtx& L) {
   const char* e = getenv("CNS_SELECT_KERNEL");
   bool want = CNS_DEFAULT_PIPE != 0;
   if (e && !strcmp(e, "legacy")) want = false;
-  if (e && (!strcmp(e, "pipe") || !strcmp(e, "wide") || !strcmp(e, "wide32"))) want = true;
+  if (e && (!strcmp(e, "pipe") || !strncmp(e, "wide", 4))) want = true;
   return want && L.max_np <= kPScan * (u32)kPNplMax;
 }
 // One launch: k_wide / k_pipe where the partitions allow it (`plain`: none of them shares nodes or runs with preemption), else
@@ -344,7 +351,8 @@ int launch_one(cns_engine* h, const KParams& K, const LaunchCtx& L, bool plain, 
 #else
   bool launched = false;
   if (const u32 ww = plain ? use_wide_kernel(h, L) : 0u) {
-    const int rc = ww == 64 ? launch_wide<w64::WideInfo>(h, K, L, name) : launch_wide<w32::WideInfo>(h, K, L, name);
+    const int rc = ww == 64 ? launch_wide<w64::WideInfo>(h, K, L, name) : ww == 32 ? launch_wide<w32::WideInfo>(h, K, L, name)
+                 : ww == 16 ? launch_wide<w16::WideInfo>(h, K, L, name) : launch_wide<w8::WideInfo>(h, K, L, name);
     if (rc == 1) { *err = "k_wide: control block allocation / upload / launch failed"; return CNS_ERR_HIP; }
     launched = rc == 0;
   }

@@ -2566,23 +2566,37 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
 }
 
 #include "pipe_kernel.inc"
-// k_wide in two builds: 8 scanner workgroups (32 scanner waves, up to 24 partitions) and 16 (64 waves, up to 8 partitions)
+// k_wide in four builds — scanner workgroups per partition / scanner waves / partitions of one launch it serves (every workgroup of
+// the launch must be resident at once, the workgroups of a partition on one XCD): 16 / 64 / up to 8, 8 / 32 / up to 24,
+// 4 / 16 / up to 48, 2 / 8 / up to 80.  The engine takes the widest one that fits the cluster (engine.hip: use_wide_kernel).
 #ifndef CNS_WIDE_WGS
-#define CNS_WIDE_WGS_BOTH
+#define CNS_WIDE_WGS_ALL
 #define CNS_WIDE_WGS 8
 #endif
 namespace w32 {
 #include "wide_kernel.inc"
 }
-#ifdef CNS_WIDE_WGS_BOTH
+#ifdef CNS_WIDE_WGS_ALL
 #undef CNS_WIDE_WGS
 #define CNS_WIDE_WGS 16
 namespace w64 {
 #include "wide_kernel.inc"
 }
 #undef CNS_WIDE_WGS
+#define CNS_WIDE_WGS 4
+namespace w16 {
+#include "wide_kernel.inc"
+}
+#undef CNS_WIDE_WGS
+#define CNS_WIDE_WGS 2
+namespace w8 {
+#include "wide_kernel.inc"
+}
+#undef CNS_WIDE_WGS
 #else
 namespace w64 = w32;   // experiment builds with one explicit shape
+namespace w16 = w32;
+namespace w8 = w32;
 #endif
 
 #ifdef CNS_ONLY_NPL   // experiment builds: one tile width only

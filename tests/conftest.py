@@ -41,6 +41,19 @@ def engine_cls(built, request, monkeypatch):
     return GpuNodeSelector
 
 
+@pytest.fixture(params=["wide16", "wide8"])
+def engine_cls_narrow(built, request, monkeypatch):
+    """k_wide's builds for clusters of MANY partitions: 16 scanner waves on 4 workgroups (25..48 partitions) and 8 scanner waves on
+    2 workgroups (49..80) next to the home workgroup.  CNS_SELECT_KERNEL=wide16 / wide8 caps the build, so that small test clusters
+    run on them too (tests/test_gpu_wide_narrow.py: a cross-section of the suite, not all of it again)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    monkeypatch.setenv("CNS_SELECT_KERNEL", request.param)
+    from cranesched_amd.engine import GpuNodeSelector
+    return GpuNodeSelector
+
+
 @pytest.fixture
 def engine_default(built):
     """The engine class on its default selection kernel: for the kernels that never read CNS_SELECT_KERNEL (run limits,

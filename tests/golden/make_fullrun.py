@@ -102,6 +102,9 @@ CASES = {
     "c4all": ("C4all", None, None, None), "c4rp": ("C4rp", None, None, None),
     # C4 with 8 active and 8 future reservations (24 schedulers: k_wide's nine-workgroup build)
     "c4v": ("C4v", None, None, None),
+    # C4's cluster and mix cut into 64 partitions of 1 024 nodes (the configuration on which more GPUs add chains): on one
+    # GPU the three-workgroup build of k_wide (8 scanner waves per partition), k_pipe under CNS_SELECT_KERNEL=pipe
+    "c4p64": ("C4p64", None, None, None),
 }
 
 

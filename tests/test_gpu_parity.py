@@ -40,8 +40,8 @@ def test_scaled_configs(engine_cls, name, J, N, P):
 
 @pytest.mark.parametrize("P", [8, 9, 20, 24, 25])
 def test_many_partitions(engine_cls, P):
-    """k_wide lays 17 (up to 8 partitions) or 9 (up to 24) workgroups per partition out over the XCDs in groups of 8 partitions
-    (beyond 24 the launch falls back to k_pipe): the edges of that layout, against the oracle."""
+    """k_wide lays 17 (up to 8 partitions), 9 (up to 24), 5 (up to 48) or 3 (up to 80) workgroups per partition out over the XCDs in
+    groups of 8 partitions: the edges of that layout, against the oracle (more of them: tests/test_gpu_wide_narrow.py)."""
     c, j, now = synth.make_config("C4", J=24000, N=128 * P, P=P)
     got, t = _run(engine_cls, c, j, now, tag=f"C4 with {P} partitions")
     assert (got.reason[:j.num_jobs] == 1).sum() > 0, "scenario must exercise backfill"
