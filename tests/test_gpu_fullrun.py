@@ -22,6 +22,9 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
     if tag == "c3" and not os.path.exists(path):   # one 1 M-job chain on 16 k nodes: hours of oracle time on one core
         pytest.skip(f"{path} not generated (python tests/golden/make_fullrun.py c3)")
     assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
+    if tag == "c4rp" and os.environ.get("CNS_SELECT_KERNEL") in ("pipe", "wide32"):
+        pytest.skip("the preempting partition runs on k_select's general path under every setting (25 s each): legacy and wide cover "
+                    "the two shapes of the cycle (one launch / split), the other partitions are C4r's")
     ref = dict(np.load(path))
     name, J, N, P = CASES[tag]
     cluster, jobs, now, running, pre = load_case5(name, J, N, P)
