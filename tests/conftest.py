@@ -32,7 +32,7 @@ def built():
 def engine_cls(built, request, monkeypatch):
     """The engine class, once per selection kernel: k_select (one worker wave carries test + commit), k_pipe
     (decoupled test / commit pipeline on one CU) and k_wide (k_pipe's protocol with the scanners of a partition spread over
-    16 more workgroups — "wide32": 8, the build that serves 9..24 partitions —, exchange through HBM granules; clusters it does not cover fall back to k_pipe / k_select).  The library reads CNS_SELECT_KERNEL at every run."""
+    16 more workgroups — "wide32": 8, the build that serves 9..24 partitions; the 4- and 2-workgroup builds for 25..80 partitions: engine_cls_narrow —, exchange through HBM granules; clusters it does not cover fall back to k_pipe / k_select).  The library reads CNS_SELECT_KERNEL at every run."""
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
