@@ -40,7 +40,6 @@ if m[0]:
 ws = e.wide_stats()
 print(f"  always-on counters (every build): {ws}; jobs per consuming look {j.num_jobs/max(ws['looks_consumed'],1):.2f}; "
       f"leader polls in front of a full ring per job {ws['leader_polls_ring_full']/j.num_jobs:.2f}")
-print(f"  leader: jobs through the fast run {m[30]:.0f} of {jobs:.0f} per partition")
 print(f"  leader polls {m[13]:.0f} ({m[13]/max(m[20],1):.2f} per job)")
 print(f"  leader jobs {m[20]:.0f}; supervisor: consumed {m[24]:.0f}, empty polls {m[27]:.0f}, stops {m[25]:.0f}, flushes {m[29]:.0f}")
 if m[15]:
