@@ -220,9 +220,24 @@ def main():
                 w0 = time.perf_counter()
                 eng.node_select(now, my_jobs)
                 walls.append(time.perf_counter() - w0)
-            incl = {"decisions_per_s": total_jobs / float(np.median(walls)), "ms_per_cycle": 1e3 * float(np.median(walls)),
-                    "what": "whole cns_select from host buffers: H2D job arrays + k_pack_jobs + k_prep_jobs + k_init_nodes + "
-                            "selection kernel + D2H placements (SURVEY 8d bracket), median of 5"}
+            # ... and the same call with the caller's job table and result arrays in page-locked memory (cns_host_alloc), result
+            # arrays reused across cycles: what an adapter that packs into such buffers sees (DMA straight from / to them; a fresh
+            # pageable result array costs a page fault per 4 KB on top of the runtime's staging copies)
+            pj, pout = eng.pinned_jobs(my_jobs), eng.pinned_placements(my_jobs)
+            eng.node_select(now, pj, out=pout)
+            assert got.diff(pout) is None, "page-locked buffers: result differs"
+            pwalls = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                w0 = time.perf_counter()
+                eng.node_select(now, pj, out=pout)
+                pwalls.append(time.perf_counter() - w0)
+            incl = {"decisions_per_s": total_jobs / float(np.median(pwalls)), "ms_per_cycle": 1e3 * float(np.median(pwalls)),
+                    "what": "whole cns_select from the caller's host buffers: H2D job arrays + k_pack_jobs + k_prep_jobs + k_init_nodes + "
+                            "selection kernel + D2H placements (SURVEY 8d bracket), median of 5; buffers page-locked (cns_host_alloc) and "
+                            "reused across cycles",
+                    "pageable_fresh_buffers": {"decisions_per_s": total_jobs / float(np.median(walls)), "ms_per_cycle": 1e3 * float(np.median(walls)),
+                                               "what": "the same call from pageable numpy arrays, result arrays allocated per call"}}
         r = got.reason[:my_jobs.num_jobs]
         line = {
             "metric": "scheduling decisions/sec at 1M pending x 64k nodes",

@@ -332,21 +332,24 @@ class Jobs:
 class Placements:
     """Caller-allocated result arrays (cns_placement_soa)."""
 
-    def __init__(self, num_jobs: int, capacity: int):
+    def __init__(self, num_jobs: int, capacity: int, alloc=None):
+        """alloc(n, dtype, fill) -> array: where the arrays live (default: numpy; GpuNodeSelector.pinned: page-locked memory)."""
         self.num_jobs, self.capacity = num_jobs, capacity
         cap = max(capacity, 1)
-        self.start_sec = np.zeros(max(num_jobs, 1), np.int64)
-        self.reason = np.zeros(max(num_jobs, 1), np.uint8)
-        self.place_offsets = np.zeros(num_jobs + 1, np.uint64)
-        self.node_idx = np.full(cap, NODE_NONE, np.uint32)
-        self.ntasks = np.zeros(cap, np.uint32)
-        self.cpu_raw = np.zeros(cap, np.int64)
-        self.mem = np.zeros(cap, np.uint64)
-        self.core_lo = np.zeros(cap, np.uint64)
-        self.core_hi = np.zeros(cap, np.uint64)
-        self.gres = np.zeros(cap, np.uint64)
-        self.core_w2 = np.zeros(cap, np.uint64)
-        self.core_w3 = np.zeros(cap, np.uint64)
+        if alloc is None:
+            alloc = lambda n, dt, fill=0: np.full(n, fill, dt) if fill else np.zeros(n, dt)
+        self.start_sec = alloc(max(num_jobs, 1), np.int64, 0)
+        self.reason = alloc(max(num_jobs, 1), np.uint8, 0)
+        self.place_offsets = alloc(num_jobs + 1, np.uint64, 0)
+        self.node_idx = alloc(cap, np.uint32, NODE_NONE)
+        self.ntasks = alloc(cap, np.uint32, 0)
+        self.cpu_raw = alloc(cap, np.int64, 0)
+        self.mem = alloc(cap, np.uint64, 0)
+        self.core_lo = alloc(cap, np.uint64, 0)
+        self.core_hi = alloc(cap, np.uint64, 0)
+        self.gres = alloc(cap, np.uint64, 0)
+        self.core_w2 = alloc(cap, np.uint64, 0)
+        self.core_w3 = alloc(cap, np.uint64, 0)
 
     def to_c(self) -> CnsPlacementSoa:
         s = CnsPlacementSoa()

@@ -123,6 +123,7 @@ struct cns_engine {
   u32 R = 0;                                    // running jobs of the last cns_set_running
   std::vector<u32> ent_job, ent_slot;           // slot-grouped allocation entry d -> running job, slot
   std::vector<i64> ent_end;                     // ... -> end time as handed in
+  std::vector<void*> host_bufs;                 // page-locked host buffers handed out by cns_host_alloc
   bool pre_active = false;                      // the next run is a cycle with preemption (general path of k_select only)
   PreParams pre_params{};
   DevBuf d_pre[24];
@@ -520,6 +521,8 @@ void cns_destroy(cns_handle* h) {
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
   for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last}) b->release();
+  for (void* p : h->host_bufs) (void)hipHostFree(p);   // cns_host_alloc
+  h->host_bufs.clear();
   for (DevBuf& b : h->d_prio) b.release();
   for (DevBuf& b : h->d_lim) b.release();
   for (DevBuf& b : h->d_raw) b.release();
@@ -1104,6 +1107,28 @@ int cns_download(cns_handle* h, cns_placement_soa* out) {
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
   h->timing.d2h_ms = ms;
+  return CNS_OK;
+}
+
+int cns_host_alloc(cns_handle* h, uint64_t bytes, void** out) {
+  if (!h || !out) return fail(h, CNS_ERR_INVALID_ARG, "cns_host_alloc: null argument");
+  *out = nullptr;
+  HIPCHK(h, hipSetDevice(h->device));
+  void* p = nullptr;
+  HIPCHK(h, hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
+  h->host_bufs.push_back(p);
+  *out = p;
+  return CNS_OK;
+}
+
+int cns_host_free(cns_handle* h, void* p) {
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_host_free: null handle");
+  if (!p) return CNS_OK;
+  auto it = std::find(h->host_bufs.begin(), h->host_bufs.end(), p);
+  if (it == h->host_bufs.end()) return fail(h, CNS_ERR_INVALID_ARG, "cns_host_free: not a buffer of cns_host_alloc on this handle");
+  h->host_bufs.erase(it);
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipHostFree(p));
   return CNS_OK;
 }
 

@@ -26,7 +26,7 @@ _LIB = None
 # every symbol include/crane_gpu/node_select.h declares
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
                "cns_set_reservations", "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
-               "cns_device_results", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
+               "cns_device_results", "cns_host_alloc", "cns_host_free", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
                "cns_debug_last_kernel", "cns_debug_get_prof")
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
@@ -80,6 +80,7 @@ class GpuNodeSelector:
             raise EngineError(rc, msg.decode() if msg else "")
         self._cluster = None
         self._jobs = None
+        self._pinned = []   # arrays over cns_host_alloc buffers (cns_destroy releases the memory: do not touch them after close())
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -165,6 +166,7 @@ class GpuNodeSelector:
         if self._h:
             self._L.cns_destroy(self._h)
             self._h = C.c_void_p()
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -194,13 +196,45 @@ class GpuNodeSelector:
             self._check(self._L.cns_set_running(self._h, C.byref(r)))
 
     # -- NodeSelect --------------------------------------------------------------------------------
-    def node_select(self, now: int, jobs: abi.Jobs) -> abi.Placements:
-        """SchedulerAlgo::NodeSelect(now, running_jobs, pending_jobs) in one call."""
-        out = abi.Placements(jobs.num_jobs, jobs.total_places())
+    def node_select(self, now: int, jobs: abi.Jobs, out: "abi.Placements | None" = None) -> abi.Placements:
+        """SchedulerAlgo::NodeSelect(now, running_jobs, pending_jobs) in one call (`out`: result arrays to reuse)."""
+        if out is None:
+            out = abi.Placements(jobs.num_jobs, jobs.total_places())
+        assert out.num_jobs == jobs.num_jobs and out.capacity >= jobs.total_places()
         cj, co = jobs.to_c(), out.to_c()
         self._check(self._L.cns_select(self._h, C.c_int64(now), C.byref(cj), C.byref(co)))
         self._jobs = jobs
         return out
+
+    # page-locked host buffers (cns_host_alloc): the caller's job table and result arrays at full PCIe rate
+    def pinned(self, n: int, dtype, fill=None) -> np.ndarray:
+        """A numpy array of n elements in page-locked host memory of this handle (released by close())."""
+        dt = np.dtype(dtype)
+        p = C.c_void_p()
+        self._check(self._L.cns_host_alloc(self._h, C.c_uint64(max(n, 1) * dt.itemsize), C.byref(p)))
+        a = np.frombuffer((C.c_char * (max(n, 1) * dt.itemsize)).from_address(p.value), dtype=dt)
+        self._pinned.append(a)
+        if fill is not None:
+            a[:] = fill
+        return a
+
+    def pinned_jobs(self, jobs: abi.Jobs) -> abi.Jobs:
+        """The same job table with every array in page-locked memory (what an adapter that packs into such buffers hands over)."""
+        import dataclasses
+        kw = {}
+        for f in dataclasses.fields(jobs):
+            v = getattr(jobs, f.name)
+            if v is None:
+                kw[f.name] = None
+                continue
+            a = self.pinned(v.size, v.dtype)
+            a[:v.size] = v.reshape(-1)
+            kw[f.name] = a[:v.size].reshape(v.shape)
+        return abi.Jobs(**kw)
+
+    def pinned_placements(self, jobs: abi.Jobs) -> abi.Placements:
+        """Result arrays in page-locked memory, to be reused across cycles: node_select(now, jobs, out=...)."""
+        return abi.Placements(jobs.num_jobs, jobs.total_places(), alloc=self.pinned)
 
     # split form: inputs resident in HBM before the timed region (bench.py)
     def node_select_preempt(self, now: int, jobs: abi.Jobs, preempt: "abi.Preempt"):

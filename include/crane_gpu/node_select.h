@@ -250,6 +250,14 @@ int cns_download(cns_handle* h, cns_placement_soa* out);
 /* Device pointer + byte size of the packed placement buffer of the last run (for RCCL allgather). */
 int cns_device_results(cns_handle* h, void** dptr, uint64_t* bytes);
 
+/* Page-locked host memory for the caller's job arrays and result arrays (optional).  Every host buffer stays the caller's
+ * (ownership); buffers from here are copied by the DMA engines directly — pageable memory goes through the
+ * runtime's staging buffers at a third of the rate, and a freshly allocated result array pays a page fault per 4 KB on its
+ * first download.  Keep them across cycles (the adapter packs the job table into them; JobScheduler.cpp:1439-1447 is the
+ * bracket they shorten).  cns_host_free, or cns_destroy, releases them. */
+int cns_host_alloc(cns_handle* h, uint64_t bytes, void** out);
+int cns_host_free(cns_handle* h, void* p);
+
 int cns_get_timing(const cns_handle* h, cns_timing* t);
 
 /* Parity / debugging: final per-node cost (fp64 bit patterns) and time-availability map. */

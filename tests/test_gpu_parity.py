@@ -148,3 +148,29 @@ def test_wide_protocol_fault_is_retried_on_the_single_workgroup_kernels(built, m
         helpers.assert_same(eng, got, ref, c, tag="after the stall")
     finally:
         eng.close()
+
+
+def test_page_locked_caller_buffers(built, monkeypatch):
+    """cns_host_alloc: the caller's job table and result arrays in page-locked memory (reused across cycles) — same results as from
+    pageable numpy arrays, the arrays really are the handed-out buffers, cns_host_free rejects foreign pointers."""
+    import ctypes as C
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from cranesched_amd.engine import GpuNodeSelector, EngineError
+    c, j, now = synth.make_config("C4", J=20000, N=2048, P=8)
+    eng = GpuNodeSelector(device=0)
+    try:
+        eng.set_nodes(c)
+        ref = eng.node_select(now, j)
+        pj, pout = eng.pinned_jobs(j), eng.pinned_placements(j)
+        bases = {a.ctypes.data: a.nbytes for a in eng._pinned}
+        inside = lambda a: any(b <= a.ctypes.data and a.ctypes.data + a.nbytes <= b + n for b, n in bases.items())
+        assert inside(pj.partition) and inside(pj.gres_spec) and inside(pout.start_sec) and inside(pout.node_idx)
+        for _ in range(2):   # reused across cycles
+            got = eng.node_select(now, pj, out=pout)
+            assert got is pout and ref.diff(pout) is None
+        with pytest.raises(EngineError):
+            eng._check(eng._L.cns_host_free(eng._h, C.c_void_p(ref.start_sec.ctypes.data)))
+    finally:
+        eng.close()
