@@ -19,6 +19,41 @@ namespace crane {
 
 namespace {
 const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", "", "Reservation Not Found", "Preempted"};
+
+// Page-locked storage (cns_host_alloc) for the arrays that cross the C ABI every cycle — the packed job table and the packed
+// placements: kept across cycles (no page faults on a fresh array, no reallocation once they have grown to the queue's size) and
+// copied by the DMA engines directly.  Each block carries its owner in a 64-byte header: without an engine (host-only benches, a
+// failed cns_create) it is plain malloc memory.
+struct PinCtx { cns_handle* h = nullptr; };
+template <class T>
+struct PinAlloc {
+  using value_type = T;
+  using propagate_on_container_move_assignment = std::true_type;   // `v = PinVec<T>()` hands v's block back at once (the destructor relies on it)
+  using propagate_on_container_swap = std::true_type;
+  PinCtx* ctx = nullptr;
+  PinAlloc() = default;
+  explicit PinAlloc(PinCtx* c) : ctx(c) {}
+  template <class U> PinAlloc(const PinAlloc<U>& o) : ctx(o.ctx) {}
+  T* allocate(size_t n) {
+    const size_t bytes = n * sizeof(T) + 64;
+    void* base = nullptr;
+    cns_handle* owner = nullptr;
+    if (ctx && ctx->h && cns_host_alloc(ctx->h, bytes, &base) == 0 && base) owner = ctx->h;
+    else base = std::malloc(bytes);
+    if (!base) throw std::bad_alloc();
+    *reinterpret_cast<cns_handle**>(base) = owner;
+    return reinterpret_cast<T*>(static_cast<char*>(base) + 64);
+  }
+  void deallocate(T* p, size_t) noexcept {
+    char* base = reinterpret_cast<char*>(p) - 64;
+    cns_handle* owner = *reinterpret_cast<cns_handle**>(base);
+    if (owner) (void)cns_host_free(owner, base);
+    else std::free(base);
+  }
+  template <class U> bool operator==(const PinAlloc<U>& o) const { return ctx == o.ctx; }
+  template <class U> bool operator!=(const PinAlloc<U>& o) const { return ctx != o.ctx; }
+};
+template <class T> using PinVec = std::vector<T, PinAlloc<T>>;
 }
 
 struct GpuNodeSelectionAlgo::Impl {
@@ -107,12 +142,20 @@ struct GpuNodeSelectionAlgo::Impl {
   // objects owned by another thread's malloc arena) and left the packing unchanged, so both loops are plain loops.
   template <class F>
   static void parallel_for(size_t n, F&& body) { body((size_t)0, n); }
+  PinCtx pin;   // (pin.h = h once the engine exists)
   struct PackedJobs {
-    std::vector<uint32_t> part, k, nt, tmin, tmax, inodes, enodes, jresv;
-    std::vector<int64_t> L, ncpu, tcpu;
-    std::vector<uint64_t> nmem, tmem, ioff, eoff;
-    std::vector<uint8_t> excl, skip, gtot, gspec;
+    PinVec<uint32_t> part, k, nt, tmin, tmax, inodes, enodes, jresv;
+    PinVec<int64_t> L, ncpu, tcpu;
+    PinVec<uint64_t> nmem, tmem, ioff, eoff;
+    PinVec<uint8_t> excl, skip, gtot, gspec;
+    explicit PackedJobs(PinCtx* c = nullptr)
+        : part(PinAlloc<uint32_t>(c)), k(PinAlloc<uint32_t>(c)), nt(PinAlloc<uint32_t>(c)), tmin(PinAlloc<uint32_t>(c)), tmax(PinAlloc<uint32_t>(c)),
+          inodes(PinAlloc<uint32_t>(c)), enodes(PinAlloc<uint32_t>(c)), jresv(PinAlloc<uint32_t>(c)), L(PinAlloc<int64_t>(c)), ncpu(PinAlloc<int64_t>(c)),
+          tcpu(PinAlloc<int64_t>(c)), nmem(PinAlloc<uint64_t>(c)), tmem(PinAlloc<uint64_t>(c)), ioff(PinAlloc<uint64_t>(c)), eoff(PinAlloc<uint64_t>(c)),
+          excl(PinAlloc<uint8_t>(c)), skip(PinAlloc<uint8_t>(c)), gtot(PinAlloc<uint8_t>(c)), gspec(PinAlloc<uint8_t>(c)) {}
   };
+  PackedJobs packed{&pin};   // the job table of the cycle: page-locked, reused
+  double t_pack_ms = 0, t_engine_ms = 0, t_write_ms = 0;   // the last NodeSelect: pack | cns_select (H2D + kernels + D2H) | write-back
   void pack_pending(const std::vector<PdJobInScheduler*>& ord, PackedJobs& B) const {
     const size_t J = ord.size();
     B.part.assign(J, 0); B.k.assign(J, 0); B.nt.assign(J, 0); B.tmin.assign(J, 0); B.tmax.assign(J, 0);
@@ -167,6 +210,10 @@ struct GpuNodeSelectionAlgo::Impl {
   // nothing but that reason, start_time and priority (JobScheduler.cpp:1503-1510) — its node list and ResourceInNodeV3
   // objects are not materialised (3.3 us per job at 1 M jobs: more than half a GPU cycle, profiles/r01_host_pack_bench.txt)
   bool lazy_write_back = true;
+  // ... deferred: a job that starts now gets reason, start / end time and craned_ids — what the commit loop reads before the
+  // run-limit admission (:1503-1573) —, its craned_id_to_task_num / allocated_res when the caller asks (MaterializeAllocation: the
+  // jobs it launches, :1590-1600).  A 1 M-job cycle admits a third of what it starts (C4's limits), the product orders 100 k per cycle.
+  bool deferred_write_back = false;
   void write_back(const std::vector<PdJobInScheduler*>& ord, const cns_placement_soa& o) const {
     parallel_for(ord.size(), [&](size_t a, size_t b) {
       for (size_t j = a; j < b; ++j) {
@@ -183,6 +230,7 @@ struct GpuNodeSelectionAlgo::Impl {
           if (o.node_idx[q] == CNS_NODE_NONE) continue;
           const CranedId& cid = node_name[o.node_idx[q]];
           p.craned_ids.push_back(cid);
+          if (deferred_write_back) continue;
           p.craned_id_to_task_num[cid] = o.ntasks[q];
           ResourceInNodeV3& res = p.allocated_res[cid];   // built in place (the map was cleared above)
           fill_res(res, o.cpu_raw[q], o.mem[q], o.core_lo[q], o.core_hi[q], o.gres[q], o.core_w2 ? o.core_w2[q] : 0, o.core_w3 ? o.core_w3[q] : 0);
@@ -362,12 +410,18 @@ struct GpuNodeSelectionAlgo::Impl {
 
   // ---- the last cycle's packed placements, kept for the wire emission ---------------------------------------------
   struct PlacementStore {
-    std::vector<int64_t> start, cpu;
-    std::vector<uint8_t> reason, excl;
-    std::vector<uint64_t> off, mem, lo, hi, g, w2, w3, msw_node, msw_task;   // msw_*: the job's memory_sw request (node + per task)
-    std::vector<uint32_t> node, nt;
+    PinVec<int64_t> start, cpu;
+    PinVec<uint8_t> reason;
+    std::vector<uint8_t> excl;
+    PinVec<uint64_t> off, mem, lo, hi, g, w2, w3;
+    std::vector<uint64_t> msw_node, msw_task;   // msw_*: the job's memory_sw request (node + per task)
+    PinVec<uint32_t> node, nt;
     size_t jobs = 0;
-  } last;
+    explicit PlacementStore(PinCtx* c = nullptr)
+        : start(PinAlloc<int64_t>(c)), cpu(PinAlloc<int64_t>(c)), reason(PinAlloc<uint8_t>(c)), off(PinAlloc<uint64_t>(c)), mem(PinAlloc<uint64_t>(c)),
+          lo(PinAlloc<uint64_t>(c)), hi(PinAlloc<uint64_t>(c)), g(PinAlloc<uint64_t>(c)), w2(PinAlloc<uint64_t>(c)), w3(PinAlloc<uint64_t>(c)),
+          node(PinAlloc<uint32_t>(c)), nt(PinAlloc<uint32_t>(c)) {}
+  } last{&pin};
   uint64_t mem_sw_of(size_t j, uint64_t q) const {   // what write_back puts into memory_sw_bytes
     return last.excl[j] ? node_mem_sw[last.node[q]] : last.msw_node[j] + last.msw_task[j] * last.nt[q];
   }
@@ -454,6 +508,7 @@ GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(int device, uint64_t scheduled_batch_
   batch_ = scheduled_batch_size;
   status_ = cns_create(&cfg, &impl_->h);
   if (status_ != 0) error_ = cns_last_error(nullptr);
+  impl_->pin.h = impl_->h;   // (null without an engine: the cycle's arrays are then plain memory)
 }
 
 void GpuNodeSelectionAlgo::SetCranedState(const CranedId& craned_id, bool alive, bool drain) {
@@ -492,7 +547,9 @@ void GpuNodeSelectionAlgo::PendingCycleForBench(const std::vector<std::unique_pt
   *write_back_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   {  // the same placements as "the last cycle" of the wire emission (EmitWireForBench)
     Impl::PlacementStore& S = I.last;
-    S.start = st; S.cpu = cpu; S.reason = rs; S.off = off; S.mem = mem; S.lo = lo; S.hi = hi; S.g = g; S.node = node; S.nt = ntk; S.w2.assign(J, 0); S.w3.assign(J, 0);
+    S.start.assign(st.begin(), st.end()); S.cpu.assign(cpu.begin(), cpu.end()); S.reason.assign(rs.begin(), rs.end()); S.off.assign(off.begin(), off.end());
+    S.mem.assign(mem.begin(), mem.end()); S.lo.assign(lo.begin(), lo.end()); S.hi.assign(hi.begin(), hi.end()); S.g.assign(g.begin(), g.end());
+    S.node.assign(node.begin(), node.end()); S.nt.assign(ntk.begin(), ntk.end()); S.w2.assign(J, 0); S.w3.assign(J, 0);
     S.excl.assign(J, 0); S.msw_node.assign(J, 0); S.msw_task.assign(J, 0);
     S.jobs = J;
     I.last_ord.assign(ord.begin(), ord.end());
@@ -530,10 +587,46 @@ size_t GpuNodeSelectionAlgo::PackRunningForBench(const std::vector<std::unique_p
 }
 
 GpuNodeSelectionAlgo::~GpuNodeSelectionAlgo() {
+  if (impl_) {   // the page-locked arrays go back first: cns_destroy releases whatever the handle still owns
+    impl_->packed = Impl::PackedJobs(nullptr);
+    impl_->last = Impl::PlacementStore(nullptr);
+    impl_->pin.h = nullptr;
+  }
   if (impl_ && impl_->h) cns_destroy(impl_->h);
 }
 
+void GpuNodeSelectionAlgo::LastCycleMs(double* pack_ms, double* engine_ms, double* write_back_ms) const {
+  if (pack_ms) *pack_ms = impl_->t_pack_ms;
+  if (engine_ms) *engine_ms = impl_->t_engine_ms;
+  if (write_back_ms) *write_back_ms = impl_->t_write_ms;
+}
+
 void GpuNodeSelectionAlgo::SetFullWriteBack(bool full) { impl_->lazy_write_back = !full; }
+void GpuNodeSelectionAlgo::SetDeferredWriteBack(bool deferred) { impl_->deferred_write_back = deferred; }
+
+bool GpuNodeSelectionAlgo::MaterializeAllocation(PdJobInScheduler& job) {
+  Impl& I = *impl_;
+  const Impl::PlacementStore& S = I.last;
+  if (I.last_index.size() != I.last_ord.size()) {
+    I.last_index.clear();
+    I.last_index.reserve(I.last_ord.size());
+    for (size_t j = 0; j < I.last_ord.size(); ++j) I.last_index[I.last_ord[j]] = j;
+  }
+  auto li = I.last_index.find(&job);
+  if (li == I.last_index.end() || li->second >= S.jobs || S.start[li->second] == 0) return false;
+  const size_t j = li->second;
+  job.craned_id_to_task_num.clear();
+  job.allocated_res.clear();
+  for (uint64_t q = S.off[j]; q < S.off[j + 1]; ++q) {
+    if (S.node[q] == CNS_NODE_NONE) continue;
+    const CranedId& cid = I.node_name[S.node[q]];
+    job.craned_id_to_task_num[cid] = S.nt[q];
+    ResourceInNodeV3& res = job.allocated_res[cid];
+    I.fill_res(res, S.cpu[q], S.mem[q], S.lo[q], S.hi[q], S.g[q], S.w2[q], S.w3[q]);
+    res.memory_sw_bytes = I.mem_sw_of(j, q);
+  }
+  return true;
+}
 
 void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   Impl& I = *impl_;
@@ -769,7 +862,8 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
     }
   }
   const size_t J = ord.size();
-  Impl::PackedJobs B;
+  const auto tp0 = std::chrono::steady_clock::now();
+  Impl::PackedJobs& B = I.packed;
   I.pack_pending(ord, B);
   auto &part = B.part, &k = B.k, &nt = B.nt, &tmin = B.tmin, &tmax = B.tmax, &inodes = B.inodes, &enodes = B.enodes, &jresv = B.jresv;
   auto &L = B.L, &ncpu = B.ncpu, &tcpu = B.tcpu;
@@ -806,6 +900,8 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   I.last_ord.clear();
   I.cancelled.clear();
   for (PdJobInScheduler* p : ord) p->preempted_jobs.clear();
+  const auto tp1 = std::chrono::steady_clock::now();
+  I.t_pack_ms = std::chrono::duration<double, std::milli>(tp1 - tp0).count();
   if (!I.preempt_enabled) {
     st = cns_select(I.h, now, &js, &out);
     if (st != 0) return fail_all(st, cns_last_error(I.h));
@@ -852,7 +948,11 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   S.jobs = J;
   status_ = 0;
   error_.clear();
+  const auto tp2 = std::chrono::steady_clock::now();
   I.write_back(ord, out);
+  const auto tp3 = std::chrono::steady_clock::now();
+  I.t_engine_ms = std::chrono::duration<double, std::milli>(tp2 - tp1).count();
+  I.t_write_ms = std::chrono::duration<double, std::milli>(tp3 - tp2).count();
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -198,6 +198,78 @@ static int cycle_bench(int n_nodes, int n_jobs) {
          1e3 * wire_ms / n_jobs, recs, bytes / 1e6);
   std::string one;
   CHECK(algo.AppendResourceInNodeV3Wire(*pd[n_jobs / 2], pd[n_jobs / 2]->craned_ids[0], &one) && !one.empty());
+  {   // deferred write-back + MaterializeAllocation = the full write-back, object for object
+    std::vector<std::unique_ptr<PdJobInScheduler>> pd2;
+    for (int j = 0; j < n_jobs; ++j) pd2.push_back(job((job_id_t)(j + 1), 4, 600 + j % 1000));
+    algo.SetDeferredWriteBack(true);
+    double p2, w2;
+    uint64_t s2;
+    algo.PendingCycleForBench(pd2, &p2, &w2, &s2);
+    algo.SetDeferredWriteBack(false);
+    printf("  deferred write-back                    : %8.2f ms = %.2f us / job\n", w2, 1e3 * w2 / n_jobs);
+    CHECK(pd2[7]->allocated_res.empty() && pd2[7]->craned_ids == pd[7]->craned_ids && pd2[7]->end_time == pd[7]->end_time);
+    size_t same = 0;
+    for (int j = 0; j < n_jobs; j += 13) {
+      CHECK(algo.MaterializeAllocation(*pd2[j]));
+      const auto& a = pd[j]->allocated_res.begin()->second;
+      const auto& b = pd2[j]->allocated_res.begin()->second;
+      same += pd2[j]->allocated_res.size() == 1 && pd[j]->allocated_res.begin()->first == pd2[j]->allocated_res.begin()->first &&
+              a.cpu_set.core_ids == b.cpu_set.core_ids && a.memory_bytes == b.memory_bytes && a.memory_sw_bytes == b.memory_sw_bytes &&
+              pd2[j]->craned_id_to_task_num == pd[j]->craned_id_to_task_num;
+    }
+    CHECK(same == (size_t)((n_jobs + 12) / 13));
+  }
+  printf("%s\n", g_fail ? "FAIL" : "ok");
+  return g_fail != 0;
+}
+
+// One whole NodeSelect through the adapter at full size, on the GPU: what an integrator's ScheduleThread sees between entering and
+// leaving m_node_selection_algo_->NodeSelect (JobScheduler.cpp:1439-1447) — packing, cns_select, write-back — P partitions of N / P nodes
+// (64 cores, 256 GiB), J pending jobs of 1..8 cores for 10..170 minutes, spread over the partitions.
+static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred) {
+  GpuNodeSelectionAlgo algo(0);
+  if (!algo.Ok()) { printf("engine: %s\n", algo.LastError().c_str()); return 2; }
+  algo.SetDeferredWriteBack(deferred);
+  ClusterSnapshot snap;
+  std::vector<std::vector<CranedId>> ids(n_parts);
+  for (int i = 0; i < n_nodes; ++i) {
+    char name[16];
+    snprintf(name, sizeof name, "cn%05d", i);
+    snap.craned_metas.push_back(node(name, 64, 256));
+    ids[i / ((n_nodes + n_parts - 1) / n_parts)].push_back(name);
+  }
+  for (int p = 0; p < n_parts; ++p) snap.partitions.push_back({"P" + std::to_string(p), ids[p]});
+  algo.SetClusterSnapshot(snap);
+  if (!algo.Ok()) { printf("snapshot: %s\n", algo.LastError().c_str()); return 2; }
+  std::vector<std::unique_ptr<RnJobInScheduler>> running;
+  printf("e2e-bench: %d nodes in %d partitions, %d pending jobs, %s write-back, one NodeSelect per line (1 host thread + 1 GPU)\n", n_nodes, n_parts, n_jobs,
+         deferred ? "deferred (allocated_res on demand)" : "lazy (default)");
+  for (int rep = 0; rep < 4; ++rep) {
+    std::vector<std::unique_ptr<PdJobInScheduler>> pd;
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (int j = 0; j < n_jobs; ++j) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      pd.push_back(job((job_id_t)(j + 1), 1 << (x & 3), 600 * (1 + (int)((x >> 8) % 17)), ("P" + std::to_string((x >> 16) % n_parts)).c_str()));
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    algo.NodeSelect(1000, running, pd);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    CHECK(algo.Ok());
+    double a = 0, b = 0, c = 0;
+    algo.LastCycleMs(&a, &b, &c);
+    size_t now_n = 0, later = 0;
+    for (const auto& p : pd) { now_n += p->reason.empty() && p->start_time == 1000; later += !p->reason.empty() && p->start_time > 1000; }
+    if (deferred) {   // the jobs a commit loop would launch: every tenth here
+      const auto m0 = std::chrono::steady_clock::now();
+      size_t n = 0;
+      for (size_t j = 0; j < pd.size(); j += 10) n += algo.MaterializeAllocation(*pd[j]);
+      const double mm = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - m0).count();
+      CHECK(n > 0 && !pd[0]->allocated_res.empty() && pd[1]->allocated_res.empty());
+      printf("  (MaterializeAllocation of %zu jobs: %.1f ms = %.2f us each)\n", n, mm, 1e3 * mm / n);
+    }
+    printf("  cycle %d: %8.1f ms = %.2f M decisions/s  (pack %.1f | cns_select %.1f | write-back %.1f ms; %zu start now, %zu backfilled)%s\n", rep, ms,
+           1e-3 * n_jobs / ms, a, b, c, now_n, later, rep == 0 ? "  [first cycle: the page-locked arrays are allocated]" : "");
+  }
   printf("%s\n", g_fail ? "FAIL" : "ok");
   return g_fail != 0;
 }
@@ -273,6 +345,7 @@ static int wire_dump(const char* path, int n, bool jobtod) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000);
+  if (argc > 1 && !strcmp(argv[1], "--e2e-bench")) return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"));
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
   if (argc > 2 && !strcmp(argv[1], "--wire-dump")) return wire_dump(argv[2], argc > 3 ? atoi(argv[3]) : 600, argc > 4 && !strcmp(argv[4], "jobtod"));
   if (argc > 1 && !strcmp(argv[1], "--mirror-check")) return mirror_check(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 20000);

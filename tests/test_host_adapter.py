@@ -22,6 +22,17 @@ def test_adapter_known_answers_on_gpu(built):
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["lazy", "deferred"])
+def test_whole_cycle_through_the_adapter_on_gpu(built, mode):
+    """One NodeSelect per cycle through the C++ adapter on the GPU (pack into page-locked arrays kept across cycles, cns_select,
+    write-back), with the default and the deferred write-back (allocated_res of the launched jobs on demand: MaterializeAllocation);
+    the full-size run is `test_host_adapter --e2e-bench 65536 8 1000000 [deferred]` (profiles/r03_adapter_e2e.txt)."""
+    r = subprocess.run([EXE, "--e2e-bench", "4096", "8", "40000"] + (["deferred"] if mode == "deferred" else []),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
 def test_incremental_running_pack_equals_full_pack(built):
     """the per-job cache of packed running allocations gives byte-identical cns_running_soa arrays, also
     after jobs ended / started (host-only, no device needed); the printed timings are the measurement."""
@@ -30,7 +41,8 @@ def test_incremental_running_pack_equals_full_pack(built):
 
 
 def test_pending_pack_and_write_back_host_only(built):
-    """cns_job_soa packing + write-back of synthetic placements into PdJobInScheduler objects (no device needed)."""
+    """cns_job_soa packing + write-back of synthetic placements into PdJobInScheduler objects (no device needed); the deferred
+    write-back followed by MaterializeAllocation builds the same objects as the full one."""
     r = subprocess.run([EXE, "--cycle-bench", "1024", "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
 
