@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <iterator>
+#include <thread>
 
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/priority.h"
@@ -138,10 +139,24 @@ struct GpuNodeSelectionAlgo::Impl {
   // ---- pending jobs -> cns_job_soa arrays, and placements -> PdJobInScheduler.  The reference's structures — a
   // std::set of core ids, string-keyed maps per job — are what makes the write-back expensive (~0.65 us per placed
   // job); a caller that can consume the SoA of the C ABI directly skips it. ------------------------------------------
-  // Measured (test_host_adapter --cycle-bench): 8 host threads made the write-back 5x SLOWER (small allocations into
-  // objects owned by another thread's malloc arena) and left the packing unchanged, so both loops are plain loops.
+  // Host threads (SetHostThreads; default 1): the loops are per job and independent, but the write-back is bound by the allocator —
+  // eight small allocations per placed job — and by the page faults behind it: on the MI355X box's host 1 M jobs take 440 ms on one
+  // thread, 261 ms on 4, 445 ms on 16 (pack: 51 / 37 / 31 ms; profiles/r03_host_threads.txt).  The deferred write-back (40 ms) is
+  // the better lever.
+  int host_threads = 1;
   template <class F>
-  static void parallel_for(size_t n, F&& body) { body((size_t)0, n); }
+  void parallel_for(size_t n, F&& body) const {
+    const size_t T = (size_t)std::max(1, host_threads);
+    if (T == 1 || n < 4096) { body((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + T - 1) / T;
+    for (size_t t = 1; t < T; ++t) {
+      const size_t a = std::min(n, t * chunk), b = std::min(n, a + chunk);
+      if (a < b) th.emplace_back([&body, a, b] { body(a, b); });
+    }
+    body((size_t)0, std::min(n, chunk));
+    for (auto& x : th) x.join();
+  }
   PinCtx pin;   // (pin.h = h once the engine exists)
   struct PackedJobs {
     PinVec<uint32_t> part, k, nt, tmin, tmax, inodes, enodes, jresv;
@@ -603,6 +618,7 @@ void GpuNodeSelectionAlgo::LastCycleMs(double* pack_ms, double* engine_ms, doubl
 
 void GpuNodeSelectionAlgo::SetFullWriteBack(bool full) { impl_->lazy_write_back = !full; }
 void GpuNodeSelectionAlgo::SetDeferredWriteBack(bool deferred) { impl_->deferred_write_back = deferred; }
+void GpuNodeSelectionAlgo::SetHostThreads(int n) { impl_->host_threads = n < 1 ? 1 : n; }
 
 bool GpuNodeSelectionAlgo::MaterializeAllocation(PdJobInScheduler& job) {
   Impl& I = *impl_;

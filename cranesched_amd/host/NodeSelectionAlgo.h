@@ -309,6 +309,9 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // craned_id_to_task_num / allocated_res (exactly what the full write-back builds) for the jobs that ARE launched (:1590-1600),
   // from the packed placements the adapter keeps.  0.39 -> 0.1 us per started job in NodeSelect; false: the job was not placed.
   void SetDeferredWriteBack(bool deferred);
+  // Host threads for the two per-job loops of a cycle (packing the pending jobs, the write-back): default 1, like the reference's
+  // single ScheduleThread; jobs are independent there, so n threads take n slices of the ordered vector.
+  void SetHostThreads(int n);
   bool MaterializeAllocation(PdJobInScheduler& job);
   // The cycle's license table for the pre-pass NodeSelect runs between ordering and selection
   // (g_license_manager->CheckLicenseCountSufficient, JobScheduler.cpp:6739; LicenseManager.cpp:167-221): a tiny

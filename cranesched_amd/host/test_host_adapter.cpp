@@ -168,8 +168,9 @@ static int mirror_check(int n_nodes, int n_jobs) {
 
 // Host-side cost of the pending side of one cycle: cns_job_soa packing and the write-back of the placements into the
 // PdJobInScheduler objects; needs no device.
-static int cycle_bench(int n_nodes, int n_jobs) {
+static int cycle_bench(int n_nodes, int n_jobs, int threads = 1) {
   GpuNodeSelectionAlgo algo(0);
+  algo.SetHostThreads(threads);
   ClusterSnapshot snap;
   std::vector<CranedId> ids;
   for (int i = 0; i < n_nodes; ++i) {
@@ -187,7 +188,7 @@ static int cycle_bench(int n_nodes, int n_jobs) {
   algo.PendingCycleForBench(pd, &pack_ms, &wb_ms, &sum);
   CHECK(pd[n_jobs / 2]->allocated_res.begin()->second.cpu_set.core_ids == (std::set<uint32_t>{0, 1, 2, 3}));
   CHECK(pd[n_jobs - 1]->end_time == 1000 + pd[n_jobs - 1]->time_limit && pd[0]->craned_ids[0] == "cn00000");
-  printf("cycle-bench: %d nodes, %d pending jobs (all placed, 1 node x 4 cores each), 1 host thread\n", n_nodes, n_jobs);
+  printf("cycle-bench: %d nodes, %d pending jobs (all placed, 1 node x 4 cores each), %d host thread%s\n", n_nodes, n_jobs, threads, threads > 1 ? "s" : "");
   printf("  pack  PdJobInScheduler -> cns_job_soa : %8.2f ms = %.2f us / job\n", pack_ms, 1e3 * pack_ms / n_jobs);
   printf("  write placements -> PdJobInScheduler  : %8.2f ms = %.2f us / job\n", wb_ms, 1e3 * wb_ms / n_jobs);
   size_t recs = 0, bytes = 0;
@@ -344,7 +345,7 @@ static int wire_dump(const char* path, int n, bool jobtod) {
 }
 
 int main(int argc, char** argv) {
-  if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000);
+  if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000, argc > 4 ? atoi(argv[4]) : 1);
   if (argc > 1 && !strcmp(argv[1], "--e2e-bench")) return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"));
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
   if (argc > 2 && !strcmp(argv[1], "--wire-dump")) return wire_dump(argv[2], argc > 3 ? atoi(argv[3]) : 600, argc > 4 && !strcmp(argv[4], "jobtod"));
