@@ -177,3 +177,31 @@ def test_bracketing_rounds_equal_greedy_admission(seed):
         assert got == want
         worst = max(worst, rounds)
     assert worst <= 60
+
+
+# ---- 4. k_wide's launch layout (cranesched_amd/csrc/wide_kernel.inc: blockIdx -> partition, member; engine.hip: launch_wide) -------------
+@pytest.mark.parametrize("group,max_parts", [(17, 8), (9, 24), (5, 48), (3, 80)])
+def test_wide_launch_layout(group, max_parts):
+    """The four builds of k_wide give a partition 1 + 16 / 8 / 4 / 2 workgroups.  Block b lands on XCD b % 8 (observed; speed only) and an
+    XCD has 32 CUs with one workgroup each, so the layout must (a) give every (partition, member) pair of the launch exactly one
+    block, (b) keep all workgroups of a partition on one value of b % 8, (c) put at most 32 workgroups on any XCD for up to
+    `max_parts` partitions, (d) fit the device's 256 CUs — for every partition count the build serves."""
+    for nparts in range(1, max_parts + 1):
+        groups = (nparts + 7) // 8
+        grid = 8 * groups * group
+        seen = {}
+        per_xcd = [0] * 8
+        for b in range(grid):
+            bslot = b >> 3
+            pidx = (bslot // group) * 8 + (b & 7)
+            m = bslot % group
+            if pidx >= nparts:          # the kernel returns at once: no CU held
+                continue
+            assert (pidx, m) not in seen
+            seen[(pidx, m)] = b
+            per_xcd[b % 8] += 1
+            assert b % 8 == pidx % 8    # (b): a partition's workgroups share the XCD
+        assert len(seen) == nparts * group                       # (a)
+        assert max(per_xcd) <= 32, (nparts, per_xcd)              # (c)
+        assert grid <= 256                                       # (d) what engine.hip's fits() checks before the launch
+    assert (32 // group) * 8 == max_parts                        # kWMaxParts of that build
