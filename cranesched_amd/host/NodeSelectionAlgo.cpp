@@ -261,6 +261,16 @@ struct GpuNodeSelectionAlgo::Impl {
   struct MirrorRec { CranedId craned; ResourceInNodeV3 res; AllocRec packed; bool known; };
   struct MirrorJob { TimeSec end_time = 0; std::string resv; std::vector<MirrorRec> recs; };
   std::map<job_id_t, MirrorJob> mirror;   // ascending job id = the order of the reference's running-job map
+  // The packed form of the mirror is kept between cycles and PATCHED: jobs that ended are squeezed out in one sequential pass, jobs
+  // that started (ids above everything packed) are appended, a changed end time is written in place.  Anything else — an allocation
+  // added to or taken from a job that is already packed and still runs, an id below the packed range, a reservation that changes,
+  // a new snapshot, an explicit running vector in between — falls back to the full walk over the map.
+  std::vector<job_id_t> r_job;            // packed job ids, ascending (valid while mirror_packed)
+  bool mirror_packed = false;             // r_* hold a packed mirror
+  bool mirror_full = true;                // the next pack walks the whole map
+  job_id_t m_last_id = 0;                 // highest packed id
+  std::vector<job_id_t> m_removed, m_touched, m_info;   // events since the last pack
+  size_t mirror_full_packs = 0, mirror_patch_packs = 0;
   void pack_rec(MirrorRec& r) {
     auto it = node_idx.find(r.craned);
     r.known = it != node_idx.end();
@@ -274,29 +284,102 @@ struct GpuNodeSelectionAlgo::Impl {
   void repack_mirror() {   // after a new snapshot
     for (auto& [id, mj] : mirror)
       for (auto& r : mj.recs) pack_rec(r);
+    mirror_full = true;
   }
-  void pack_from_mirror() {
+  void append_mirror_job(job_id_t id, const MirrorJob& mj) {
+    uint32_t rv = CNS_RESV_NONE;
+    if (!mj.resv.empty()) {
+      auto it = resv_idx.find(mj.resv);
+      if (it == resv_idx.end()) return;
+      rv = it->second;
+    }
+    r_job.push_back(id);
+    r_resv.push_back(rv);
+    r_end.push_back(mj.end_time);
+    for (const MirrorRec& r : mj.recs) {
+      if (!r.known) continue;
+      const AllocRec& a = r.packed;
+      r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
+      r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g); r_w2.push_back(a.w2); r_w3.push_back(a.w3);
+    }
+    r_off.push_back((uint32_t)r_node.size());
+  }
+  void pack_from_mirror_full() {
     r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear(); r_w2.clear(); r_w3.clear();
-    r_src.clear();        // the mirror has no RnJobInScheduler objects: a cycle with preemption must be refused, never served from an
-    r_src_valid = false;  // earlier explicit cycle's (freed) pointers that happen to match in number
+    r_job.clear();
     r_off.assign(1, 0);
-    for (const auto& [id, mj] : mirror) {
+    for (const auto& [id, mj] : mirror) append_mirror_job(id, mj);
+    m_last_id = mirror.empty() ? 0 : mirror.rbegin()->first;
+    ++mirror_full_packs;
+  }
+  // false: something happened that the patch does not cover
+  bool pack_from_mirror_patch() {
+    for (job_id_t id : m_touched) if (mirror.count(id)) return false;   // (a touched job that ended since is just a removal)
+    for (job_id_t id : m_info) {
+      auto mit = mirror.find(id);
+      if (mit == mirror.end()) continue;
+      auto pos = std::lower_bound(r_job.begin(), r_job.end(), id);
+      if (pos == r_job.end() || *pos != id) return false;               // not packed (its reservation was unknown): the full walk decides
+      const size_t j = (size_t)(pos - r_job.begin());
       uint32_t rv = CNS_RESV_NONE;
-      if (!mj.resv.empty()) {
-        auto it = resv_idx.find(mj.resv);
-        if (it == resv_idx.end()) continue;
+      if (!mit->second.resv.empty()) {
+        auto it = resv_idx.find(mit->second.resv);
+        if (it == resv_idx.end()) return false;
         rv = it->second;
       }
-      r_resv.push_back(rv);
-      r_end.push_back(mj.end_time);
-      for (const MirrorRec& r : mj.recs) {
-        if (!r.known) continue;
-        const AllocRec& a = r.packed;
-        r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
-        r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g); r_w2.push_back(a.w2); r_w3.push_back(a.w3);
-      }
-      r_off.push_back((uint32_t)r_node.size());
+      if (rv != r_resv[j]) return false;
+      r_end[j] = mit->second.end_time;
     }
+    if (!m_removed.empty()) {   // squeeze the ended jobs out: one sequential pass, runs of kept jobs move as blocks
+      std::sort(m_removed.begin(), m_removed.end());
+      m_removed.erase(std::unique(m_removed.begin(), m_removed.end()), m_removed.end());
+      const size_t Jn = r_job.size();
+      size_t wj = 0, ri = 0;          // next job slot to write, next removed id to meet
+      uint32_t wa = 0;                // next record slot to write
+      size_t j = 0;
+      while (j < Jn) {
+        while (ri < m_removed.size() && m_removed[ri] < r_job[j]) ++ri;
+        if (ri < m_removed.size() && m_removed[ri] == r_job[j]) { ++j; continue; }
+        size_t e = j + 1;             // the run of kept jobs [j, e)
+        while (e < Jn) {
+          while (ri < m_removed.size() && m_removed[ri] < r_job[e]) ++ri;
+          if (ri < m_removed.size() && m_removed[ri] == r_job[e]) break;
+          ++e;
+        }
+        const uint32_t a0 = r_off[j], a1 = r_off[e];
+        if (wj != j) {
+          std::move(r_job.begin() + j, r_job.begin() + e, r_job.begin() + wj);
+          std::move(r_end.begin() + j, r_end.begin() + e, r_end.begin() + wj);
+          std::move(r_resv.begin() + j, r_resv.begin() + e, r_resv.begin() + wj);
+          std::move(r_node.begin() + a0, r_node.begin() + a1, r_node.begin() + wa);
+          std::move(r_cpu.begin() + a0, r_cpu.begin() + a1, r_cpu.begin() + wa);
+          std::move(r_mem.begin() + a0, r_mem.begin() + a1, r_mem.begin() + wa);
+          std::move(r_lo.begin() + a0, r_lo.begin() + a1, r_lo.begin() + wa);
+          std::move(r_hi.begin() + a0, r_hi.begin() + a1, r_hi.begin() + wa);
+          std::move(r_g.begin() + a0, r_g.begin() + a1, r_g.begin() + wa);
+          std::move(r_w2.begin() + a0, r_w2.begin() + a1, r_w2.begin() + wa);
+          std::move(r_w3.begin() + a0, r_w3.begin() + a1, r_w3.begin() + wa);
+        }
+        const uint32_t shift = a0 - wa;   // (offsets of the run, ascending: r_off[wj + 1 ..] are behind what is still to be read)
+        for (size_t x = j; x < e; ++x) r_off[wj + (x - j) + 1] = r_off[x + 1] - shift;
+        wj += e - j; wa += a1 - a0;
+        j = e;
+      }
+      r_job.resize(wj); r_end.resize(wj); r_resv.resize(wj); r_off.resize(wj + 1);
+      r_node.resize(wa); r_cpu.resize(wa); r_mem.resize(wa); r_lo.resize(wa); r_hi.resize(wa); r_g.resize(wa); r_w2.resize(wa); r_w3.resize(wa);
+    }
+    for (auto it = mirror.upper_bound(m_last_id); it != mirror.end(); ++it) append_mirror_job(it->first, it->second);
+    if (!mirror.empty()) m_last_id = std::max(m_last_id, mirror.rbegin()->first);
+    ++mirror_patch_packs;
+    return true;
+  }
+  void pack_from_mirror() {
+    r_src.clear();        // the mirror has no RnJobInScheduler objects: a cycle with preemption must be refused, never served from an
+    r_src_valid = false;  // earlier explicit cycle's (freed) pointers that happen to match in number
+    if (!mirror_packed || mirror_full || !pack_from_mirror_patch()) pack_from_mirror_full();
+    mirror_packed = true;
+    mirror_full = false;
+    m_removed.clear(); m_touched.clear(); m_info.clear();
   }
   // checksum of the packed running arrays that ignores the order of a job's per-node records
   uint64_t running_checksum_canonical() const {
@@ -317,6 +400,7 @@ struct GpuNodeSelectionAlgo::Impl {
     r_end.clear(); r_cpu.clear(); r_node.clear(); r_resv.clear(); r_mem.clear(); r_lo.clear(); r_hi.clear(); r_g.clear(); r_w2.clear(); r_w3.clear();
     r_src.clear();
     r_src_valid = true;
+    mirror_packed = false;   // (r_* now hold the caller's vector)
     r_off.assign(1, 0);
     ++alloc_gen;
     PackedAlloc scratch;
@@ -760,6 +844,7 @@ void GpuNodeSelectionAlgo::MallocResourceFromNode(const CranedId& craned_id, job
   auto rit = resources.find(craned_id);   // resources.At(node_id), :198
   if (rit == resources.end()) return;
   auto& mj = I.mirror[job_id];
+  if (I.mirror_packed && job_id <= I.m_last_id) I.m_touched.push_back(job_id);   // a job inside the packed range changes (or appears there)
   Impl::MirrorRec* rec = nullptr;
   for (auto& r : mj.recs) if (r.craned == craned_id) rec = &r;   // (rn_job_res_map.emplace: one record per (craned, job))
   if (!rec) { mj.recs.emplace_back(); rec = &mj.recs.back(); rec->craned = craned_id; }
@@ -774,6 +859,10 @@ void GpuNodeSelectionAlgo::FreeResourceFromNode(const CranedId& craned_id, job_i
   auto& recs = it->second.recs;
   for (size_t i = 0; i < recs.size(); ++i)
     if (recs[i].craned == craned_id) { recs.erase(recs.begin() + i); break; }
+  if (I.mirror_packed && job_id <= I.m_last_id) {
+    if (recs.empty()) I.m_removed.push_back(job_id);
+    else I.m_touched.push_back(job_id);   // (the rest of its nodes usually follow before the next cycle: then it is a removal)
+  }
   if (recs.empty()) I.mirror.erase(it);
 }
 
@@ -781,9 +870,14 @@ void GpuNodeSelectionAlgo::SetRunningJobInfo(job_id_t job_id, TimeSec end_time, 
   auto& mj = impl_->mirror[job_id];
   mj.end_time = end_time;
   mj.resv = reservation;
+  if (impl_->mirror_packed && job_id <= impl_->m_last_id) impl_->m_info.push_back(job_id);
 }
 
 size_t GpuNodeSelectionAlgo::MirroredRunningJobs() const { return impl_->mirror.size(); }
+void GpuNodeSelectionAlgo::MirrorPackCounts(size_t* full_walks, size_t* patches) const {
+  if (full_walks) *full_walks = impl_->mirror_full_packs;
+  if (patches) *patches = impl_->mirror_patch_packs;
+}
 
 size_t GpuNodeSelectionAlgo::PackMirrorForBench(uint64_t* checksum_canonical, double* pack_ms) {
   Impl& I = *impl_;

@@ -336,6 +336,8 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   void FreeResourceFromNode(const CranedId& craned_id, job_id_t job_id);
   void SetRunningJobInfo(job_id_t job_id, TimeSec end_time, const std::string& reservation = "");
   size_t MirroredRunningJobs() const;
+  // how the mirror was packed so far: full walks over the job map / patches of the packed form kept from the previous cycle
+  void MirrorPackCounts(size_t* full_walks, size_t* patches) const;
   // (`running_for_priority`: only read by a multifactor sorter, JobScheduler.cpp:7692-7746; not needed with BasicPriority)
   void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
                   const std::vector<std::unique_ptr<RnJobInScheduler>>* running_for_priority = nullptr);

@@ -162,6 +162,67 @@ static int mirror_check(int n_nodes, int n_jobs) {
   }
   algo.SetClusterSnapshot(snap);   // a new snapshot re-packs the mirror (dense indices / GRES bits are per snapshot)
   same();
+  // ---- the packed form is patched between cycles (ended jobs squeezed out, new ones appended, end times in place); what the patch
+  // does not cover must fall back to the full walk — either way the result is the walk's ----------------------------------------
+  size_t f0 = 0, p0 = 0, f1 = 0, p1 = 0;
+  algo.MirrorPackCounts(&f0, &p0);
+  CHECK(p0 >= 3);                                    // the churn rounds above were patches
+  same();                                            // nothing happened: an empty patch
+  algo.MirrorPackCounts(&f1, &p1);
+  CHECK(f1 == f0 && p1 == p0 + 1);
+  {   // a running job loses one of its nodes and goes on: not a removal
+    job_id_t victim = 0;
+    for (auto& [id, r] : live) if (r->allocated_res.size() > 1) { victim = id; break; }
+    CHECK(victim != 0);
+    const CranedId cid = live[victim]->allocated_res.begin()->first;
+    algo.FreeResourceFromNode(cid, victim);
+    live[victim]->allocated_res.erase(cid);
+    same();
+    algo.MirrorPackCounts(&f0, &p0);
+    CHECK(f0 == f1 + 1);                             // full walk
+  }
+  {   // a packed job gets one more allocation
+    const job_id_t id = live.begin()->first;
+    ResourceV3 one;
+    ResourceInNodeV3& res = one[ids[7]];
+    res.cpu_set.cpu_count = cpu_t(2); res.cpu_set.core_ids = {60, 61}; res.memory_bytes = 1ull << 30;
+    live[id]->allocated_res[ids[7]] = res;
+    algo.MallocResourceFromNode(ids[7], id, one);
+    same();
+  }
+  {   // a job id BELOW the packed range starts (ids are not promised to grow), another one ends and comes back within the cycle
+    const job_id_t low = live.begin()->first - 1 > 0 && !live.count(live.begin()->first - 1) ? live.begin()->first - 1 : 0;
+    if (low) start_job(low);
+    const job_id_t again = live.rbegin()->first;
+    end_job(again);
+    start_job(again);
+    same();
+  }
+  {   // jobs end only; then jobs start only
+    std::vector<job_id_t> idsv;
+    for (auto& [id, r] : live) idsv.push_back(id);
+    for (size_t i = 0; i < idsv.size(); i += 7) end_job(idsv[i]);
+    algo.MirrorPackCounts(&f0, &p0);
+    same();
+    algo.MirrorPackCounts(&f1, &p1);
+    CHECK(p1 == p0 + 1 && f1 == f0);                 // removals alone: a patch
+    for (int e = 0; e < 1000; ++e) start_job(next++);
+    same();
+    algo.MirrorPackCounts(&f0, &p0);
+    CHECK(p0 == p1 + 1 && f0 == f1);                 // appends alone: a patch
+  }
+  {   // the first and the last packed job end, every job in between stays
+    end_job(live.begin()->first);
+    end_job(live.rbegin()->first);
+    same();
+  }
+  {   // a cycle with an explicit running vector in between overwrites the packed arrays
+    std::vector<std::unique_ptr<RnJobInScheduler>> vec;
+    uint64_t c;
+    double ms;
+    algo.PackRunningForBench(vec, true, &c, &ms);
+    same();
+  }
   printf("%s\n", g_fail ? "FAIL" : "ok");
   return g_fail != 0;
 }
