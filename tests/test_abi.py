@@ -74,3 +74,14 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, flags=re.M), f"{f} imports the oracle"
                 assert "liboracle" not in txt and "pyoracle" not in txt and "oracle/" not in txt, f"{f} uses the oracle"
+
+
+def test_bench_names_the_shape_of_every_wide_build():
+    """bench.py's `config.sharding` text is derived from the kernel name the engine reports (k_wide<NPL> x<scanner waves>)."""
+    import bench
+    assert bench._wide_shape("k_wide<2> x64") == "single GPU, 1 + 16 workgroups per partition (k_wide, 64 scanner waves)"
+    assert bench._wide_shape("k_wide<4> x32").startswith("single GPU, 1 + 8 workgroups")
+    assert bench._wide_shape("k_wide<2> x16").startswith("single GPU, 1 + 4 workgroups")
+    assert bench._wide_shape("k_wide<2> x8").startswith("single GPU, 1 + 2 workgroups")
+    assert bench._wide_shape("k_wide<2> x64 + k_select<37> on 1 of 8 partitions").startswith("single GPU, 1 + 16 workgroups")
+    assert bench._wide_shape("k_wide") == "single GPU, k_wide"
