@@ -1172,7 +1172,7 @@ ResourceView UnlimitedTres() {  // DbClient.cpp:420-428
   return v;
 }
 const char* kLimitReasonStr[] = {"", "QosEntryNotFound", "QosCpuResourceLimit", "QosJobsResourceLimit", "QosWallTimeLimit",
-                                 "CpuResourceLimit", "MemResourceLimit", "GresResourceLimit", "PartitionEntryNotFound",
+                                 "QosCpuResourceLimit", "QosMemResourceLimit", "QosGresResourceLimit", "PartitionEntryNotFound",
                                  "UserPartitionJobsLimit", "UserPartitionWallTimeLimit", "AccPartitionJobsLimit",
                                  "AccPartitionWallTimeLimit", "PartitionCpuResourceLimit", "PartitionMemResourceLimit",
                                  "PartitionGresResourceLimit"};

@@ -707,7 +707,7 @@ int main(int argc, char** argv) {
       CHECK(algo.Ok());
       CHECK(res.size() == 5 && res[0].empty() && res[1] == "QosJobsResourceLimit" && res[2].empty());
       CHECK(res[3] == "InvalidUser");                      // not in AccountManager (:186-191)
-      CHECK(res[4] == "CpuResourceLimit");                 // lab already holds 2 cores (alice, bob)
+      CHECK(res[4] == "QosCpuResourceLimit");                 // lab already holds 2 cores (alice, bob)
       CHECK(meta.user_meta["alice"].qos_to_resource_map["normal"].jobs_count == 1);
       CHECK(meta.user_meta["alice"].account_to_partition_to_resource_map["lab"]["CPU"].jobs_count == 1);  // created by DoMallocResource_
       CHECK(meta.account_meta["root"].qos_to_resource_map["normal"].jobs_count == 2);

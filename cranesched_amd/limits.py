@@ -23,9 +23,11 @@ UNLIMITED_CPU_RAW = 1 << 53
 MAX_JOB_MEMORY = 10737418240000
 NOT_CANDIDATE = 255
 
+# The reference's strings (AccountMetaContainer.cpp; CheckTres_'s prefix defaults to "Qos", AccountMetaContainer.h:179-181):
+# codes 2 and 5 are different checks (max_cpus_per_user / a max_tres* cpu count) that report the same string.
 LIMIT_REASON_STR = {
     0: "", 1: "QosEntryNotFound", 2: "QosCpuResourceLimit", 3: "QosJobsResourceLimit", 4: "QosWallTimeLimit",
-    5: "CpuResourceLimit", 6: "MemResourceLimit", 7: "GresResourceLimit", 8: "PartitionEntryNotFound",
+    5: "QosCpuResourceLimit", 6: "QosMemResourceLimit", 7: "QosGresResourceLimit", 8: "PartitionEntryNotFound",
     9: "UserPartitionJobsLimit", 10: "UserPartitionWallTimeLimit", 11: "AccPartitionJobsLimit",
     12: "AccPartitionWallTimeLimit", 13: "PartitionCpuResourceLimit", 14: "PartitionMemResourceLimit",
     15: "PartitionGresResourceLimit", 255: "<not a candidate>",

@@ -61,9 +61,9 @@ typedef enum cns_limit_reason {
   CNS_LIM_QOS_CPU = 2,                    /* "QosCpuResourceLimit"         [:525] */
   CNS_LIM_QOS_JOBS = 3,                   /* "QosJobsResourceLimit"        [:527,534,1001] */
   CNS_LIM_QOS_WALL = 4,                   /* "QosWallTimeLimit"            [:530,537,1012] */
-  CNS_LIM_CPU = 5,                        /* "CpuResourceLimit"            [:349] */
-  CNS_LIM_MEM = 6,                        /* "MemResourceLimit"            [:353] */
-  CNS_LIM_GRES = 7,                       /* "GresResourceLimit"           [:357] */
+  CNS_LIM_CPU = 5,                        /* "QosCpuResourceLimit"         [:349; CheckTres_'s prefix defaults to "Qos", .h:179-181] */
+  CNS_LIM_MEM = 6,                        /* "QosMemResourceLimit"         [:353] */
+  CNS_LIM_GRES = 7,                       /* "QosGresResourceLimit"        [:357] */
   CNS_LIM_PARTITION_ENTRY_NOT_FOUND = 8,  /* "PartitionEntryNotFound"      [:559,568,621] */
   CNS_LIM_USER_PARTITION_JOBS = 9,        /* "UserPartitionJobsLimit"      [:580] */
   CNS_LIM_USER_PARTITION_WALL = 10,       /* "UserPartitionWallTimeLimit"  [:594] */

@@ -14,9 +14,12 @@
 // The reference's maps (std::unordered_map keyed by strings) are kept as MAPS here — entries appear and are
 // looked up exactly where the reference does — but keyed by the dense indices of include/crane_gpu/run_limits.h
 // and ordered (std::map), which fixes the iteration order CheckGres_ depends on (ascending name, ascending
-// type class).  PARITY UNPINNED: the reference holds no test for this path (test/ has no AccountMetaContainer
-// case) and cannot be built here (C++23 + generated protobuf); the KATs in
-// tests/test_run_limits.py are hand-derived from the cited lines.
+// type class).  PINNED (round 4): the reference holds no test for this path (test/ has no AccountMetaContainer case),
+// but its own code runs here: oracle/_ref compiles AccountMetaContainer.h:30-295 and AccountMetaContainer.cpp:39-45,
+// 180-224,345-365,508-687,891-1124 (sliced at build time by oracle/ref_build/extract.py) and
+// tests/test_ref_pin_limits_steps.py holds this restatement to it — every reason string, the admitted count and every
+// usage record after the pass, on the hand-derived scenarios of tests/test_run_limits.py, 40 random account trees and
+// BASELINE config 4's account / QoS tables.
 #pragma once
 #include <cstdint>
 #include <map>
@@ -79,7 +82,7 @@ struct MetaResourceStat {  // one user or one account (AccountMetaContainer.h:62
 
 inline const char* reason_string(int code) {
   static const char* s[] = {"", "QosEntryNotFound", "QosCpuResourceLimit", "QosJobsResourceLimit", "QosWallTimeLimit",
-                            "CpuResourceLimit", "MemResourceLimit", "GresResourceLimit", "PartitionEntryNotFound",
+                            "QosCpuResourceLimit", "QosMemResourceLimit", "QosGresResourceLimit", "PartitionEntryNotFound",
                             "UserPartitionJobsLimit", "UserPartitionWallTimeLimit", "AccPartitionJobsLimit",
                             "AccPartitionWallTimeLimit", "PartitionCpuResourceLimit", "PartitionMemResourceLimit",
                             "PartitionGresResourceLimit"};
@@ -255,7 +258,7 @@ class Limits {
     }
     return true;
   }
-  // CheckTres_ (:345-360); prefix 0 = "", 8 = "Partition" (reason codes 5..7 / 13..15)
+  // CheckTres_ (:345-360); prefix 0 = "Qos" (the default, AccountMetaContainer.h:179-181), 8 = "Partition" (reason codes 5..7 / 13..15)
   static int check_tres(const ResourceView& req, const ResourceView& total, int prefix) {
     if (req.cpu > total.cpu) return CNS_LIM_CPU + prefix;
     if (req.mem > total.mem) return CNS_LIM_MEM + prefix;

@@ -1,8 +1,9 @@
 // TEST INFRASTRUCTURE ONLY — CPU restatement of MultiFactorPriority, the checker of cns_priority_order.
 // Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use anything under oracle/.
-// PARITY UNPINNED: the reference ships no test or golden vector for this class and cannot be built offline
-// (SURVEY.md §8c); the restatement follows the cited lines one by one and is pinned by hand-derived KATs
-// (tests/test_priority.py).
+// PINNED (round 3): the reference ships no test or golden vector for this class, but its own
+// MultiFactorPriority::{GetOrderedJobPtrVec, CalculateFactorBound_, CalculatePriority_} are compiled into oracle/_ref
+// (oracle/ref_build/extract.py) and tests/test_ref_pin.py holds this restatement to them (fp64 priorities as bit
+// patterns and the order, 40 random cases), beside the hand-derived KATs of tests/test_priority.py.
 //
 // Reference: src/CraneCtld/JobScheduler.cpp:7606-7819 (GetOrderedJobPtrVec :7606-7631,
 // CalculateFactorBound_ :7633-7752, CalculatePriority_ :7754-7817), struct FactorBound JobScheduler.h:214-224,

@@ -2,7 +2,7 @@
 
 ORACLE = TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
 bench.py's cpu_baseline leg, never from cranesched_amd/ (the product).  See
-oracle/res_algebra.hpp for what it restates and for its "parity unpinned" status.
+oracle/res_algebra.hpp for what it restates and how it is pinned to the reference's own code (oracle/_ref).
 """
 from __future__ import annotations
 
@@ -250,30 +250,40 @@ def priority_order(now: int, cfg, num_accounts: int, pending, running=None, back
     return order[:J], prio[:J]
 
 
-def run_limits(layout: abi.GresLayout, tables, jobs, placements: abi.Placements):
+def run_limits(layout: abi.GresLayout, tables, jobs, placements: abi.Placements, backend: str = "oracle"):
     """CPU restatement of the commit loop's run-limit admission (oracle/limits_oracle.hpp).
 
     `placements` are a NodeSelect result (of the oracle or of the engine).  Returns (reason[J] u8, admitted, Usage).
+    backend `ref`: the reference's own AccountMetaContainer::CheckAndMallocMetaResource (AccountMetaContainer.cpp:180-224
+    with CheckRunLimits_ :891-1028, the per-entity checks :508-687, CheckTres_ / CheckGres_ :345-365,1030-1050 and
+    DoMallocResource_ :1067-1124), compiled from /root/reference (oracle/_ref).  Its reasons are strings; the code
+    returned is the FIRST code of include/crane_gpu/run_limits.h with that string (codes 2 and 5 share
+    "QosCpuResourceLimit"): compare through limits.REASON_STRINGS.
     """
     from cranesched_amd import limits as lm
-    L = lib()
+    L = lib(backend)
     reason = np.full(max(jobs.num_jobs, 1), 0, np.uint8)
     adm = C.c_uint64(0)
     usage = tables.empty_usage()
     gl, ct, cj, cp = layout.to_c(), tables.to_c(), jobs.to_c(), placements.to_c()
     rc = L.ora_run_limits(C.byref(gl), C.byref(ct), C.byref(cj), C.byref(cp), reason.ctypes.data_as(C.c_void_p),
                           C.byref(adm), *usage.pointers())
-    if rc != 0:
+    if rc == -1:
         raise ValueError("ora_run_limits: key index out of range")
+    if rc != 0:
+        raise RuntimeError(f"ora_run_limits ({backend}) failed: {rc}: {L.ref_last_error().decode() if backend != 'oracle' else ''}")
     return reason[:jobs.num_jobs], adm.value, usage
 
 
-def schedule_steps(layout: abi.GresLayout, step_jobs, steps, algebra: int = MASK):
-    """CPU restatement of JobInCtld::SchedulePendingSteps for every job (oracle/steps_oracle.hpp).  Returns StepResults."""
+def schedule_steps(layout: abi.GresLayout, step_jobs, steps, algebra: int = MASK, backend: str = "oracle"):
+    """CPU restatement of JobInCtld::SchedulePendingSteps for every job (oracle/steps_oracle.hpp).  Returns StepResults.
+    backend `ref`: the reference's own JobInCtld::SchedulePendingSteps (CtldPublicDefs.cpp:2038-2159), compiled from
+    /root/reference (oracle/_ref); a job's nodes must be given in ascending node index (the order its map walk has there)."""
     from cranesched_amd import steps as st
     out = st.StepResults(step_jobs, steps)
     gl, cj, cs, co = layout.to_c(), step_jobs.to_c(), steps.to_c(), out.to_c()
-    rc = lib().ora_schedule_steps(C.byref(gl), C.byref(cj), C.byref(cs), C.byref(co), C.c_int(algebra))
+    L = lib(backend)
+    rc = L.ora_schedule_steps(C.byref(gl), C.byref(cj), C.byref(cs), C.byref(co), C.c_int(algebra))
     if rc != 0:
-        raise RuntimeError(f"ora_schedule_steps failed: {rc}")
+        raise RuntimeError(f"ora_schedule_steps ({backend}) failed: {rc}: {L.ref_last_error().decode() if backend != 'oracle' else ''}")
     return out

@@ -19,6 +19,12 @@ What is sliced:
                    LocalScheduler, EarliestStartSubsetSelector, PreemptSegTree
   JobScheduler.cpp LocalScheduler::{CalculateRunningNodesAndStartTime_, GetNodesAndTrySchedule_,
                    Backfill_, TryPreempt_}, SchedulerAlgo::NodeSelect, MultiFactorPriority::*
+  AccountMetaContainer.h    struct MetaResource … the end of class AccountMetaContainer
+  AccountMetaContainer.cpp  the run-limit admission of the commit loop: MetaResource::operator+=,
+                   AccountMetaContainer::{CheckAndMallocMetaResource, CheckTres_, IsUnlimitedTres_,
+                   CheckQosRunLimitsForEntity_, CheckPartitionRunLimitsForEntity_, CheckEntityRunLimits_,
+                   CheckRunLimits_, CheckGres_, LockAccountStripes_, DoMallocResource_}
+  CtldPublicDefs.cpp        JobInCtld::SchedulePendingSteps (SURVEY.md §8f-4)
 
 Every slice is located by ANCHOR TEXT (a changed reference fails loudly) and the line
 ranges found are written to oracle/_ref/gen/MANIFEST.txt.  No line of a slice is edited.
@@ -36,6 +42,9 @@ PH_H = "src/Utilities/PublicHeader/include/crane/PublicHeader.h"
 PH_CPP = "src/Utilities/PublicHeader/PublicHeader.cpp"
 JS_H = "src/CraneCtld/JobScheduler.h"
 JS_CPP = "src/CraneCtld/JobScheduler.cpp"
+AMC_H = "src/CraneCtld/Accounting/AccountMetaContainer.h"
+AMC_CPP = "src/CraneCtld/Accounting/AccountMetaContainer.cpp"
+CPD_CPP = "src/CraneCtld/CtldPublicDefs.cpp"
 
 
 def read(rel):
@@ -106,6 +115,27 @@ def function_range(lines, sig_prefix, start=0):
     raise SystemExit(f"extract.py: unterminated definition at {sig_prefix!r}")
 
 
+def definition_range(lines, needle):
+    """[b, e] of the top-level definition whose declarator contains `needle` (a qualified name such as
+    `AccountMetaContainer::CheckTres_(`): the return type may sit on the line(s) above the name."""
+    hits = [i for i, ln in enumerate(lines) if needle in ln]
+    if len(hits) != 1:
+        raise SystemExit(f"extract.py: {len(hits)} matches for {needle!r} (expected exactly one definition)")
+    b = hits[0]
+    while b > 0 and lines[b - 1].strip() and not lines[b - 1].rstrip().endswith((";", "}", "*/")) \
+            and not lines[b - 1].lstrip().startswith(("//", "#", "*")):
+        b -= 1
+    depth, seen = 0, False
+    for i in range(hits[0], len(lines)):
+        code = re.sub(r'"(\\.|[^"\\])*"', '""', lines[i]).split("//", 1)[0]
+        depth += code.count("{") - code.count("}")
+        if "{" in code:
+            seen = True
+        if seen and depth == 0:
+            return b, i
+    raise SystemExit(f"extract.py: unterminated definition at {needle!r}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", required=True)
@@ -171,11 +201,42 @@ def main():
     ranges = [function_range(jc, n) for n in names]
     emit("js_impl.inc", JS_CPP, ranges, jc, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
 
+    # ---- AccountMetaContainer.h: MetaResource … end of class AccountMetaContainer ---------------
+    ah = read(AMC_H)
+    b = find_line(ah, "struct MetaResource {", exact=True)
+    e = find_line(ah, "}  // namespace Ctld", b) - 1
+    while ah[e].strip() == "":
+        e -= 1
+    emit("amc_types.inc", AMC_H, [(b, e)], ah, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
+
+    # ---- AccountMetaContainer.cpp: the run-limit admission ----------------------------------------
+    ac = read(AMC_CPP)
+    names = [
+        "MetaResource& MetaResource::operator+=(",
+        "AccountMetaContainer::CheckAndMallocMetaResource(",
+        "AccountMetaContainer::CheckTres_(",
+        "AccountMetaContainer::IsUnlimitedTres_(",
+        "AccountMetaContainer::CheckQosRunLimitsForEntity_(",
+        "AccountMetaContainer::CheckPartitionRunLimitsForEntity_(",
+        "AccountMetaContainer::CheckEntityRunLimits_(",
+        "AccountMetaContainer::CheckRunLimits_(",
+        "AccountMetaContainer::CheckGres_(",
+        "AccountMetaContainer::LockAccountStripes_(",
+        "AccountMetaContainer::DoMallocResource_(",
+    ]
+    ranges = sorted(definition_range(ac, n) for n in names)
+    emit("amc_impl.inc", AMC_CPP, ranges, ac, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
+
+    # ---- CtldPublicDefs.cpp: JobInCtld::SchedulePendingSteps ------------------------------------------
+    cc = read(CPD_CPP)
+    ranges = [definition_range(cc, "JobInCtld::SchedulePendingSteps(")]
+    emit("steps_impl.inc", CPD_CPP, ranges, cc, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
+
     sha = hashlib.sha256()
-    for rel in (PH_H, PH_CPP, JS_H, JS_CPP):
+    for rel in (PH_H, PH_CPP, JS_H, JS_CPP, AMC_H, AMC_CPP, CPD_CPP):
         with open(os.path.join(REF, rel), "rb") as f:
             sha.update(f.read())
-    manifest.append("sha256 of the four reference files: " + sha.hexdigest())
+    manifest.append("sha256 of the seven reference files: " + sha.hexdigest())
     with open(os.path.join(args.out, "MANIFEST.txt"), "w") as f:
         f.write("\n".join(manifest) + "\n")
     print("\n".join(manifest))

@@ -6,10 +6,14 @@
 //   JobScheduler.h         namespace Ctld … SchedulerAlgo (NodeState, NodeSelector, LocalScheduler,
 //                          EarliestStartSubsetSelector, PreemptSegTree, the priority sorters)
 //   JobScheduler.cpp       LocalScheduler::*, SchedulerAlgo::NodeSelect, MultiFactorPriority::*
+//   AccountMetaContainer.h MetaResource, MetaResourceStat, class AccountMetaContainer
+//   AccountMetaContainer.cpp  CheckAndMallocMetaResource, CheckRunLimits_, the per-entity checks, CheckTres_ / CheckGres_,
+//                          DoMallocResource_ (the run-limit admission of the commit loop)
+//   CtldPublicDefs.cpp     JobInCtld::SchedulePendingSteps
 // against the stand-ins in oracle/ref_build/shim/ (abseil time + containers, fpm::fixed, the CraneCtld
 // singletons NodeSelect reads).  It then exposes THE SAME C entry points as the restated oracle
 // (oracle/crane_oracle.cpp: ora_select*, ora_get_costs, ora_get_timeline, ora_feasible, ora_binop,
-// ora_priority_order), so tests/ can run every scenario through the reference's code and diff it against
+// ora_priority_order, ora_run_limits, ora_schedule_steps), so tests/ can run every scenario through the reference's code and diff it against
 // the restatement.  Output: oracle/_ref/libcrane_ref.so (and libcrane_ref_hash.so, see below).
 //
 // Two flavours (oracle/Makefile):
@@ -49,6 +53,16 @@ class crane_ref_ordered_map : public std::map<K, V> {
 #undef protected
 #include "js_impl.inc"
 
+// run-limit admission (AccountMetaContainer) and the step scheduler (JobInCtld::SchedulePendingSteps)
+#include "shim/crane_shim_acct.h"
+#define unexpected crane_ref_unexpected   // see shim/expected_shim.h
+#define private public
+#include "amc_types.inc"
+#undef private
+#include "amc_impl.inc"
+#include "steps_impl.inc"
+#undef unexpected
+
 #ifdef CRANE_REF_CANONICAL
 #undef unordered_map
 #undef sort
@@ -59,6 +73,8 @@ class crane_ref_ordered_map : public std::map<K, V> {
 
 #include "../../include/crane_gpu/node_select.h"
 #include "../../include/crane_gpu/preempt.h"
+#include "../../include/crane_gpu/run_limits.h"
+#include "../../include/crane_gpu/steps.h"
 
 namespace {
 
@@ -555,6 +571,310 @@ int ora_priority_order(int64_t now_sec, uint64_t max_age, uint32_t w_age, uint32
     for (uint32_t i = 0; i < J; ++i) { order_out[i] = (uint32_t)pd_arena.index_of(vec[i]); }
     for (uint32_t i = 0; i < J; ++i) prio_out[i] = pd_arena.owners[i]->priority;
     return 0;
+  } catch (const std::exception& e) { g_last_error = e.what(); return -2; }
+}
+
+// ---- AccountMetaContainer::CheckAndMallocMetaResource over the commit loop (JobScheduler.cpp:1492-1573) -----------
+// Same arguments as oracle/crane_oracle.cpp's ora_run_limits.  reason_out[i] = index of the reference's reason STRING
+// in the table of include/crane_gpu/run_limits.h (first match: the reference returns "QosCpuResourceLimit" both for
+// max_cpus_per_user, code 2, and for a max_tres* cpu count, code 5 — compare strings, tests/test_ref_pin.py does).
+namespace {
+const char* const kLimitReasonStr[16] = {"", "QosEntryNotFound", "QosCpuResourceLimit", "QosJobsResourceLimit", "QosWallTimeLimit",
+                                         "QosCpuResourceLimit", "QosMemResourceLimit", "QosGresResourceLimit", "PartitionEntryNotFound",
+                                         "UserPartitionJobsLimit", "UserPartitionWallTimeLimit", "AccPartitionJobsLimit",
+                                         "AccPartitionWallTimeLimit", "PartitionCpuResourceLimit", "PartitionMemResourceLimit",
+                                         "PartitionGresResourceLimit"};
+std::string user_name(uint32_t u) { char b[16]; snprintf(b, sizeof b, "u%06u", u); return b; }
+std::string acct_name(uint32_t a) { char b[16]; snprintf(b, sizeof b, "c%06u", a); return b; }
+
+ResourceView limit_view(const Layout& L, const cns_tres& t) {   // a LIMIT: entries exist where the masks say so
+  ResourceView v;
+  v.SetCpuCount(cpu_t::from_raw_value(t.cpu_raw));
+  v.SetMemoryBytes(t.mem);
+  for (uint32_t n = 0; n < CNS_MAX_GRES_NAMES; ++n)
+    if (t.name_mask >> n & 1) v.GetGresMap()[gres_name(n)].total = t.name_total[n];
+  for (uint32_t g = 0; g < L.g.num_classes; ++g)
+    if ((t.class_mask >> g & 1) && (t.name_mask >> L.g.class_name[g] & 1))
+      v.GetGresMap()[gres_name(L.g.class_name[g])].specified[gres_type(g)] = t.class_count[g];
+  return v;
+}
+Ctld::MetaResource meta_of(const Layout& L, const cns_usage* u) {   // a USAGE record: entries for the non-zero counts
+  Ctld::MetaResource m;
+  if (!u) return m;
+  m.resource.SetCpuCount(cpu_t::from_raw_value(u->cpu_raw));
+  m.resource.SetMemoryBytes(u->mem);
+  for (uint32_t n = 0; n < CNS_MAX_GRES_NAMES; ++n)
+    if (u->name_total[n]) m.resource.GetGresMap()[gres_name(n)].total = u->name_total[n];
+  for (uint32_t g = 0; g < L.g.num_classes; ++g)
+    if (u->class_count[g]) m.resource.GetGresMap()[gres_name(L.g.class_name[g])].specified[gres_type(g)] = u->class_count[g];
+  m.jobs_count = u->jobs_count;
+  m.wall_time = absl::Seconds(u->wall_sec);
+  return m;
+}
+void put_usage(cns_usage* out, uint8_t* ex, size_t i, const Ctld::MetaResource* m) {
+  if (ex) ex[i] = m ? 1 : 0;
+  if (!out) return;
+  cns_usage u{};
+  if (m) {
+    u.cpu_raw = m->resource.GetCpuCount().raw_value();
+    u.mem = m->resource.GetMemoryBytes();
+    u.wall_sec = absl::ToInt64Seconds(m->wall_time);
+    u.jobs_count = m->jobs_count;
+    for (const auto& [name, gc] : m->resource.GetGresMap()) {
+      u.name_total[idx_of(name)] = gc.total;
+      for (const auto& [type, cnt] : gc.specified) u.class_count[idx_of(type)] = cnt;
+    }
+  }
+  out[i] = u;
+}
+}  // namespace
+
+int ora_run_limits(const cns_gres_layout* gl, const cns_limit_tables* t, const cns_limit_job_soa* jobs,
+                   const cns_placement_soa* pl, uint8_t* reason_out, uint64_t* num_admitted, cns_usage* uq, uint8_t* uqe,
+                   cns_usage* up, uint8_t* upe, cns_usage* aq, uint8_t* aqe, cns_usage* ap, uint8_t* ape, cns_usage* qu) {
+  using namespace Ctld;
+  try {
+    Layout L; L.g = *gl;
+    const uint32_t Q = t->num_qos, Pn = t->num_partitions;
+    auto ex = [](const uint8_t* e, size_t i) { return !e || e[i]; };
+    auto us = [&](const cns_usage* u, size_t i) { return meta_of(L, u ? u + i : nullptr); };
+    for (uint64_t i = 0; i < jobs->num_jobs; ++i)
+      if (jobs->user[i] >= t->num_users || jobs->user_acct[i] >= t->num_user_accts || jobs->account[i] >= t->num_accounts ||
+          jobs->qos[i] >= Q || jobs->partition[i] >= Pn)
+        return -1;
+    // ---- g_account_manager: QoS, accounts (parents, partition limits), users (per-account partition limits) ----
+    AccountManager mgr;
+    for (uint32_t q = 0; q < Q; ++q) {
+      const cns_qos_limits& s = t->qos[q];
+      auto qos = std::make_unique<Qos>();
+      qos->max_jobs_per_user = s.max_jobs_per_user; qos->max_jobs_per_account = s.max_jobs_per_account; qos->max_jobs = s.max_jobs;
+      qos->max_cpus_per_user = cpu_t::from_raw_value(s.max_cpus_per_user_raw);
+      qos->max_wall = absl::Seconds(s.max_wall_sec);
+      qos->max_tres = limit_view(L, s.max_tres);
+      qos->max_tres_per_user = limit_view(L, s.max_tres_per_user);
+      qos->max_tres_per_account = limit_view(L, s.max_tres_per_account);
+      mgr.qos_map[qos_name(q)] = std::move(qos);
+    }
+    auto part_limit = [&](uint32_t idx) {
+      PartitionResourceLimit pl_;
+      pl_.max_tres = limit_view(L, t->part_limits[idx].max_tres);
+      pl_.max_jobs = t->part_limits[idx].max_jobs;
+      pl_.max_wall = absl::Seconds(t->part_limits[idx].max_wall_sec);
+      return pl_;
+    };
+    for (uint32_t a = 0; a < t->num_accounts; ++a) {
+      auto acc = std::make_unique<Account>();
+      acc->name = acct_name(a);
+      if (t->acct_parent[a] != CNS_LIM_NONE) acc->parent_account = acct_name(t->acct_parent[a]);
+      if (t->acct_part_limit)
+        for (uint32_t p = 0; p < Pn; ++p)
+          if (t->acct_part_limit[(size_t)a * Pn + p] != CNS_LIM_NONE)
+            acc->partition_to_limit_map.emplace(part_name(p), part_limit(t->acct_part_limit[(size_t)a * Pn + p]));
+      mgr.account_map.emplace(acct_name(a), std::move(acc));
+    }
+    for (uint32_t u = 0; u < t->num_users; ++u) {
+      auto user = std::make_unique<User>();
+      user->name = user_name(u);
+      mgr.user_map.emplace(user_name(u), std::move(user));
+    }
+    // the (user, account) pair of a user_acct index arrives with the jobs
+    std::vector<uint32_t> user_of_ua(t->num_user_accts, CNS_LIM_NONE), acct_of_ua(t->num_user_accts, CNS_LIM_NONE);
+    AccountMetaContainer amc;
+    for (uint32_t u = 0; u < t->num_users; ++u) {
+      MetaResourceStat& st = amc.m_user_meta_map_[user_name(u)];
+      for (uint32_t q = 0; q < Q; ++q)
+        if (ex(t->user_qos_exists, (size_t)u * Q + q)) st.qos_to_resource_map[qos_name(q)] = us(t->user_qos, (size_t)u * Q + q);
+    }
+    for (uint64_t i = 0; i < jobs->num_jobs; ++i) {
+      const uint32_t ua = jobs->user_acct[i];
+      if (user_of_ua[ua] != CNS_LIM_NONE) continue;
+      user_of_ua[ua] = jobs->user[i]; acct_of_ua[ua] = jobs->account[i];
+      User& user = *mgr.user_map.at(user_name(jobs->user[i]));
+      User::AttrsInAccount& attrs = user.account_to_attrs_map[acct_name(jobs->account[i])];
+      MetaResourceStat& st = amc.m_user_meta_map_[user_name(jobs->user[i])];
+      for (uint32_t p = 0; p < Pn; ++p) {
+        if (t->user_part_limit && t->user_part_limit[(size_t)ua * Pn + p] != CNS_LIM_NONE)
+          attrs.partition_to_limit_map.emplace(part_name(p), part_limit(t->user_part_limit[(size_t)ua * Pn + p]));
+        if (ex(t->user_part_exists, (size_t)ua * Pn + p))
+          st.account_to_partition_to_resource_map[acct_name(jobs->account[i])][part_name(p)] = us(t->user_part, (size_t)ua * Pn + p);
+      }
+    }
+    for (uint32_t a = 0; a < t->num_accounts; ++a) {
+      MetaResourceStat& st = amc.m_account_meta_map_[acct_name(a)];
+      for (uint32_t q = 0; q < Q; ++q)
+        if (ex(t->acct_qos_exists, (size_t)a * Q + q)) st.qos_to_resource_map[qos_name(q)] = us(t->acct_qos, (size_t)a * Q + q);
+      for (uint32_t p = 0; p < Pn; ++p)
+        if (ex(t->acct_part_exists, (size_t)a * Pn + p)) st.partition_to_resource_map[part_name(p)] = us(t->acct_part, (size_t)a * Pn + p);
+    }
+    for (uint32_t q = 0; q < Q; ++q) amc.m_qos_meta_map_[qos_name(q)] = us(t->qos_usage, q);
+    g_account_manager = &mgr;
+
+    // ---- the commit loop, pending-vector order (JobScheduler.cpp:1492) ---------------------------------
+    uint64_t adm = 0;
+    for (uint64_t i = 0; i < jobs->num_jobs; ++i) {
+      const uint64_t s = jobs->select_index ? jobs->select_index[i] : i;
+      if (pl->reason[s] != CNS_REASON_NONE || (jobs->skip && jobs->skip[i])) {   // :1507-1510 and the `continue`s before :1565
+        reason_out[i] = CNS_LIM_NOT_CANDIDATE;
+        continue;
+      }
+      JobInCtld j;
+      j.job_id = (job_id_t)i;
+      j.username = user_name(jobs->user[i]);
+      j.account = acct_name(jobs->account[i]);
+      for (uint32_t a = jobs->account[i]; a != CNS_LIM_NONE; a = t->acct_parent[a]) j.account_chain.push_back(acct_name(a));
+      j.qos = qos_name(jobs->qos[i]);
+      j.partition_id = part_name(jobs->partition[i]);
+      j.time_limit = absl::Seconds(jobs->time_limit_sec[i]);
+      PdJobInScheduler pd(&j);
+      for (uint64_t r = pl->place_offsets[s]; r < pl->place_offsets[s + 1]; ++r) {
+        if (pl->node_idx[r] == CNS_NODE_NONE) continue;
+        MaskRes m;
+        m.cpu = pl->cpu_raw[r]; m.mem = pl->mem[r]; m.clo = pl->core_lo[r]; m.chi = pl->core_hi[r]; m.gres = pl->gres[r];
+        m.c2 = pl->core_w2 ? pl->core_w2[r] : 0; m.c3 = pl->core_w3 ? pl->core_w3[r] : 0;
+        pd.allocated_res.AddResourceInNode(node_name(pl->node_idx[r]), to_ref(L, m));
+      }
+      const std::expected<void, std::string> result = amc.CheckAndMallocMetaResource(pd);   // AccountMetaContainer.cpp:180-224
+      int code = 0;
+      if (!result) {
+        code = -1;
+        for (int c = 1; c < 16; ++c)
+          if (result.error() == kLimitReasonStr[c]) { code = c; break; }
+        if (code < 0) throw std::runtime_error("reason outside include/crane_gpu/run_limits.h: " + result.error());
+      }
+      reason_out[i] = (uint8_t)code;
+      adm += code == 0;
+    }
+    if (num_admitted) *num_admitted = adm;
+
+    // ---- usage after the pass, shapes as in cns_limit_tables -------------------------------------------
+    auto find2 = [](const auto& map, const std::string& k) -> const MetaResource* {
+      auto it = map.find(k);
+      return it == map.end() ? nullptr : &it->second;
+    };
+    for (uint32_t u = 0; u < t->num_users; ++u) {
+      const MetaResourceStat& st = amc.m_user_meta_map_.find(user_name(u))->second;
+      for (uint32_t q = 0; q < Q; ++q) put_usage(uq, uqe, (size_t)u * Q + q, find2(st.qos_to_resource_map, qos_name(q)));
+    }
+    for (uint32_t x = 0; x < t->num_user_accts; ++x)
+      for (uint32_t p = 0; p < Pn; ++p) {
+        const MetaResource* m = nullptr;
+        MetaResource tmp;
+        if (user_of_ua[x] != CNS_LIM_NONE) {
+          const MetaResourceStat& st = amc.m_user_meta_map_.find(user_name(user_of_ua[x]))->second;
+          auto a = st.account_to_partition_to_resource_map.find(acct_name(acct_of_ua[x]));
+          if (a != st.account_to_partition_to_resource_map.end()) m = find2(a->second, part_name(p));
+        } else if (ex(t->user_part_exists, (size_t)x * Pn + p)) {
+          tmp = us(t->user_part, (size_t)x * Pn + p);
+          m = &tmp;
+        }
+        put_usage(up, upe, (size_t)x * Pn + p, m);
+      }
+    for (uint32_t a = 0; a < t->num_accounts; ++a) {
+      const MetaResourceStat& st = amc.m_account_meta_map_.find(acct_name(a))->second;
+      for (uint32_t q = 0; q < Q; ++q) put_usage(aq, aqe, (size_t)a * Q + q, find2(st.qos_to_resource_map, qos_name(q)));
+      for (uint32_t p = 0; p < Pn; ++p) put_usage(ap, ape, (size_t)a * Pn + p, find2(st.partition_to_resource_map, part_name(p)));
+    }
+    for (uint32_t q = 0; q < Q; ++q) put_usage(qu, nullptr, q, &amc.m_qos_meta_map_.find(qos_name(q))->second);
+    g_account_manager = nullptr;
+    return 0;
+  } catch (const std::exception& e) { g_last_error = e.what(); Ctld::g_account_manager = nullptr; return -2; }
+}
+const char* ref_limit_reason_string(int code) { return code >= 0 && code < 16 ? kLimitReasonStr[code] : "?"; }
+
+// ---- JobInCtld::SchedulePendingSteps (CtldPublicDefs.cpp:2038-2159), structs of include/crane_gpu/steps.h ----------
+// The reference walks step_res_avail_.EachNodeResMap(), an unordered_map.  In the canonical flavour that map is ordered
+// by the craned id string; the ids here are zero-padded, so the walk is in ascending dense node index — the order
+// include/crane_gpu/steps.h defines.  (libcrane_ref_hash.so walks in libstdc++'s hash order: only for cases where
+// the order cannot matter.)
+int ora_schedule_steps(const cns_gres_layout* gl, const cns_step_job_soa* jb, const cns_step_soa* st, cns_step_result_soa* out, int) {
+  using namespace Ctld;
+  try {
+    Layout L; L.g = *gl;
+    auto nname = [](uint32_t n) { char b[16]; snprintf(b, sizeof b, "n%09u", n); return std::string(b); };
+    uint64_t po = 0, to = 0;
+    for (uint32_t s = 0; s < st->num_steps; ++s) {
+      out->place_offsets[s] = po; out->task_offsets[s] = to;
+      po += st->node_num[s]; to += st->ntasks[s];
+    }
+    out->place_offsets[st->num_steps] = po; out->task_offsets[st->num_steps] = to;
+    for (uint64_t i = 0; i < po; ++i) {
+      out->node_idx[i] = CNS_NODE_NONE; out->node_ntasks[i] = 0; out->node_cpu_raw[i] = 0; out->node_mem[i] = 0;
+      out->node_core_lo[i] = 0; out->node_core_hi[i] = 0; out->node_gres[i] = 0;
+      if (out->node_core_w2) out->node_core_w2[i] = 0;
+      if (out->node_core_w3) out->node_core_w3[i] = 0;
+    }
+    for (uint64_t i = 0; i < to; ++i) {
+      out->task_node[i] = CNS_NODE_NONE; out->task_cpu_raw[i] = 0; out->task_mem[i] = 0; out->task_core_lo[i] = 0;
+      out->task_core_hi[i] = 0; out->task_gres[i] = 0;
+      if (out->task_core_w2) out->task_core_w2[i] = 0;
+      if (out->task_core_w3) out->task_core_w3[i] = 0;
+    }
+    for (uint32_t s = 0; s < st->num_steps; ++s) out->scheduled[s] = 0;
+    for (uint32_t jx = 0; jx < jb->num_jobs; ++jx) {
+      JobInCtld job;
+      job.job_id = jx;
+      for (uint32_t n = jb->node_offsets[jx]; n < jb->node_offsets[jx + 1]; ++n) {
+        MaskRes m;
+        m.cpu = jb->avail_cpu_raw[n]; m.mem = jb->avail_mem[n]; m.clo = jb->avail_core_lo[n];
+        m.chi = jb->avail_core_hi ? jb->avail_core_hi[n] : 0; m.gres = jb->avail_gres ? jb->avail_gres[n] : 0;
+        m.c2 = jb->avail_core_w2 ? jb->avail_core_w2[n] : 0; m.c3 = jb->avail_core_w3 ? jb->avail_core_w3[n] : 0;
+        job.step_res_avail_.EachNodeResMap()[nname(jb->node_idx[n])] = to_ref(L, m);   // SetStepResAvail, CtldPublicDefs.h:1140
+      }
+      std::vector<std::unique_ptr<CommonStepInCtld>> steps;
+      for (uint32_t s = jb->step_offsets[jx]; s < jb->step_offsets[jx + 1]; ++s) {
+        auto sp = std::make_unique<CommonStepInCtld>();
+        sp->job_id = jx; sp->step_id = s;
+        sp->req_node_res_view = view_of(L, st->node_cpu_raw ? st->node_cpu_raw[s] : 0, st->node_mem ? st->node_mem[s] : 0,
+                                        st->node_gres_total ? st->node_gres_total + (size_t)s * CNS_MAX_GRES_NAMES : nullptr,
+                                        st->node_gres_spec ? st->node_gres_spec + (size_t)s * CNS_MAX_GRES_CLASSES : nullptr);
+        sp->req_task_res_view = view_of(L, st->task_cpu_raw[s], st->task_mem[s],
+                                        st->task_gres_total ? st->task_gres_total + (size_t)s * CNS_MAX_GRES_NAMES : nullptr,
+                                        st->task_gres_spec ? st->task_gres_spec + (size_t)s * CNS_MAX_GRES_CLASSES : nullptr);
+        sp->node_num = st->node_num[s]; sp->ntasks = st->ntasks[s];
+        sp->ntasks_per_node_min = st->ntasks_per_node_min[s]; sp->ntasks_per_node_max = st->ntasks_per_node_max[s];
+        if (st->incl_offsets) for (uint32_t k = st->incl_offsets[s]; k < st->incl_offsets[s + 1]; ++k) sp->included_nodes.insert(nname(st->incl_nodes[k]));
+        if (st->excl_offsets) for (uint32_t k = st->excl_offsets[s]; k < st->excl_offsets[s + 1]; ++k) sp->excluded_nodes.insert(nname(st->excl_nodes[k]));
+        job.m_steps_[s] = sp.get();
+        job.pending_step_ids_.push(s);   // AddStep, CtldPublicDefs.h:1108-1113
+        steps.push_back(std::move(sp));
+      }
+      std::vector<CommonStepInCtld*> scheduled;
+      job.SchedulePendingSteps(&scheduled);
+      for (CommonStepInCtld* sp : scheduled) {
+        const uint32_t s = sp->step_id;
+        out->scheduled[s] = 1;
+        // pop order of the candidate queue = order of the first task id handed to each node (:2109-2128)
+        std::map<task_id_t, std::string> first_task;
+        for (const auto& [cid, tasks] : sp->craned_task_map) first_task[*tasks.begin()] = cid;
+        uint64_t p = out->place_offsets[s];
+        for (const auto& [tid, cid] : first_task) {
+          const MaskRes m = from_ref(sp->allocated_res.At(cid));
+          out->node_idx[p] = (uint32_t)strtoul(cid.c_str() + 1, nullptr, 10);
+          out->node_ntasks[p] = (uint32_t)sp->craned_task_map.at(cid).size();
+          out->node_cpu_raw[p] = m.cpu; out->node_mem[p] = m.mem; out->node_core_lo[p] = m.clo; out->node_core_hi[p] = m.chi; out->node_gres[p] = m.gres;
+          if (out->node_core_w2) out->node_core_w2[p] = m.c2;
+          if (out->node_core_w3) out->node_core_w3[p] = m.c3;
+          ++p;
+        }
+        for (const auto& [cid, tasks] : sp->craned_task_map)
+          for (task_id_t tid : tasks) {
+            const uint64_t q = out->task_offsets[s] + tid;
+            const MaskRes m = from_ref(sp->task_res_map.at(tid));
+            out->task_node[q] = (uint32_t)strtoul(cid.c_str() + 1, nullptr, 10);
+            out->task_cpu_raw[q] = m.cpu; out->task_mem[q] = m.mem; out->task_core_lo[q] = m.clo; out->task_core_hi[q] = m.chi; out->task_gres[q] = m.gres;
+            if (out->task_core_w2) out->task_core_w2[q] = m.c2;
+            if (out->task_core_w3) out->task_core_w3[q] = m.c3;
+          }
+      }
+      for (uint32_t n = jb->node_offsets[jx]; n < jb->node_offsets[jx + 1]; ++n) {
+        const MaskRes m = from_ref(job.step_res_avail_.At(nname(jb->node_idx[n])));
+        out->avail_cpu_raw[n] = m.cpu; out->avail_mem[n] = m.mem; out->avail_core_lo[n] = m.clo; out->avail_core_hi[n] = m.chi; out->avail_gres[n] = m.gres;
+        if (out->avail_core_w2) out->avail_core_w2[n] = m.c2;
+        if (out->avail_core_w3) out->avail_core_w3[n] = m.c3;
+      }
+    }
+    return 0;
+  } catch (const crane_ref::RefAssertion& e) { g_last_error = std::string("reference assertion failed: ") + e.what(); return -3;
   } catch (const std::exception& e) { g_last_error = e.what(); return -2; }
 }
 

@@ -142,6 +142,9 @@ constexpr Time InfiniteFuture() { return Time::FromDuration(InfiniteDuration());
 constexpr Time InfinitePast() { return Time::FromDuration(-InfiniteDuration()); }
 constexpr Time UnixEpoch() { return Time(); }
 constexpr Time FromUnixSeconds(int64_t s) { return Time::FromDuration(Seconds(s)); }
+// absl::Now(): the step scheduler stamps a step's start time with it (CtldPublicDefs.cpp:2041); the harness sets the clock.
+inline int64_t g_ref_now_sec = 0;
+inline Time Now() { return FromUnixSeconds(g_ref_now_sec); }
 constexpr int64_t ToUnixSeconds(Time t) {
   // abseil floors; whole-second inputs only on this path
   const Duration d = t.since_epoch();

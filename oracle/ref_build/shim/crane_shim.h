@@ -45,6 +45,7 @@ inline bool g_asserts_enabled = true;
   } while (false)
 
 #include "absl_shim.h"
+#include "expected_shim.h"
 #include "fpm/fixed.hpp"
 
 // crane/Logger.h:62-150
@@ -78,7 +79,7 @@ class GresMap;
 class ResourceInNodeV3;
 class ResourceV3;
 class ResourceView;
-enum JobStatus { Pending, Running, Completed, Failed, ExceedTimeLimit, Cancelled, OutOfMemory, Deadline };
+enum JobStatus { Pending, Running, Completed, Failed, ExceedTimeLimit, Cancelled, OutOfMemory, Deadline, Configuring };
 enum class PreemptType { PREEMPT_NONE = 0, PREEMPT_QOS = 1 };
 struct JobToCtld {
   struct License {};

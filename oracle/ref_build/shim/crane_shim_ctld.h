@@ -10,6 +10,8 @@
 
 namespace Ctld {
 
+struct CommonStepInCtld;
+
 // src/CraneCtld/CtldPublicDefs.h: JobInCtld, as read by the constructors of
 // RnJobInScheduler / PdJobInScheduler (JobScheduler.h:75-90,143-170)
 struct JobInCtld {
@@ -48,6 +50,15 @@ struct JobInCtld {
   const ResourceV3& AllocatedRes() const { return allocated_res; }
   const crane::grpc::JobToCtld& JobToCtld() const { return job_to_ctld; }
   const std::string& Username() const { return username; }
+
+  // step scheduler (CtldPublicDefs.h:899-900,825,1115-1123; SchedulePendingSteps is the sliced definition,
+  // CtldPublicDefs.cpp:2038-2159)
+  std::queue<step_id_t> pending_step_ids_;
+  ResourceV3 step_res_avail_;
+  absl::Time deadline_time;
+  std::map<step_id_t, CommonStepInCtld*> m_steps_;
+  CommonStepInCtld* GetStep(step_id_t step) const;
+  uint32_t SchedulePendingSteps(std::vector<CommonStepInCtld*>* scheduled_steps);
 };
 
 // src/CraneCtld/CtldPublicDefs.h:92-242 (fields read by the slices)
@@ -142,14 +153,65 @@ struct CranedMetaContainer {
 };
 inline CranedMetaContainer* g_meta_container = nullptr;
 
-// src/CraneCtld/Account/AccountDefs.h:27-49 (fields read at JobScheduler.cpp:6530-6537)
+// src/CraneCtld/Account/AccountDefs.h:27-49 (fields read at JobScheduler.cpp:6530-6537 and by the run-limit
+// checks, AccountMetaContainer.cpp:508-540,542-670,985-1025)
 struct Qos {
   bool deleted{false};
   std::vector<std::string> preempt;
+  uint32_t max_jobs_per_user{std::numeric_limits<uint32_t>::max()};
+  uint32_t max_jobs_per_account{std::numeric_limits<uint32_t>::max()};
+  cpu_t max_cpus_per_user;
+  uint32_t max_jobs{std::numeric_limits<uint32_t>::max()};
+  absl::Duration max_wall;
+  ResourceView max_tres;
+  ResourceView max_tres_per_user;
+  ResourceView max_tres_per_account;
 };
+// src/CraneCtld/Account/AccountDefs.h:163-175
+struct PartitionResourceLimit {
+  ResourceView max_tres;
+  ResourceView max_tres_per_job;
+  uint32_t max_jobs{std::numeric_limits<uint32_t>::max()};
+  uint32_t max_submit_jobs{std::numeric_limits<uint32_t>::max()};
+  absl::Duration max_wall{absl::ZeroDuration()};
+  absl::Duration max_wall_duration_per_job;
+};
+using PartitionToLimitMap = std::unordered_map<std::string, PartitionResourceLimit>;   // AccountDefs.h:177-178
+// src/CraneCtld/Account/AccountDefs.h:180-207 (fields read at AccountMetaContainer.cpp:958-969)
+struct Account {
+  std::string name;
+  std::string parent_account;
+  PartitionToLimitMap partition_to_limit_map;
+};
+// src/CraneCtld/Account/AccountDefs.h:209-262 (fields read at AccountMetaContainer.cpp:921-933)
+struct User {
+  struct AttrsInAccount {
+    PartitionToLimitMap partition_to_limit_map;
+    bool blocked{false};
+  };
+  using AccountToAttrsMap = std::unordered_map<std::string, AttrsInAccount>;
+  std::string name;
+  AccountToAttrsMap account_to_attrs_map;
+};
+// src/CraneCtld/Account/AccountManager.h: GetAllQosInfo (JobScheduler.cpp:6530) and the three look-ups of
+// CheckAndMallocMetaResource (AccountMetaContainer.cpp:185,193,201).  The real ones return shared-lock pointers.
 struct AccountManager {
   std::map<std::string, std::unique_ptr<Qos>> qos_map;
+  std::map<std::string, std::unique_ptr<User>> user_map;
+  std::unordered_map<std::string, std::unique_ptr<Account>> account_map;   // AccountMetaContainer::AccountRawMap
+  bool have_accounts{true};
   RefPtrLike<std::map<std::string, std::unique_ptr<Qos>>> GetAllQosInfo() { return {&qos_map}; }
+  RefPtrLike<const User> GetExistedUserInfo(const std::string& name) {
+    auto it = user_map.find(name);
+    return {it == user_map.end() ? nullptr : it->second.get()};
+  }
+  RefPtrLike<const std::unordered_map<std::string, std::unique_ptr<Account>>> GetAllAccountInfo() {
+    return {have_accounts ? &account_map : nullptr};
+  }
+  RefPtrLike<const Qos> GetExistedQosInfo(const std::string& name) {
+    auto it = qos_map.find(name);
+    return {it == qos_map.end() || it->second->deleted ? nullptr : it->second.get()};
+  }
 };
 inline AccountManager* g_account_manager = nullptr;
 

@@ -10,11 +10,14 @@
 // tests/ prove Lit == Mask on random inputs and pin both against the reference's own
 // known-answer vectors (test/Utilities/dedicated_resource_test.cpp:27-251).
 //
-// PARITY STATUS: the reference cannot be compiled in this environment (C++23 stdlib,
-// protobuf/abseil/fpm fetched from the network — SURVEY.md §8c), and it ships no test
-// for GetFeasibleResourceInNode / Ckmin / NodeSelect.  Apart from the slot-set vectors
-// named above, this oracle is therefore "parity unpinned": it is a line-by-line
-// restatement, reviewed against the cited lines, not a checked build of the reference.
+// PARITY STATUS: PINNED.  The reference's own build system cannot run here (C++23 stdlib,
+// protobuf/abseil/fpm fetched from the network — SURVEY.md §8c) and it ships no test for
+// GetFeasibleResourceInNode / Ckmin / NodeSelect, but the path's own sources compile:
+// oracle/_ref (oracle/ref_build/, built by `make -C oracle _ref` from slices of
+// /root/reference cut at build time) is the reference's code, and tests/test_ref_pin.py +
+// tests/test_ref_pin_limits_steps.py hold every restatement under oracle/ to it, exactly
+// (6 000 random algebra calls, whole NodeSelect cycles incl. final costs and time maps,
+// priorities, run-limit admission, step scheduling).
 //
 // Third-party arithmetic restated here: fpm::fixed<int64_t,__int128,8>
 // (github.com/MikeLankamp/fpm @ b46537fe9697e1a598ac8a26f8ae43d8b286ac3f,

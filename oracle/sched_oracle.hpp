@@ -1,5 +1,6 @@
-// ORACLE — TEST INFRASTRUCTURE ONLY (see res_algebra.hpp header). "Parity unpinned":
-// the reference ships no test of NodeSelect; this file restates it line by line.
+// ORACLE — TEST INFRASTRUCTURE ONLY (see res_algebra.hpp header).  PINNED: the reference ships no test of
+// NodeSelect; this file restates it line by line and tests/test_ref_pin.py holds it to the reference's own
+// SchedulerAlgo::NodeSelect compiled from /root/reference (oracle/_ref).
 //
 // CPU restatement of CraneCtld's node-selection cycle, templated on the resource algebra:
 //   SchedulerAlgo::NodeSelect                 src/CraneCtld/JobScheduler.cpp:6507-6836

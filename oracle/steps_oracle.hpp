@@ -3,8 +3,10 @@
 // Restatement of JobInCtld::SchedulePendingSteps (src/CraneCtld/CtldPublicDefs.cpp:2038-2159), statement by statement,
 // with the reference's std::priority_queue (so libstdc++'s heap decides ties) and the resource algebra of
 // res_algebra.hpp.  One canonicalisation: the job's nodes are walked in the order given (the reference walks an
-// unordered_map).  PARITY UNPINNED: the reference has no test of this function; tests/test_steps.py holds hand-derived
-// known answers.
+// unordered_map).  PINNED (round 4): the reference has no test of this function, but the function itself runs here:
+// oracle/_ref compiles CtldPublicDefs.cpp:2038-2159 (sliced at build time by oracle/ref_build/extract.py) and
+// tests/test_ref_pin_limits_steps.py holds this restatement to it (scheduled flags, nodes in pop order, every task's
+// allocation, step_res_avail_ afterwards) on the hand-derived scenarios of tests/test_steps.py and 15 random cases.
 #pragma once
 #include <queue>
 #include <set>

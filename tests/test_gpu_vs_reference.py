@@ -112,3 +112,74 @@ def test_engine_vs_reference_code_shared_nodes(built, seed, lay):
         _same(f"overlap {seed} {lay}", c, j, eng, got, pyoracle.select(c, j, now, running=run, backend="ref"))
     finally:
         eng.close()
+
+
+# ---- run-limit admission and step scheduler: the engine against the reference's own AccountMetaContainer /
+# ---- JobInCtld::SchedulePendingSteps (oracle/_ref, round 4; tests/test_ref_pin_limits_steps.py pins the oracles) ----
+def _limits_vs_reference(tag, cluster, jobs, now, lay, t, lj):
+    from cranesched_amd import limits as lm
+    eng = _engine(cluster)
+    try:
+        got = eng.node_select(now, jobs)
+        eng.set_run_limits(t)
+        reason, adm = eng.apply_run_limits(lj)
+        usage = eng.usage()
+        # the reference admits over the ENGINE's placements: nothing of the restated oracle is in the loop
+        r_ref, a_ref, u_ref = pyoracle.run_limits(lay, t, lj, got, backend="ref")
+        s_gpu, s_ref = [lm.LIMIT_REASON_STR[int(x)] for x in reason], [lm.LIMIT_REASON_STR[int(x)] for x in r_ref]
+        bad = [i for i in range(len(s_gpu)) if s_gpu[i] != s_ref[i]]
+        assert not bad, f"{tag}: job {bad[0]}: engine {s_gpu[bad[0]]!r}, reference {s_ref[bad[0]]!r}"
+        assert adm == a_ref
+        for f in usage.__dataclass_fields__:
+            assert np.array_equal(getattr(usage, f), getattr(u_ref, f)), f"{tag}: usage table {f} differs from the reference's"
+        return reason
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("mode", ["parallel", "ordered"])
+@pytest.mark.parametrize("seed,tight", [(1, True), (2, True), (3, True), (4, False), (7, True), (8, True)])
+def test_engine_run_limits_vs_reference_code_random(built, monkeypatch, seed, tight, mode):
+    from tests.test_run_limits import random_limit_case
+    if mode == "ordered":
+        monkeypatch.setenv("CNS_LIMITS_MODE", "seq")
+    else:
+        monkeypatch.delenv("CNS_LIMITS_MODE", raising=False)
+    cluster, jobs, now, lay, t, lj = random_limit_case(seed, J=900, N=128, tight=tight)
+    r = _limits_vs_reference(f"limits {seed}", cluster, jobs, now, lay, t, lj)
+    if tight:
+        assert set(np.unique(r)) - {0, 255}
+
+
+def test_engine_run_limits_vs_reference_code_hand_derived(built):
+    from tests import test_run_limits as trl
+    for name in sorted(trl.SCENARIOS):
+        specs, keys, ua, t, exp, extra = trl.SCENARIOS[name]()
+        cluster, lay = trl._cluster()
+        jobs = kat.jobs(specs)
+        r = _limits_vs_reference(name, cluster, jobs, trl.NOW, lay, t, trl._limjobs(keys, ua, jobs.time_limit_sec))
+        assert list(r) == exp, name
+
+
+def test_engine_run_limits_vs_reference_code_c4_accounts(built):
+    """BASELINE config 4's account / QoS tables, caps tightened until they bind, scaled queue."""
+    c, j, now = synth.make_config("C4", J=8000, N=1024, P=8)
+    tables, lj = synth.make_limits("C4", c, j)
+    tables.qos["max_jobs_per_user"][:] = 3
+    tables.qos["max_tres_per_account"]["cpu_raw"][:] = 200 * 256
+    r = _limits_vs_reference("C4 accounts", c, j, now, c.gres, tables, lj)
+    assert 0 < int((r == 0).sum()) < int((r != 255).sum())
+
+
+@pytest.mark.parametrize("seed,wide", [(0, False), (1, False), (2, False), (10, True), (11, True)])
+def test_engine_steps_vs_reference_code(built, seed, wide):
+    from tests.test_steps import random_step_case
+    lay, jobs, steps = random_step_case(seed, J=300, wide=wide)
+    eng = _engine(kat.cluster([4], layout=lay))
+    try:
+        got, _ = eng.schedule_steps(jobs, steps)
+        ref = pyoracle.schedule_steps(lay, jobs, steps, backend="ref")
+        assert got.diff(ref) is None, f"steps {seed}: engine differs from the reference's SchedulePendingSteps: {got.diff(ref)}"
+        assert 0 < got.scheduled[:steps.num_steps].sum() < steps.num_steps
+    finally:
+        eng.close()
