@@ -6,11 +6,13 @@ src/CraneCtld/JobScheduler.cpp:6507-6836, bracket :1439-1447) over the synthetic
 1 M pending jobs x 64 k nodes in 8 disjoint partitions, CPU+mem+GRES requests,
 with the job table and node snapshot already resident in HBM when the timed region starts.
 At N > 1 the queue is job-sharded by partition (rank r owns partitions p % N == r; partitions that share nodes
-stay together) and each step ends with one RCCL all-gather of the packed placement buffers; total work is fixed
-("strong").  A partition is ONE sequential chain; k_wide spreads its per-job node scan over 16 more workgroups of the SAME
-XCD (exchange through that XCD's L2, ~0.4 us per job), so 8 partitions occupy 136 of 256 CUs and run concurrently on one
-GPU: more GPUs do not add chains and the curve is flat by construction (an exchange over xGMI would cost more per job
-than the whole chain does now).
+stay together; a rank's snapshot lists only its own partitions) and each step ends with one RCCL all-gather of the packed
+placement buffers; total work is fixed ("strong").  A partition is ONE sequential chain; k_wide spreads its per-job node scan
+over 16 more workgroups of the SAME XCD (exchange through that XCD's L2, ~0.4 us per job), so C4's 8 partitions occupy 136 of
+256 CUs and run concurrently on one GPU: more GPUs do not add chains there and the curve is flat by construction (an exchange
+over xGMI would cost more per job than the whole chain does now).  --config C4p64 / C4p256 (the same cluster cut
+into 64 / 256 partitions) are the layouts on which more GPUs DO add chains: the engine sizes its launch by the partitions that
+have pending jobs on the rank, so fewer partitions per rank get the wider k_wide build.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -93,12 +95,15 @@ def main():
         cluster, jobs, now, running = synth.make_loaded(args.config, J=args.jobs, N=args.nodes)
     else:
         cluster, jobs, now = synth.make_config(args.config, J=args.jobs, N=args.nodes)
-    my_jobs, my_idx = sharding.shard(cluster, jobs, rank, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))
+    # a rank's snapshot lists only ITS partitions (node indices stay global): time maps, costs and the launch — hence the k_wide
+    # build, sized by the partitions that have pending jobs — are those of the shard (sharding.shard_cluster)
+    my_cluster, my_jobs, my_idx = sharding.shard_cluster(cluster, jobs, rank, world) if world > 1 else (cluster, jobs, np.arange(jobs.num_jobs))
 
     eng = GpuNodeSelector(device=local_rank)
-    eng.set_nodes(cluster)
-    if running is not None:
-        eng.set_running(running)       # (every rank holds the whole running set: allocations on other ranks' nodes are inert)
+    eng.set_nodes(my_cluster)
+    if running is not None:            # the running jobs on this rank's nodes (every job of make_running lives inside one partition)
+        eng.set_running(running if world == 1 else synth.running_of_partitions(
+            cluster, running, sharding.partition_plan(cluster.num_partitions, world, sharding.partition_groups(cluster))[rank]))
     eng.upload_jobs(my_jobs)           # inputs resident in HBM before the timed region
     h2d_ms = eng.timing()["h2d_ms"]
 
@@ -160,7 +165,7 @@ def main():
         host = gather_out.cpu().numpy()
         shards = []
         for rk in range(world):
-            sj, sidx = sharding.shard(cluster, jobs, rk, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))
+            sj, sidx = sharding.shard(cluster, jobs, rk, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))   # (partition ids are not in the packed buffer)
             shards.append((sharding.unpack_results(host[rk * pad:(rk + 1) * pad], sj, cluster.wide_cores), sidx))
         merged = sharding.merge(jobs, shards)
         eng1 = GpuNodeSelector(device=local_rank)

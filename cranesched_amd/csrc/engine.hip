@@ -108,6 +108,7 @@ struct cns_engine {
   i64 last_now = 0;
   std::vector<u32> eng_members;                 // engine partition -> number of caller partitions it runs (> 1: they share nodes)
   std::vector<u32> job_part;                    // pending job (queue index) -> engine partition (kNone: not given to the ordered loop)
+  std::vector<u64> part_jobs;                   // engine partition -> jobs of the uploaded queue that reach its ordered loop
   std::vector<uint8_t> pre_part;                // cycle with preemption: engine partition has a pending job whose qos may preempt
   DevBuf d_params2, d_pmap_a, d_pmap_b, d_wide_last;
   bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
@@ -847,6 +848,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   std::vector<u64> pj_off(h->P + 1, 0);
   for (u32 p = 0; p < h->P; ++p) pj_off[p + 1] = pj_off[p] + pj_cnt[p + 1];
   const u64 Jg = pj_off[h->P];
+  h->part_jobs.assign(pj_cnt.begin() + 1, pj_cnt.end());
   // grouped by partition in queue order: one u32 per job on the host; the 64-dword records are packed on the
   // device from the caller's arrays (k_pack_jobs)
   std::vector<u64> cur(pj_off.begin(), pj_off.end() - 1);
@@ -937,6 +939,10 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   return CNS_OK;
 }
 
+// device buffers of a cycle with preemption (cns_engine::d_pre)
+enum { B_QPOFF, B_QP, B_PJQOS, B_PJQP, B_PJPRIO, B_PJREC0, B_PJK, B_PJEND, B_RNJOB, B_ENTSLOT, B_ENTGONE, B_RJQOS, B_RJQP,
+       B_RJSTART, B_RJEND, B_RJPRE, B_RJOFF, B_RJENT, B_HEAD, B_RECNEXT, B_RECORIG, B_RECSLOT, B_RECGONE, B_MISC };
+
 // One pass of the cycle on the device.  *fault_code: the device fault it ended with (0: none).
 static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
   *fault_code = 0;
@@ -952,6 +958,16 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
   if (h->wide_cores) HIPCHK(h, hipMemsetAsync(rb + h->ro.c2, 0, h->ro.total - h->ro.c2, h->stream));   // core ids 128..255 of the records
   HIPCHK(h, hipMemcpyAsync(rb + h->ro.reason, h->d_reason_init.p, J, hipMemcpyDeviceToDevice, h->stream));
   HIPCHK(h, hipMemsetAsync(h->d_fault.p, 0, 16, h->stream));
+  if (h->pre_active) {
+    // The mutable preemption state starts every PASS empty, not every call: the retry after a k_wide protocol fault re-runs the
+    // k_select partitions too, and a second pass over a first pass's per-slot job lists (slot_head / rec_next), hidden
+    // candidates (ent_gone / rec_gone) and preempted pairs (out_cnt) would loop on a self-linked list or report pairs twice.
+    DevBuf* B = h->d_pre;
+    HIPCHK(h, hipMemsetAsync(B[B_ENTGONE].p, 0, std::max<size_t>(h->ent_job.size(), 1), h->stream));
+    HIPCHK(h, hipMemsetAsync(B[B_HEAD].p, 0xFF, (size_t)std::max<u32>(h->S, 1) * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(B[B_RECGONE].p, 0, pl, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->pre_params.out_cnt, 0, 16, h->stream));
+  }
   HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, ((size_t)h->P * (32 + 8) + 2048) * sizeof(u64), h->stream));   // cycle counters + the always-on protocol counters
   HIPCHK(h, h->d_params.ensure(sizeof(KParams)));
   HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
@@ -965,22 +981,33 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
     // in a cycle with preemption, the partitions that have a pending job whose qos may preempt anything (TryPreempt_ returns at
     // JobScheduler.cpp:6384-6385 for every other job).  Everything else runs on k_wide / k_pipe IN THE SAME CYCLE, side by
     // side on a second stream: partitions with disjoint node sets never interact (:6723-6732,6746-6761).
+    // Only partitions that HAVE pending jobs get a scheduler (the reference builds NodeStates and a LocalScheduler only for
+    // the partitions some pending job names, JobScheduler.cpp:6516-6530,6571-6573,6723-6732): the launch, and with it the choice
+    // of the k_wide build (workgroups per partition), is sized by the busy partitions, not by the snapshot.
     std::vector<u32> pa, pb;
     u32 npa = 0, npb = 0;
     for (u32 p = 0; p < h->P; ++p) {
+      if (p >= h->part_jobs.size() || h->part_jobs[p] == 0) continue;
       const bool sel = (p < h->eng_members.size() && h->eng_members[p] > 1) || (h->pre_active && p < h->pre_part.size() && h->pre_part[p]);
       const u32 np = h->part_off[p + 1] - h->part_off[p];
       if (sel) { pb.push_back(p); npb = std::max(npb, np); } else { pa.push_back(p); npa = std::max(npa, np); }
     }
     std::string err, name_a, name_b;
     if (pb.empty() || pa.empty()) {
-      // one launch over all partitions (identity map)
+      // one launch: over all partitions (identity map) when every one is busy, else over the busy ones (part_map)
       const bool plain = pb.empty();
-      LaunchCtx L{h->P, h->max_np, h->stream, h->d_params.as<KParams>(), 0u};
+      const std::vector<u32>& pm = plain ? pa : pb;
+      const bool ident = pm.size() == h->P;
+      LaunchCtx L{(u32)pm.size(), plain ? npa : npb, h->stream, h->d_params.as<KParams>(), 0u};
       KParams K1 = K;
       if (plain) { K1.general_only = 0; K1.pre = PreParams{}; }
-      if (K1.general_only != K.general_only) HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K1, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
+      if (!ident) {
+        if (int rc = upload(h, h->d_pmap_a, pm)) return rc;
+        K1.part_map = h->d_pmap_a.as<u32>(); K1.launch_parts = (u32)pm.size();
+      }
+      if (K1.general_only != K.general_only || !ident) HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K1, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
       if (const int rc = launch_one(h, K1, L, plain, &h->last_kernel, &err)) return fail(h, rc, err);
+      if (!ident) h->last_kernel += " on " + std::to_string(pm.size()) + " busy of " + std::to_string(h->P) + " partitions";
     } else {
       if (int rc = upload(h, h->d_pmap_a, pa)) return rc;
       if (int rc = upload(h, h->d_pmap_b, pb)) return rc;
@@ -1247,8 +1274,6 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   const u32 pool_nodes = 1u << 16;
   const u32 cand_cap = (u32)std::max<u64>(4096, std::min<u64>((u64)R + J + 1, (64ull << 20) / std::max<u32>(h->P, 1)));
   const u32 out_cap = (u32)std::min<u64>(4 * (J + R) + 64, 1u << 28);
-  enum { B_QPOFF, B_QP, B_PJQOS, B_PJQP, B_PJPRIO, B_PJREC0, B_PJK, B_PJEND, B_RNJOB, B_ENTSLOT, B_ENTGONE, B_RJQOS, B_RJQP,
-         B_RJSTART, B_RJEND, B_RJPRE, B_RJOFF, B_RJENT, B_HEAD, B_RECNEXT, B_RECORIG, B_RECSLOT, B_RECGONE, B_MISC };
   DevBuf* B = h->d_pre;
   if (int rc = upload(h, B[B_QPOFF], qp_off)) return rc;
   if (int rc = upload(h, B[B_QP], qp)) return rc;
@@ -1258,7 +1283,7 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   HIPCHK(h, B[B_PJREC0].ensure(std::max<u64>(J, 1) * 4)); HIPCHK(h, B[B_PJK].ensure(std::max<u64>(J, 1) * 4)); HIPCHK(h, B[B_PJEND].ensure(std::max<u64>(J, 1) * 8));
   { std::vector<u32> ej = h->ent_job, es = h->ent_slot; if (ej.empty()) { ej.push_back(0); es.push_back(0); }
     if (int rc = upload(h, B[B_RNJOB], ej)) return rc; if (int rc = upload(h, B[B_ENTSLOT], es)) return rc; }
-  HIPCHK(h, B[B_ENTGONE].ensure(std::max<u32>(A, 1))); HIPCHK(h, hipMemsetAsync(B[B_ENTGONE].p, 0, std::max<u32>(A, 1), h->stream));
+  HIPCHK(h, B[B_ENTGONE].ensure(std::max<u32>(A, 1)));   // (zeroed at the start of every pass: run_resident_once)
   if (int rc = upload(h, B[B_RJQOS], rj_qos)) return rc;
   if (int rc = upload(h, B[B_RJQP], rj_qprio)) return rc;
   if (int rc = upload(h, B[B_RJSTART], rj_start)) return rc;
@@ -1266,15 +1291,14 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   if (int rc = upload(h, B[B_RJPRE], rj_pre)) return rc;
   if (int rc = upload(h, B[B_RJOFF], rj_off)) return rc;
   if (int rc = upload(h, B[B_RJENT], rj_ent)) return rc;
-  HIPCHK(h, B[B_HEAD].ensure((size_t)std::max<u32>(h->S, 1) * 4)); HIPCHK(h, hipMemsetAsync(B[B_HEAD].p, 0xFF, (size_t)std::max<u32>(h->S, 1) * 4, h->stream));
+  HIPCHK(h, B[B_HEAD].ensure((size_t)std::max<u32>(h->S, 1) * 4));
   HIPCHK(h, B[B_RECNEXT].ensure(places * 4)); HIPCHK(h, B[B_RECORIG].ensure(places * 4)); HIPCHK(h, B[B_RECSLOT].ensure(places * 4));
-  HIPCHK(h, B[B_RECGONE].ensure(places)); HIPCHK(h, hipMemsetAsync(B[B_RECGONE].p, 0, places, h->stream));
+  HIPCHK(h, B[B_RECGONE].ensure(places));
   // one block for: segment-tree pools | candidate lists | chosen lists | output counter | output pairs
   const size_t pool_b = (size_t)h->P * pool_nodes * sizeof(PreNode), cand_b = (size_t)h->P * cand_cap * 4;
   const size_t off_cand = align16(pool_b), off_chosen = off_cand + align16(cand_b), off_cnt = off_chosen + align16(cand_b), off_out = off_cnt + 16;
   HIPCHK(h, B[B_MISC].ensure(off_out + (size_t)out_cap * 8));
   char* misc = B[B_MISC].as<char>();
-  HIPCHK(h, hipMemsetAsync(misc + off_cnt, 0, 16, h->stream));
   PreParams& Q = h->pre_params;
   Q = PreParams{};
   Q.enabled = 1; Q.num_qos = pre->num_qos;

@@ -61,6 +61,26 @@ def shard(cluster: abi.Cluster, jobs: abi.Jobs, rank: int, world: int):
     return synth.select_partitions(cluster, jobs, parts)
 
 
+def shard_cluster(cluster: abi.Cluster, jobs: abi.Jobs, rank: int, world: int):
+    """(snapshot of this rank, its jobs, their indices in the global queue): the node table keeps every node (node indices stay
+    global, so placements need no translation) but lists only this rank's partitions, renumbered 0.. in ascending order, and the
+    jobs' partition ids are renumbered with them.  The rank's engine then holds time maps, costs and a launch only for its own
+    partitions (the reference builds NodeStates only for partitions with pending jobs, JobScheduler.cpp:6571-6573)."""
+    parts = partition_plan(cluster.num_partitions, world, partition_groups(cluster))[rank]
+    mine, idx = synth.select_partitions(cluster, jobs, parts)
+    local = np.full(cluster.num_partitions, 0xFFFFFFFF, np.uint32)
+    local[np.asarray(parts, np.int64)] = np.arange(len(parts), dtype=np.uint32)
+    po, pn = [0], []
+    for p in parts:
+        pn.append(np.asarray(cluster.part_nodes[cluster.part_offsets[p]:cluster.part_offsets[p + 1]], np.uint32))
+        po.append(po[-1] + len(pn[-1]))
+    import dataclasses
+    sub = dataclasses.replace(cluster, part_offsets=np.asarray(po, np.uint32),
+                              part_nodes=np.concatenate(pn) if pn else np.zeros(0, np.uint32))
+    mine.partition = local[mine.partition.astype(np.int64)]
+    return sub, mine, idx
+
+
 def _align16(x: int) -> int:
     return (x + 15) & ~15
 

@@ -27,6 +27,10 @@ CONFIGS = {
     # C4's cluster and job mix cut into 64 partitions of 1 024 nodes: the configuration on which more GPUs DO add chains
     # (one GPU: 64 chains on k_pipe, one CU each; 8 GPUs: 8 chains per GPU on k_wide x64) — bench.py --config C4p64, DESIGN.md 6
     "C4p64": dict(idx=6, J=1_000_000, N=65_536, P=64, gres=True, Q=600, LM=24),
+    # ... and into 256 partitions of 256 nodes: beyond k_wide's 80 partitions on ONE GPU (k_pipe, one workgroup per partition);
+    # 4 GPUs: 64 busy partitions each -> k_wide x8, 8 GPUs: 32 each -> k_wide x16 (the launch is sized by the partitions that
+    # have pending jobs on that rank) — bench.py --config C4p256, DESIGN.md 6
+    "C4p256": dict(idx=7, J=1_000_000, N=65_536, P=256, gres=True, Q=600, LM=24),
 }
 
 

@@ -22,3 +22,58 @@ def test_rccl_allgather_path_on_one_gpu(built, config, jobs, nodes):
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["allgather_merged_identical_to_single_gpu"] is True
     assert line["config"]["selection_kernel"].startswith("k_wide")
+
+
+def test_launch_is_sized_by_the_partitions_that_have_pending_jobs(built):
+    """The reference builds a LocalScheduler only for partitions some pending job names (JobScheduler.cpp:6516-6530,6571-6573).
+    A 100-partition snapshot with 5 busy partitions must run the widest k_wide build (x64: up to 8 partitions), not k_pipe
+    (what 100 partitions would get), with results identical to the oracle's."""
+    import numpy as np
+    from cranesched_amd import synth
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    from tests import helpers
+    c, j, now = synth.make_config("C4", J=60000, N=12800, P=100)
+    busy = np.array([3, 17, 42, 64, 99], np.uint32)
+    j.partition = busy[j.partition % 5]
+    ref = pyoracle.select(c, j, now)
+    eng = GpuNodeSelector(device=0)
+    try:
+        eng.set_nodes(c)
+        got = eng.node_select(now, j)
+        k = eng.last_kernel()
+        assert k.startswith("k_wide") and " x64" in k and "5 busy of 100 partitions" in k, k
+        helpers.assert_same(eng, got, ref, c, tag="5 busy of 100")
+        # ... and the next cycle, with every partition busy, is back on the launch over all of them
+        c2, j2, now2 = synth.make_config("C4", J=60000, N=12800, P=100)
+        got2 = eng.node_select(now2, j2)
+        assert "busy of" not in eng.last_kernel() and eng.last_kernel().startswith("k_pipe"), eng.last_kernel()
+        helpers.assert_same(eng, got2, pyoracle.select(c2, j2, now2), c2, tag="100 busy of 100")
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("world,expect", [(1, "k_pipe"), (4, " x8"), (8, " x16")])
+def test_c4p256_shards_get_the_k_wide_build_the_plan_predicts(built, world, expect):
+    """C4p256 (256 partitions of 256 nodes): what each rank of an N-GPU run executes — its own snapshot (sharding.shard_cluster),
+    its own jobs — run here rank after rank on ONE GPU, merged like bench.py's all-gather, compared with the single-engine run.
+    One GPU: 256 partitions -> k_pipe; 4 GPUs: 64 per rank -> k_wide x8; 8 GPUs: 32 per rank -> k_wide x16."""
+    import numpy as np
+    from cranesched_amd import sharding, synth
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    c, j, now = synth.make_config("C4p256", J=60000)
+    ref = pyoracle.select(c, j, now)
+    shards, kernels = [], set()
+    for rk in range(world):
+        sub, mine, idx = sharding.shard_cluster(c, j, rk, world) if world > 1 else (c, j, np.arange(j.num_jobs))
+        eng = GpuNodeSelector(device=0)
+        try:
+            eng.set_nodes(sub)
+            shards.append((eng.node_select(now, mine), idx))
+            kernels.add(eng.last_kernel())
+        finally:
+            eng.close()
+    assert all(expect in k for k in kernels), kernels
+    merged = sharding.merge(j, shards) if world > 1 else shards[0][0]
+    assert merged.diff(ref.placements) is None

@@ -412,3 +412,36 @@ def test_python_restatement_on_preemption_with_reservations(built, seed):
     ref = pyoracle.select(c, j, now, running=run, reservations=rv, preempt=pre)
     cyc, out, lists = run_pyref_preempt(c, j, now, run, pre, rv=rv)
     compare_preempt(f"resv preempt {seed}", c, j, ref, cyc, out, lists)
+
+
+@pytest.mark.gpu
+def test_engine_split_preempt_cycle_survives_a_k_wide_retry(built, monkeypatch):
+    """A cycle with preemption is split: partitions whose pending jobs may preempt run on k_select, the rest on k_wide.  A
+    k_wide protocol fault re-runs the WHOLE cycle — k_select's partitions too — so the mutable preemption state (per-slot job
+    lists, hidden candidates, the preempted-pair counter) must start every pass empty, not every call (a second
+    pass over the first pass's lists walked a self-linked list).  Partition 0's jobs get a QoS that preempts nothing, the hook
+    makes its leader scanner drop one exchange; the result must be the oracle's, preempted lists included."""
+    from oracle import pyoracle
+    c, j, now, run, pre = random_preempt_case(777, N=24, J=900, P=3, running=30)
+    pd_qos = np.where(j.partition == 0, 0, pre.pd_qos).astype(np.uint32)
+    qprio = np.array([10, 20, 30])
+    pre = abi.Preempt([[], [0], [1, 0]], pre.pd_job_id, pd_qos, qprio[pd_qos], pre.pd_priority, pre.rn_job_id, pre.rn_qos,
+                      pre.rn_qos_priority, pre.rn_start_sec, preempting=pre.preempting)
+    assert int((j.partition == 0).sum()) > 200
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    assert sum(len(x) for x in ref.preempt_out.lists()) > 0, "the case must preempt something"
+    monkeypatch.setenv("CNS_SELECT_KERNEL", "wide")
+    monkeypatch.setenv("CNS_WIDE_NO_RETRY", "0")
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        assert eng.last_kernel().startswith("k_wide") and " + k_select" in eng.last_kernel(), eng.last_kernel()
+        compare_engine("split cycle", c, j, ref, eng, pl, po)
+        monkeypatch.setenv("CNS_WIDE_INJECT_STALL", "137")
+        pl, po = eng.node_select_preempt(now, j, pre)
+        assert "retry after" in eng.last_kernel() and not eng.last_kernel().startswith("k_wide"), eng.last_kernel()
+        compare_engine("split cycle, retried", c, j, ref, eng, pl, po)
+        monkeypatch.delenv("CNS_WIDE_INJECT_STALL")
+        pl, po = eng.node_select_preempt(now, j, pre)
+        compare_engine("split cycle, after", c, j, ref, eng, pl, po)
+    finally:
+        eng.close()

@@ -34,13 +34,17 @@ def _worker(rank, world, port, q, cfg=("C4", 6000, 512, 8)):
     from cranesched_amd import sharding, synth
     from oracle import pyoracle
     name, J, N, P = cfg
-    running = None
+    running = all_running = None
     if name in synth.LOADED:   # the same queue on a cluster that already runs jobs: every rank holds the whole running set
         cluster, jobs, now, running = synth.make_loaded(name, J=J, N=N, P=P)
+        all_running = running
     else:
         cluster, jobs, now = synth.make_config(name, J=J, N=N, P=P)
-    mine, idx = sharding.shard(cluster, jobs, rank, world)
-    r = pyoracle.select(cluster, mine, now, running=running)
+    # what bench.py gives a rank: a snapshot that lists only its partitions (renumbered), its jobs, its running jobs
+    sub, mine, idx = sharding.shard_cluster(cluster, jobs, rank, world)
+    if running is not None:
+        running = synth.running_of_partitions(cluster, running, sharding.partition_plan(cluster.num_partitions, world, sharding.partition_groups(cluster))[rank])
+    r = pyoracle.select(sub, mine, now, running=running)
     buf = pack(r.placements, mine)
     sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([len(buf)], dtype=torch.int64))
@@ -56,15 +60,17 @@ def _worker(rank, world, port, q, cfg=("C4", 6000, 512, 8)):
         raw = out[rk * pad:(rk + 1) * pad].numpy()
         shards.append((sharding.unpack_results(raw, sj), sidx))
     merged = sharding.merge(jobs, shards)
-    ref = pyoracle.select(cluster, jobs, now, running=running)
+    ref = pyoracle.select(cluster, jobs, now, running=all_running)
     q.put((rank, merged.diff(ref.placements)))
     dist.destroy_process_group()
 
 
 # C4: 8 partitions (rank r owns partitions p % world == r); C4p64: the same cluster cut into 64 partitions of 1 024 nodes — the
 # configuration on which more GPUs add chains (bench.py --config C4p64); C4r: the loaded cluster
+# C4p256: 256 partitions (one GPU: k_pipe; 4 / 8 GPUs: 64 / 32 busy partitions per rank -> k_wide x8 / x16)
 @pytest.mark.parametrize("world,cfg", [(2, ("C4", 6000, 512, 8)), (2, ("C4p64", 8000, 1024, 64)), (4, ("C4p64", 8000, 1024, 64)),
-                                       (2, ("C4r", 6000, 512, 8))])
+                                       (2, ("C4r", 6000, 512, 8)), (2, ("C4p256", 12000, 2048, 256)), (4, ("C4p256", 12000, 2048, 256)),
+                                       (8, ("C4p256", 12000, 2048, 256))])
 def test_shard_allgather_merge(world, cfg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
