@@ -149,6 +149,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     tm = eng.timing()
+    wide_counters = eng.wide_stats() if eng.last_kernel().startswith("k_wide") and my_cluster.num_partitions == cluster.num_partitions else None
     ordered = torch.tensor([tm["jobs_ordered"]], device=dev, dtype=torch.int64)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
@@ -263,6 +264,9 @@ def main():
                        "rank0_outcome": {"start_now": int((r == 0).sum()), "backfilled": int((r == 1).sum()),
                                          "resource": int((r == 2).sum())},
                        "kernel_ms": {kernel: avg_sel_ms, "k_init_nodes+k_prep_jobs+fill": float(np.mean(init_ms))},
+                       # k_wide's always-on protocol counters of the last timed step (who waited for whom; partitions whose workgroups
+                       # were NOT all on one XCD: their exchange runs ~2.5x slower — a placement the launch cannot force, only report)
+                       "wide_protocol_counters": wide_counters,
                        "h2d_job_table_ms": h2d_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_prof,

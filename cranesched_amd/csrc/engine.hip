@@ -124,7 +124,7 @@ struct cns_engine {
   u32 R = 0;                                    // running jobs of the last cns_set_running
   std::vector<u32> ent_job, ent_slot;           // slot-grouped allocation entry d -> running job, slot
   std::vector<i64> ent_end;                     // ... -> end time as handed in
-  std::vector<void*> host_bufs;                 // page-locked host buffers handed out by cns_host_alloc
+  std::set<void*> host_bufs;                    // page-locked host buffers handed out by cns_host_alloc
   bool pre_active = false;                      // the next run is a cycle with preemption (general path of k_select only)
   PreParams pre_params{};
   DevBuf d_pre[24];
@@ -968,7 +968,7 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
     HIPCHK(h, hipMemsetAsync(B[B_RECGONE].p, 0, pl, h->stream));
     HIPCHK(h, hipMemsetAsync(h->pre_params.out_cnt, 0, 16, h->stream));
   }
-  HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, ((size_t)h->P * (32 + 8) + 2048) * sizeof(u64), h->stream));   // cycle counters + the always-on protocol counters
+  HIPCHK(h, hipMemsetAsync(h->d_prof.p, 0, ((size_t)h->P * (32 + 16) + 2048) * sizeof(u64), h->stream));   // cycle counters + the always-on protocol counters
   HIPCHK(h, h->d_params.ensure(sizeof(KParams)));
   HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
   if (h->S) hipLaunchKernelGGL(k_init_nodes, dim3((h->S + 255) / 256), dim3(256), 0, h->stream, h->d_params.as<KParams>());
@@ -1143,7 +1143,7 @@ int cns_host_alloc(cns_handle* h, uint64_t bytes, void** out) {
   HIPCHK(h, hipSetDevice(h->device));
   void* p = nullptr;
   HIPCHK(h, hipHostMalloc(&p, (size_t)std::max<uint64_t>(bytes, 1), hipHostMallocDefault));
-  h->host_bufs.push_back(p);
+  h->host_bufs.insert(p);
   *out = p;
   return CNS_OK;
 }
@@ -1151,7 +1151,7 @@ int cns_host_alloc(cns_handle* h, uint64_t bytes, void** out) {
 int cns_host_free(cns_handle* h, void* p) {
   if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_host_free: null handle");
   if (!p) return CNS_OK;
-  auto it = std::find(h->host_bufs.begin(), h->host_bufs.end(), p);
+  auto it = h->host_bufs.find(p);
   if (it == h->host_bufs.end()) return fail(h, CNS_ERR_INVALID_ARG, "cns_host_free: not a buffer of cns_host_alloc on this handle");
   h->host_bufs.erase(it);
   HIPCHK(h, hipSetDevice(h->device));
@@ -1392,11 +1392,11 @@ int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity) {
   if (!h->have_run) return fail(h, CNS_ERR_STATE, "cns_debug_get_prof before a successful run");
 #endif
   HIPCHK(h, hipSetDevice(h->device));
-  // behind them (from index 32 * P): 8 always-on protocol counters per partition of k_wide (every build; wide_kernel.inc kWs*)
+  // behind them (from index 32 * P): 16 always-on protocol counter slots per partition of k_wide (every build; wide_kernel.inc kWs*)
 #ifdef CNS_DEBUG_FLUSH_LOG
-  const size_t n = std::min<size_t>((size_t)h->P * (32 + 8) + 2048, capacity);   // + the flush log of partition 0 (diagnostics build)
+  const size_t n = std::min<size_t>((size_t)h->P * (32 + 16) + 2048, capacity);   // + the flush log of partition 0 (diagnostics build)
 #else
-  const size_t n = std::min<size_t>((size_t)h->P * (32 + 8), capacity);
+  const size_t n = std::min<size_t>((size_t)h->P * (32 + 16), capacity);
 #endif
   HIPCHK(h, hipMemcpy(out, h->d_prof.p, n * sizeof(u64), hipMemcpyDeviceToHost));
   return CNS_OK;

@@ -80,7 +80,7 @@ class GpuNodeSelector:
             raise EngineError(rc, msg.decode() if msg else "")
         self._cluster = None
         self._jobs = None
-        self._pinned = []   # arrays over cns_host_alloc buffers (cns_destroy releases the memory: do not touch them after close())
+        self._pinned = {}   # address -> array over a cns_host_alloc buffer (cns_destroy releases the memory: do not touch them after close())
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, rc: int):
@@ -166,7 +166,7 @@ class GpuNodeSelector:
         if self._h:
             self._L.cns_destroy(self._h)
             self._h = C.c_void_p()
-            self._pinned = []
+            self._pinned = {}   # (cns_destroy released them: arrays handed out by pinned() are dead from here on)
 
     def __del__(self):
         try:
@@ -208,29 +208,60 @@ class GpuNodeSelector:
 
     # page-locked host buffers (cns_host_alloc): the caller's job table and result arrays at full PCIe rate
     def pinned(self, n: int, dtype, fill=None) -> np.ndarray:
-        """A numpy array of n elements in page-locked host memory of this handle (released by close())."""
+        """A numpy array of n elements in page-locked host memory of this handle.  It lives until free_pinned(a) or close();
+        after close() the memory is gone and the array must not be touched."""
         dt = np.dtype(dtype)
         p = C.c_void_p()
         self._check(self._L.cns_host_alloc(self._h, C.c_uint64(max(n, 1) * dt.itemsize), C.byref(p)))
         a = np.frombuffer((C.c_char * (max(n, 1) * dt.itemsize)).from_address(p.value), dtype=dt)
-        self._pinned.append(a)
+        self._pinned[p.value] = a
         if fill is not None:
             a[:] = fill
         return a
 
-    def pinned_jobs(self, jobs: abi.Jobs) -> abi.Jobs:
-        """The same job table with every array in page-locked memory (what an adapter that packs into such buffers hands over)."""
+    def free_pinned(self, a: np.ndarray):
+        """Gives a buffer of pinned() (or any view of it) back (cns_host_free)."""
+        base = a
+        while isinstance(base.base, np.ndarray):
+            base = base.base
+        ptr = base.ctypes.data
+        if ptr not in self._pinned:
+            raise EngineError(-1, "free_pinned: not a buffer of pinned() on this handle")
+        del self._pinned[ptr]
+        self._check(self._L.cns_host_free(self._h, C.c_void_p(ptr)))
+
+    def pinned_jobs(self, jobs: abi.Jobs, into: "abi.Jobs | None" = None) -> abi.Jobs:
+        """The same job table with every array in page-locked memory (what an adapter that packs into such buffers hands over).
+        Every call WITHOUT `into` allocates a fresh set of buffers: call it once and refill per cycle with
+        `pj = eng.pinned_jobs(jobs, into=pj)` — arrays of `into` whose size still fits are overwritten in place, the others are
+        freed and allocated anew; free_pinned_jobs(pj) gives a set back."""
         import dataclasses
         kw = {}
         for f in dataclasses.fields(jobs):
             v = getattr(jobs, f.name)
+            old = getattr(into, f.name) if into is not None else None
             if v is None:
+                if old is not None:
+                    self.free_pinned(old)
                 kw[f.name] = None
                 continue
+            if old is not None and old.dtype == v.dtype and old.size == v.size:
+                old.reshape(-1)[:] = v.reshape(-1)
+                kw[f.name] = old.reshape(v.shape)
+                continue
+            if old is not None:
+                self.free_pinned(old)
             a = self.pinned(v.size, v.dtype)
             a[:v.size] = v.reshape(-1)
             kw[f.name] = a[:v.size].reshape(v.shape)
         return abi.Jobs(**kw)
+
+    def free_pinned_jobs(self, pj: abi.Jobs):
+        import dataclasses
+        for f in dataclasses.fields(pj):
+            v = getattr(pj, f.name)
+            if v is not None:
+                self.free_pinned(v)
 
     def pinned_placements(self, jobs: abi.Jobs) -> abi.Placements:
         """Result arrays in page-locked memory, to be reused across cycles: node_select(now, jobs, out=...)."""
@@ -289,16 +320,16 @@ class GpuNodeSelector:
         return out.reshape(P, 32)
 
     WIDE_STATS = ("looks_empty", "looks_consumed", "leader_polls_ring_full", "stops", "flushes", "redo_with_exclusion",
-                  "serial_jobs", "resource_verdicts")
+                  "serial_jobs", "resource_verdicts", "partitions_straddling_xcds")
 
     def wide_stats(self) -> dict:
         """Always-on protocol counters of k_wide's last run, summed over the partitions (every build; zeros for the other
         kernels): who waited for whom (supervisor looks without / with a decision, leader polls in front of a full ring) and
         how often the chain was broken (stops, flushes) and mended (redo with an excluded candidate, serial jobs, "Resource")."""
         P = self._cluster.num_partitions
-        out = np.zeros(P * 40, np.uint64)
-        self._check(self._L.cns_debug_get_prof(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(P * 40)))
-        st = out[P * 32:].reshape(P, 8).sum(axis=0)
+        out = np.zeros(P * 48, np.uint64)
+        self._check(self._L.cns_debug_get_prof(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(P * 48)))
+        st = out[P * 32:].reshape(P, 16).sum(axis=0)
         return {k: int(v) for k, v in zip(self.WIDE_STATS, st)}
 
     def timeline(self, node: int, cap: int = 1100):

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cstring>
 #include <iterator>
+#include <exception>
 #include <thread>
 
 #include "../../include/crane_gpu/node_select.h"
@@ -78,7 +79,7 @@ struct GpuNodeSelectionAlgo::Impl {
   // dense form (node indices, core / GRES masks) is kept per job id across cycles; a cycle costs one lookup per
   // running job instead of one string lookup + set -> mask conversion per allocated node.  Entries of jobs that did
   // not show up in a cycle are dropped; a new snapshot (new dense indices) drops everything.
-  struct AllocRec { uint32_t node; int64_t cpu; uint64_t mem, lo, hi, g, w2, w3; };   // lo / hi / w2 / w3: core ids 0..255
+  struct AllocRec { uint32_t node; int64_t cpu; uint64_t mem, lo, hi, g, w2, w3; bool ovf = false; };   // lo / hi / w2 / w3: core ids 0..255; ovf: it also holds an id >= 256
   struct PackedAlloc {
     uint32_t resv;
     uint64_t gen;
@@ -148,14 +149,22 @@ struct GpuNodeSelectionAlgo::Impl {
   void parallel_for(size_t n, F&& body) const {
     const size_t T = (size_t)std::max(1, host_threads);
     if (T == 1 || n < 4096) { body((size_t)0, n); return; }
+    // an exception on a worker (bad_alloc: the write-back is allocator-bound) is carried to the caller after every thread has
+    // been joined — a thread that lets one escape, or a joinable thread that is destroyed, would terminate CraneCtld
     std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(T);
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
     const size_t chunk = (n + T - 1) / T;
+    auto guarded = [&body, &err](size_t slot, size_t a, size_t b) {
+      try { body(a, b); } catch (...) { err[slot] = std::current_exception(); }
+    };
     for (size_t t = 1; t < T; ++t) {
       const size_t a = std::min(n, t * chunk), b = std::min(n, a + chunk);
-      if (a < b) th.emplace_back([&body, a, b] { body(a, b); });
+      if (a < b) th.emplace_back(guarded, t, a, b);
     }
-    body((size_t)0, std::min(n, chunk));
+    guarded(0, (size_t)0, std::min(n, chunk));
     for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
   }
   PinCtx pin;   // (pin.h = h once the engine exists)
   struct PackedJobs {
@@ -272,13 +281,15 @@ struct GpuNodeSelectionAlgo::Impl {
   std::vector<job_id_t> m_removed, m_touched, m_info;   // events since the last pack
   size_t mirror_full_packs = 0, mirror_patch_packs = 0;
   void pack_rec(MirrorRec& r) {
+    if (r.packed.ovf) { --mirror_ovf; r.packed.ovf = false; }
     auto it = node_idx.find(r.craned);
     r.known = it != node_idx.end();
     if (!r.known) return;
     r.packed.node = it->second;
     r.packed.cpu = r.res.cpu_set.cpu_count.raw;
     r.packed.mem = r.res.memory_bytes;
-    core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi, r.packed.w2, r.packed.w3);
+    r.packed.ovf = core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi, r.packed.w2, r.packed.w3);
+    if (r.packed.ovf) ++mirror_ovf;
     r.packed.g = gres_mask(r.res.gres);
   }
   void repack_mirror() {   // after a new snapshot
@@ -377,6 +388,7 @@ struct GpuNodeSelectionAlgo::Impl {
     r_src.clear();        // the mirror has no RnJobInScheduler objects: a cycle with preemption must be refused, never served from an
     r_src_valid = false;  // earlier explicit cycle's (freed) pointers that happen to match in number
     if (!mirror_packed || mirror_full || !pack_from_mirror_patch()) pack_from_mirror_full();
+    packed_from_mirror = true;
     mirror_packed = true;
     mirror_full = false;
     m_removed.clear(); m_touched.clear(); m_info.clear();
@@ -401,6 +413,8 @@ struct GpuNodeSelectionAlgo::Impl {
     r_src.clear();
     r_src_valid = true;
     mirror_packed = false;   // (r_* now hold the caller's vector)
+    packed_from_mirror = false;
+    run_overflow = false;
     r_off.assign(1, 0);
     ++alloc_gen;
     PackedAlloc scratch;
@@ -427,7 +441,7 @@ struct GpuNodeSelectionAlgo::Impl {
           a.node = it->second;
           a.cpu = res.cpu_set.cpu_count.raw;
           a.mem = res.memory_bytes;
-          core_masks(res.cpu_set.core_ids, a.lo, a.hi, a.w2, a.w3);
+          a.ovf = core_masks(res.cpu_set.core_ids, a.lo, a.hi, a.w2, a.w3);
           a.g = gres_mask(res.gres);
           d.recs.push_back(a);
         }
@@ -438,6 +452,7 @@ struct GpuNodeSelectionAlgo::Impl {
       r_end.push_back(rn->end_time);
       r_src.push_back(rn.get());
       for (const AllocRec& a : pa->recs) {
+        run_overflow = run_overflow || a.ovf;
         r_node.push_back(a.node); r_cpu.push_back(a.cpu); r_mem.push_back(a.mem);
         r_lo.push_back(a.lo); r_hi.push_back(a.hi); r_g.push_back(a.g); r_w2.push_back(a.w2); r_w3.push_back(a.w3);
       }
@@ -468,18 +483,25 @@ struct GpuNodeSelectionAlgo::Impl {
   // core ids as four 64-bit masks (ids 0..255, ABI 3); an id >= 256 does not fit the engine's model: it is RECORDED (core_overflow) and the
   // snapshot / cycle is refused — silently dropping it would make integer requests fail the `popc < n` test, or come back
   // without core ids, where ResourceView::GetFeasibleResourceInNode (PublicHeader.cpp:528-538) fits them
-  bool core_overflow = false;   // a core id >= 256 was met by the pack in progress (snapshot, running jobs or steps)
-  bool snap_overflow = false;   // ... by the SNAPSHOT: it stays refused until the next SetClusterSnapshot
+  // The overflow is a property of the RECORD it was found in, kept with the record: a cached or mirrored allocation that holds such an
+  // id refuses every cycle it is part of (not only the cycle that first packed it), and a step pass that meets one does not leak
+  // into the next NodeSelect.
+  bool snap_overflow = false;   // the SNAPSHOT lists such an id: it stays refused until the next SetClusterSnapshot
   std::string snap_error;       // why the last snapshot was refused (kept for the NodeSelect calls that follow it)
-  void core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi, uint64_t& w2, uint64_t& w3) {
+  bool run_overflow = false;    // pack_running: some running job of the vector just packed (cached records included) holds one
+  size_t mirror_ovf = 0;        // mirrored allocation records that hold one
+  bool packed_from_mirror = false;
+  static bool core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi, uint64_t& w2, uint64_t& w3) {   // true: an id >= 256
     lo = hi = w2 = w3 = 0;
+    bool ovf = false;
     for (uint32_t c : ids) {
       if (c < 64) lo |= 1ull << c;
       else if (c < 128) hi |= 1ull << (c - 64);
       else if (c < 192) w2 |= 1ull << (c - 128);
       else if (c < 256) w3 |= 1ull << (c - 192);
-      else core_overflow = true;
+      else ovf = true;
     }
+    return ovf;
   }
   // fills `r` (a fresh or cleared ResourceInNodeV3) from the mask form; ids and slot paths arrive in ascending order,
   // so every set insertion is hinted at end()
@@ -734,7 +756,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   I.alloc_cache.clear();   // dense node indices and GRES bit positions are per snapshot
   const uint32_t N = (uint32_t)snap.craned_metas.size();
   I.node_name.clear(); I.node_mem_sw.clear(); I.node_idx.clear(); I.part_idx.clear();
-  I.core_overflow = false;
+  bool core_overflow = false;
   I.preempt_enabled = snap.preempt_enabled;
   I.qos_id.clear(); I.qos_preempt.clear();
   if (snap.preempt_enabled) {
@@ -788,7 +810,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     I.node_idx[m.craned_id] = n;
     cpu[n] = m.res_total.cpu_set.cpu_count.raw;
     mem[n] = m.res_total.memory_bytes;
-    I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n], w2[n], w3[n]);
+    core_overflow |= I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n], w2[n], w3[n]);
     gres[n] = I.gres_mask(m.res_total.gres);
     sched[n] = m.alive && !m.drain;  // JobScheduler.cpp:6595
   }
@@ -818,16 +840,16 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
       I.v_cpu.push_back(res.cpu_set.cpu_count.raw);
       I.v_mem.push_back(res.memory_bytes);
       uint64_t l, hh, x2, x3;
-      I.core_masks(res.cpu_set.core_ids, l, hh, x2, x3);
+      core_overflow |= I.core_masks(res.cpu_set.core_ids, l, hh, x2, x3);
       I.v_lo.push_back(l); I.v_hi.push_back(hh); I.v_w2.push_back(x2); I.v_w3.push_back(x3);
       I.v_g.push_back(I.gres_mask(res.gres));
     }
     I.v_off.push_back((uint32_t)I.v_node.size());
   }
   I.repack_mirror();
-  I.snap_overflow = I.core_overflow;
+  I.snap_overflow = core_overflow;
   I.snap_error.clear();
-  if (I.core_overflow) {
+  if (core_overflow) {
     status_ = CNS_ERR_UNSUPPORTED;
     error_ = I.snap_error = "a node or reservation lists a core id >= 256 (the engine keeps core ids in four 64-bit masks); keep the CPU SchedulerAlgo";
     return;
@@ -858,7 +880,11 @@ void GpuNodeSelectionAlgo::FreeResourceFromNode(const CranedId& craned_id, job_i
   if (it == I.mirror.end()) return;   // "Try to free resource from an unknown job", :247-251
   auto& recs = it->second.recs;
   for (size_t i = 0; i < recs.size(); ++i)
-    if (recs[i].craned == craned_id) { recs.erase(recs.begin() + i); break; }
+    if (recs[i].craned == craned_id) {
+      if (recs[i].packed.ovf) --I.mirror_ovf;
+      recs.erase(recs.begin() + i);
+      break;
+    }
   if (I.mirror_packed && job_id <= I.m_last_id) {
     if (recs.empty()) I.m_removed.push_back(job_id);
     else I.m_touched.push_back(job_id);   // (the rest of its nodes usually follow before the next cycle: then it is a removal)
@@ -889,6 +915,7 @@ size_t GpuNodeSelectionAlgo::PackMirrorForBench(uint64_t* checksum_canonical, do
 }
 
 uint64_t GpuNodeSelectionAlgo::LastRunningChecksumCanonical() const { return impl_->running_checksum_canonical(); }
+bool GpuNodeSelectionAlgo::PackedRunningSetOverflows() const { return impl_->packed_from_mirror ? impl_->mirror_ovf != 0 : impl_->run_overflow; }
 
 void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
                                       const std::vector<std::unique_ptr<RnJobInScheduler>>* running_for_priority) {
@@ -912,16 +939,15 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   auto fail_all = [&](int st, const std::string& msg) {
     status_ = st; error_ = msg;
     for (const auto& j : pending_jobs) if (j->reason.empty()) j->reason = "GpuEngineError";
+    I.last.jobs = 0; I.last_ord.clear(); I.last_index.clear();   // MaterializeAllocation must not serve the PREVIOUS cycle's placements
   };
   if (!I.h) return fail_all(status_ ? status_ : CNS_ERR_NO_DEVICE, error_);
   if (!I.have_snapshot) {
     if (I.snap_overflow) return fail_all(CNS_ERR_UNSUPPORTED, I.snap_error);   // the refused snapshot's own message, every cycle
     return fail_all(CNS_ERR_STATE, "NodeSelect before SetClusterSnapshot");
   }
-  if (I.core_overflow) {
-    I.core_overflow = false;   // per pack: the next cycle's running set is judged on its own
+  if (I.packed_from_mirror ? I.mirror_ovf != 0 : I.run_overflow)   // (judged on the records of THIS cycle's running set, cached or fresh)
     return fail_all(CNS_ERR_UNSUPPORTED, "a running job holds a core id >= 256");
-  }
   const auto &r_end = I.r_end, &r_cpu = I.r_cpu;
   const auto &r_off = I.r_off, &r_node = I.r_node, &r_resv = I.r_resv;
   const auto &r_mem = I.r_mem, &r_lo = I.r_lo, &r_hi = I.r_hi, &r_g = I.r_g;
@@ -1430,6 +1456,7 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
   std::vector<int64_t> acpu;
   std::vector<uint64_t> amem, alo, ahi, ag, aw2, aw3;
   std::vector<StepInScheduler*> flat;
+  bool steps_overflow = false;   // (of THIS pass only: it says nothing about the next NodeSelect)
   for (const JobStepQueue& jq : jobs) {
     std::vector<std::pair<uint32_t, const ResourceInNodeV3*>> nodes;   // canonical walk order: ascending dense index
     if (jq.step_res_avail)
@@ -1443,13 +1470,18 @@ void GpuNodeSelectionAlgo::SchedulePendingSteps(std::vector<JobStepQueue>& jobs)
       acpu.push_back(res->cpu_set.cpu_count.raw);
       amem.push_back(res->memory_bytes);
       uint64_t lo, hi, x2, x3;
-      I.core_masks(res->cpu_set.core_ids, lo, hi, x2, x3);
+      steps_overflow |= I.core_masks(res->cpu_set.core_ids, lo, hi, x2, x3);
       alo.push_back(lo); ahi.push_back(hi); aw2.push_back(x2); aw3.push_back(x3);
       ag.push_back(I.gres_mask(res->gres));
     }
     noff.push_back((uint32_t)nidx.size());
     for (StepInScheduler* s : jq.pending_steps) flat.push_back(s);
     soff.push_back((uint32_t)flat.size());
+  }
+  if (steps_overflow) {
+    status_ = CNS_ERR_UNSUPPORTED;
+    error_ = "a job's step_res_avail holds a core id >= 256 (the engine keeps core ids in four 64-bit masks); keep JobInCtld::SchedulePendingSteps for this pass";
+    return;
   }
   const size_t S = flat.size();
   std::vector<int64_t> ncpu(S), tcpu(S);

@@ -279,8 +279,9 @@ class INodeSelectionAlgo {
                           const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) = 0;
 };
 
-// MI355X implementation.  Engine-level failures (no GPU, unsupported input) never fall back to a CPU
-// scheduler: every pending job is left unscheduled with reason "GpuEngineError" and LastError() says why.
+// MI355X implementation.  It has no CPU path of its own: on an engine-level failure (no GPU, unsupported input) every pending job
+// is left unscheduled with reason "GpuEngineError", Ok() / LastStatus() / LastError() say why, and the CALLER decides — INTEGRATION.md
+// §3 wires the reference's own SchedulerAlgo behind this class for exactly that case (two lines in JobScheduler's constructor).
 class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
  public:
   explicit GpuNodeSelectionAlgo(int device = 0, uint64_t scheduled_batch_size = 0);
@@ -369,6 +370,10 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // per-node records (the explicit path walks an unordered_map, the mirror keeps event order).
   size_t PackMirrorForBench(uint64_t* checksum_canonical, double* pack_ms = nullptr);
   uint64_t LastRunningChecksumCanonical() const;
+  // true: the running set packed last (PackRunningForBench / PackMirrorForBench / a NodeSelect) holds an allocation with a core
+  // id >= 256 — such a cycle is refused with CNS_ERR_UNSUPPORTED for as long as the job runs (the bit is kept with the cached /
+  // mirrored record, not with the cycle that first packed it)
+  bool PackedRunningSetOverflows() const;
 
   // ---- placement -> wire: the protobuf encoding of what JobToD carries, written straight from the
   // packed placements of the last NodeSelect — no ResourceInNodeV3 object, no std::set, no map is built on the way.

@@ -469,6 +469,42 @@ int main(int argc, char** argv) {
     snap.craned_metas[1].res_total.cpu_set.core_ids.insert(300);   // beyond the four mask words: refused, not dropped
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);
+    // ... and a RUNNING job that holds such an id refuses every cycle it is part of, not only the one that first packed it: the bit
+    // lives with the cached / mirrored allocation record (the flag used to be cleared after one refused cycle, and the
+    // next cycle served the cached record with the id silently dropped)
+    snap.craned_metas[1].res_total.cpu_set.core_ids.erase(300);
+    algo.SetClusterSnapshot(snap);
+    {
+      std::vector<std::unique_ptr<RnJobInScheduler>> rn;
+      auto r1 = std::make_unique<RnJobInScheduler>();
+      r1->job_id = 7; r1->end_time = 5000;
+      r1->allocated_res["cn1"].cpu_set.cpu_count = cpu_t::from_raw(2 * 256);
+      r1->allocated_res["cn1"].cpu_set.core_ids = {1, 300};
+      auto r2 = std::make_unique<RnJobInScheduler>();
+      r2->job_id = 8; r2->end_time = 5000;
+      r2->allocated_res["cn0"].cpu_set.cpu_count = cpu_t::from_raw(256);
+      r2->allocated_res["cn0"].cpu_set.core_ids = {0};
+      rn.push_back(std::move(r1)); rn.push_back(std::move(r2));
+      algo.PackRunningForBench(rn, true, nullptr, nullptr);
+      CHECK(algo.PackedRunningSetOverflows());
+      algo.PackRunningForBench(rn, true, nullptr, nullptr);      // the second cycle: served from the per-job cache
+      CHECK(algo.PackedRunningSetOverflows());
+      rn.erase(rn.begin());                                      // the job ended
+      algo.PackRunningForBench(rn, true, nullptr, nullptr);
+      CHECK(!algo.PackedRunningSetOverflows());
+      ResourceV3 res;
+      res["cn1"].cpu_set.cpu_count = cpu_t::from_raw(256);
+      res["cn1"].cpu_set.core_ids = {299};
+      algo.MallocResourceFromNode("cn1", 9, res);
+      algo.SetRunningJobInfo(9, 6000, "");
+      algo.PackMirrorForBench(nullptr);
+      CHECK(algo.PackedRunningSetOverflows());
+      algo.PackMirrorForBench(nullptr);                          // patched pack: nothing changed
+      CHECK(algo.PackedRunningSetOverflows());
+      algo.FreeResourceFromNode("cn1", 9);
+      algo.PackMirrorForBench(nullptr);
+      CHECK(!algo.PackedRunningSetOverflows());
+    }
     printf("%s\n", g_fail ? "FAIL" : "ok");
     return g_fail != 0;
   }
@@ -509,6 +545,33 @@ int main(int argc, char** argv) {
     }
     CHECK(pd[3]->allocated_res.at("cn0").cpu_set.core_ids == std::set<uint32_t>{1});  // lowest free core id
     CHECK(pd[4]->reason == "Partition Not Found");
+
+    // --- a cycle the engine refuses must not leave the PREVIOUS cycle's placements behind for MaterializeAllocation,
+    // and a running job with a core id >= 256 refuses every cycle it is part of (the second one is served from the per-job cache)
+    {
+      algo.SetDeferredWriteBack(true);
+      std::vector<std::unique_ptr<PdJobInScheduler>> pq;
+      pq.push_back(job(1, 1, 100));
+      algo.NodeSelect(now, running, pq);
+      CHECK(algo.Ok() && pq[0]->is_scheduled() && algo.MaterializeAllocation(*pq[0]));
+      std::vector<std::unique_ptr<RnJobInScheduler>> bad;
+      auto r1 = std::make_unique<RnJobInScheduler>();
+      r1->job_id = 77; r1->end_time = now + 500;
+      r1->allocated_res["cn1"].cpu_set.cpu_count = cpu_t::from_raw(256);
+      r1->allocated_res["cn1"].cpu_set.core_ids = {300};
+      bad.push_back(std::move(r1));
+      for (int rep = 0; rep < 2; ++rep) {
+        pq[0]->reason.clear();
+        algo.NodeSelect(now, bad, pq);
+        CHECK(!algo.Ok() && algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);
+        CHECK(pq[0]->reason == "GpuEngineError");
+        CHECK(!algo.MaterializeAllocation(*pq[0]));
+      }
+      pq[0]->reason.clear();
+      algo.NodeSelect(now, running, pq);   // the job ended: the next cycle is served again
+      CHECK(algo.Ok() && pq[0]->is_scheduled() && algo.MaterializeAllocation(*pq[0]));
+      algo.SetDeferredWriteBack(false);
+    }
 
     // --- the same queue after cn0 went down (CranedDown) and came back: SetCranedState re-sends the packed tables,
     // no new snapshot; a node that is not alive is skipped (JobScheduler.cpp:6595) -------------------------------

@@ -164,7 +164,7 @@ def test_page_locked_caller_buffers(built, monkeypatch):
         eng.set_nodes(c)
         ref = eng.node_select(now, j)
         pj, pout = eng.pinned_jobs(j), eng.pinned_placements(j)
-        bases = {a.ctypes.data: a.nbytes for a in eng._pinned}
+        bases = {p: a.nbytes for p, a in eng._pinned.items()}
         inside = lambda a: any(b <= a.ctypes.data and a.ctypes.data + a.nbytes <= b + n for b, n in bases.items())
         assert inside(pj.partition) and inside(pj.gres_spec) and inside(pout.start_sec) and inside(pout.node_idx)
         for _ in range(2):   # reused across cycles
@@ -172,5 +172,21 @@ def test_page_locked_caller_buffers(built, monkeypatch):
             assert got is pout and ref.diff(pout) is None
         with pytest.raises(EngineError):
             eng._check(eng._L.cns_host_free(eng._h, C.c_void_p(ref.start_sec.ctypes.data)))
+        # the natural per-cycle use must not grow the set of page-locked buffers: refill in place ...
+        n_bufs = len(eng._pinned)
+        c2, j2, _ = synth.make_config("C4", J=20000, N=2048, P=8)
+        j2.time_limit_sec = j2.time_limit_sec + 600
+        pj2 = eng.pinned_jobs(j2, into=pj)
+        assert len(eng._pinned) == n_bufs and pj2.partition.ctypes.data == pj.partition.ctypes.data
+        ref2 = eng.node_select(now, j2)
+        assert ref2.diff(eng.node_select(now, pj2, out=pout)) is None
+        # ... a queue of another size swaps the buffers it must, and a set that is given back is gone
+        c3, j3, _ = synth.make_config("C4", J=12000, N=2048, P=8)
+        pj3 = eng.pinned_jobs(j3, into=pj2)
+        assert len(eng._pinned) == n_bufs
+        eng.free_pinned_jobs(pj3)
+        assert len(eng._pinned) == n_bufs - sum(getattr(pj3, f) is not None for f in pj3.__dataclass_fields__)
+        with pytest.raises(EngineError):
+            eng.free_pinned(pj3.partition)
     finally:
         eng.close()

@@ -15,12 +15,12 @@ try:
 except Exception as ex:
     print("run failed:", ex)
 P = c.num_partitions
-out = np.zeros(P * 40 + 2048, np.uint64)
+out = np.zeros(P * 48 + 2048, np.uint64)
 e._check(e._L.cns_debug_get_prof(e._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(len(out))))
-log = out[P * 40:P * 40 + 2040]; log = log[log != 0]
+log = out[P * 48:P * 48 + 2040]; log = log[log != 0]
 orig = (log >> np.uint64(32)).astype(np.int64); cause = ((log >> np.uint64(24)) & np.uint64(0xFF)).astype(np.int64); code = (log & np.uint64(0xFFFFFF)).astype(np.int64)
 print("flushes:", list(zip(orig.tolist(), cause.tolist(), code.tolist()))[-20:])
-d = out[P * 40 + 2040:]
+d = out[P * 48 + 2040:]
 f = lambda x: struct.unpack('d', struct.pack('Q', int(x)))[0]
 print("fault 22: cost0", f(d[0]), "P.cost", f(d[1]), "orig", int(d[2]) >> 32, "node", int(d[2]) & 0xFFFFFFFF, "start-now", int(d[3]) - now, "alloc.cpu", int(d[4]) / 256, "total.cpu", int(d[5]) / 256, "L", int(d[6]))
-print("always-on counters", out[P * 32:P * 40].tolist())
+print("always-on counters", out[P * 32:P * 48].tolist())

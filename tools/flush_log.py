@@ -15,10 +15,10 @@ if running is not None:
     e.set_running(running)
 e.upload_jobs(j); e.run_resident(now)
 P = c.num_partitions
-out = np.zeros(P * 40 + 2048, np.uint64)
+out = np.zeros(P * 48 + 2048, np.uint64)
 e._check(e._L.cns_debug_get_prof(e._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(len(out))))
 # cns_debug_get_prof caps at P*40: read the raw region through a second call is not possible; the cap is lifted in this build
-log = out[P * 40:]
+log = out[P * 48:]
 log = log[log != 0]
 orig = (log >> np.uint64(32)).astype(np.int64)
 cause = ((log >> np.uint64(24)) & np.uint64(0xFF)).astype(np.int64)
