@@ -111,6 +111,7 @@ struct cns_engine {
   std::vector<u64> part_jobs;                   // engine partition -> jobs of the uploaded queue that reach its ordered loop
   std::vector<uint8_t> pre_part;                // cycle with preemption: engine partition has a pending job whose qos may preempt
   DevBuf d_params2, d_pmap_a, d_pmap_b, d_wide_last;
+  DevBuf d_params3, d_pmap_c, d_wide_mem;       // the serial-only launch of k_wide (groups wider than k_select's tile)
   bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
   u32 wide_retries = 0;                         // cycles that were re-run on k_pipe / k_select after a k_wide fault (lifetime of the handle)
   // MultiFactorPriority (priority_host.inc)
@@ -235,7 +236,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.prof = h->d_prof.as<u64>();
   K.wide_ctl = h->d_wide.as<char>();
   K.general_only = h->pre_active ? 1u : 0u;
-  K.pad_go = 0;
+  K.serial_only = 0;
   K.pre = h->pre_active ? h->pre_params : PreParams{};
   K.gres = h->gres;
   if (h->shared) {
@@ -299,6 +300,34 @@ int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string
   void* args[2] = {(void*)&K2, (void*)&dparams};
   if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, L.stream) != hipSuccess) return 1;
   *name = std::string(kname) + " x" + std::to_string(W::waves);   // (x64: cns::w64::k_wide in a profile, x32: cns::w32::k_wide, ...)
+  return 0;
+}
+// Groups of partitions that share nodes and are wider than k_select's register tile (an "ALL" partition over a large cluster):
+// k_wide's HOME workgroup alone, every job through the sequential protocol with its tester waves as memory scanners over the
+// committed HBM arrays (KParams::serial_only).  The narrowest build serves (its two scanner workgroups per partition leave at once);
+// no workgroup waits for another one, so no co-residency is needed.  Slow — every job reads every slot of its group — and exact.
+int launch_mem(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string* name) {
+  using W = w8::WideInfo;
+  const void* fn = (const void*)w8::k_wide<1>;
+  const unsigned groups = (L.nparts + 7u) / 8u;
+  const unsigned grid = 8u * groups * W::group;
+  const size_t need = (size_t)h->P * W::ctl_bytes;
+  if (h->d_wide_mem.ensure(need) != hipSuccess) return 1;
+  if (hipMemsetAsync(h->d_wide_mem.p, 0, need, L.stream) != hipSuccess) return 1;
+  KParams K2 = K;
+  K2.wide_ctl = h->d_wide_mem.as<char>();
+  K2.serial_only = 1;
+  if (hipMemcpyAsync(const_cast<KParams*>(L.dparams), &K2, sizeof(KParams), hipMemcpyHostToDevice, L.stream) != hipSuccess) return 1;
+  size_t dyn = 0;
+  hipFuncAttributes fa;
+  if (hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes < 84u * 1024u) {
+    dyn = 84u * 1024u - fa.sharedSizeBytes;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) { dyn = 0; (void)hipGetLastError(); }
+  }
+  const KParams* dparams = L.dparams;
+  void* args[2] = {(void*)&K2, (void*)&dparams};
+  if (hipLaunchKernel(fn, dim3(grid), dim3(W::block), args, dyn, L.stream) != hipSuccess) return 1;
+  *name = "k_mem (k_wide<1> home workgroup, sequential protocol over the HBM arrays)";
   return 0;
 }
 // Which selection kernel runs: k_pipe (decoupled test / commit pipeline) for partitions its tile covers, k_select
@@ -382,7 +411,7 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   for (u32 v = 0; v < h->V; ++v)
     for (u32 q = h->part_off[h->P_real + v]; q < h->part_off[h->P_real + v + 1]; ++q) h->slot_end[q] = h->resv_end[v];
   // (per partition / group: checked in cns_set_nodes — a partition that shares no node may be as wide as k_wide's widest tile)
-  if (h->max_np > std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max))
+  if (h->max_np > std::max<u32>(w8::WideInfo::mem_slots, w64::WideInfo::lanes * w64::WideInfo::npl_max))
     return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(w64::WideInfo::lanes * w64::WideInfo::npl_max) + " schedulable nodes");
   std::map<std::tuple<i64, u64, u64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
@@ -521,7 +550,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
-  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last}) b->release();
+  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last, &h->d_params3, &h->d_pmap_c, &h->d_wide_mem}) b->release();
   for (void* p : h->host_bufs) (void)hipHostFree(p);   // cns_host_alloc
   h->host_bufs.clear();
   for (DevBuf& b : h->d_prio) b.release();
@@ -632,7 +661,8 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   // share no node with another one run on it (groups run on k_select), and only while the device can hold its workgroups
   for (u32 e = 0; e < PE; ++e) {
     const u32 npe = part_off[e + 1] - part_off[e];
-    const u32 cap = members[e].size() > 1 ? kScan * (u32)CNS_NPL_MAX : std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max);
+    // (groups wider than k_select's tile run on k_wide's home workgroup alone, KParams::serial_only: launch_mem)
+    const u32 cap = members[e].size() > 1 ? w8::WideInfo::mem_slots : std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max);
     if (npe > cap)
       return fail(h, CNS_ERR_UNSUPPORTED, (members[e].size() > 1 ? "group of partitions sharing nodes with more than " : "partition with more than ") +
                                               std::to_string(cap) + " schedulable (partition, node) slots");
@@ -984,21 +1014,44 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
     // Only partitions that HAVE pending jobs get a scheduler (the reference builds NodeStates and a LocalScheduler only for
     // the partitions some pending job names, JobScheduler.cpp:6516-6530,6571-6573,6723-6732): the launch, and with it the choice
     // of the k_wide build (workgroups per partition), is sized by the busy partitions, not by the snapshot.
-    std::vector<u32> pa, pb;
-    u32 npa = 0, npb = 0;
+    // ... and a group of partitions that share nodes and is wider than k_select's register tile runs on k_wide's home workgroup
+    // alone (launch_mem): the ordinary "ALL partition over the whole cluster" layout of a large site.
+    std::vector<u32> pa, pb, pc;
+    u32 npa = 0, npb = 0, npc = 0;
     for (u32 p = 0; p < h->P; ++p) {
       if (p >= h->part_jobs.size() || h->part_jobs[p] == 0) continue;
-      const bool sel = (p < h->eng_members.size() && h->eng_members[p] > 1) || (h->pre_active && p < h->pre_part.size() && h->pre_part[p]);
+      const bool pre = h->pre_active && p < h->pre_part.size() && h->pre_part[p];
+      const bool sel = (p < h->eng_members.size() && h->eng_members[p] > 1) || pre;
       const u32 np = h->part_off[p + 1] - h->part_off[p];
-      if (sel) { pb.push_back(p); npb = std::max(npb, np); } else { pa.push_back(p); npa = std::max(npa, np); }
+      if (sel && np > kScan * (u32)CNS_NPL_MAX) {
+        if (pre) return fail(h, CNS_ERR_UNSUPPORTED, "preemption among the jobs of a partition (or group of partitions sharing nodes) with more than " +
+                                                         std::to_string(kScan * (u32)CNS_NPL_MAX) + " (partition, node) slots");
+        pc.push_back(p); npc = std::max(npc, np);
+      } else if (sel) { pb.push_back(p); npb = std::max(npb, np); }
+      else { pa.push_back(p); npa = std::max(npa, np); }
     }
-    std::string err, name_a, name_b;
-    if (pb.empty() || pa.empty()) {
+    std::string err, name_a, name_b, name_c;
+    if (!pc.empty()) {
+      if (int rc = upload(h, h->d_pmap_c, pc)) return rc;
+      HIPCHK(h, h->d_params3.ensure(sizeof(KParams)));
+      KParams KC = K;
+      KC.part_map = h->d_pmap_c.as<u32>(); KC.launch_parts = (u32)pc.size();
+      KC.general_only = 0; KC.pre = PreParams{};
+      HIPCHK(h, hipEventRecord(h->ev2[0], h->stream));                  // tables + init kernels done: the second stream may start
+      HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev2[0], 0));
+      LaunchCtx LC{(u32)pc.size(), npc, h->stream2, h->d_params3.as<KParams>(), 0u};
+      if (launch_mem(h, KC, LC, &name_c)) return fail(h, CNS_ERR_HIP, "k_mem: control block allocation / upload / launch failed");
+      name_c += " on " + std::to_string(pc.size()) + " group(s) of up to " + std::to_string(npc) + " slots";
+    }
+    const u32 held = (u32)pc.size();   // home workgroups of k_mem that hold a CU while the other launches run
+    if (pa.empty() && pb.empty()) {
+      h->last_kernel = name_c;
+    } else if (pb.empty() || pa.empty()) {
       // one launch: over all partitions (identity map) when every one is busy, else over the busy ones (part_map)
       const bool plain = pb.empty();
       const std::vector<u32>& pm = plain ? pa : pb;
       const bool ident = pm.size() == h->P;
-      LaunchCtx L{(u32)pm.size(), plain ? npa : npb, h->stream, h->d_params.as<KParams>(), 0u};
+      LaunchCtx L{(u32)pm.size(), plain ? npa : npb, h->stream, h->d_params.as<KParams>(), held};
       KParams K1 = K;
       if (plain) { K1.general_only = 0; K1.pre = PreParams{}; }
       if (!ident) {
@@ -1008,6 +1061,7 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
       if (K1.general_only != K.general_only || !ident) HIPCHK(h, hipMemcpyAsync(h->d_params.p, &K1, sizeof(KParams), hipMemcpyHostToDevice, h->stream));
       if (const int rc = launch_one(h, K1, L, plain, &h->last_kernel, &err)) return fail(h, rc, err);
       if (!ident) h->last_kernel += " on " + std::to_string(pm.size()) + " busy of " + std::to_string(h->P) + " partitions";
+      if (!pc.empty()) h->last_kernel += " + " + name_c;
     } else {
       if (int rc = upload(h, h->d_pmap_a, pa)) return rc;
       if (int rc = upload(h, h->d_pmap_b, pb)) return rc;
@@ -1023,13 +1077,18 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
       HIPCHK(h, hipStreamWaitEvent(h->stream2, h->ev2[0], 0));
       LaunchCtx LB{(u32)pb.size(), npb, h->stream2, h->d_params2.as<KParams>(), 0u};
       if (const int rc = launch_one(h, KB, LB, false, &name_b, &err)) return fail(h, rc, err);   // first: its few workgroups take their CUs
-      LaunchCtx LA{(u32)pa.size(), npa, h->stream, h->d_params.as<KParams>(), (u32)pb.size()};
+      LaunchCtx LA{(u32)pa.size(), npa, h->stream, h->d_params.as<KParams>(), (u32)pb.size() + held};
       if (const int rc = launch_one(h, KA, LA, true, &name_a, &err)) return fail(h, rc, err);
       HIPCHK(h, hipEventRecord(h->ev[3], h->stream));                   // the partitions on the fast kernels are done here
       split = true;
       HIPCHK(h, hipEventRecord(h->ev2[1], h->stream2));
       HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev2[1], 0));           // the cycle ends when both have
       h->last_kernel = name_a + " + " + name_b + " on " + std::to_string(pb.size()) + " of " + std::to_string(h->P) + " partitions";
+      if (!pc.empty()) h->last_kernel += " + " + name_c;
+    }
+    if (!pc.empty() && !split) {   // the cycle ends when the launch on the second stream has
+      HIPCHK(h, hipEventRecord(h->ev2[1], h->stream2));
+      HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev2[1], 0));
     }
     HIPCHK(h, hipGetLastError());
   }

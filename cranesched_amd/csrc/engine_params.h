@@ -189,7 +189,9 @@ struct KParams {
   u64* prof;               // [P*32] cycle counters (only written by -DCNS_PROF builds)
   char* wide_ctl;          // [P] WideCtl blocks of k_wide (exchange rings + control words), zeroed before every launch
   u32* wide_last;          // [P * 65 536] k_wide with 8 / 16 rows per lane: last task posted on a slot (in LDS for the narrower tiles); zeroed before the launch
-  u32 general_only, pad_go; // != 0: every job through the general path of k_select (preemption enabled)
+  u32 general_only;         // != 0: every job through the general path of k_select (preemption enabled)
+  u32 serial_only;          // k_wide: the home workgroup alone runs every job through the sequential protocol, its tester waves scanning the
+                            // committed HBM arrays (groups of partitions that share nodes and are wider than k_select's register tile)
   // A cycle may be SPLIT over two launches: the partitions that need k_select (groups of partitions that share nodes; with
   // preemption, the partitions whose pending jobs may preempt) and all the others on k_wide / k_pipe, side by side.  Then
   // workgroup (group) i of a launch serves engine partition part_map[i]; null: i itself.

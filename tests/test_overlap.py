@@ -83,3 +83,26 @@ def test_shared_nodes_with_reservations_on_gpu(engine_cls):
         helpers.assert_same(eng, got, ref, c2, sample_nodes=N, tag="overlap + reservations")
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,lay,J", [(1, "all+subsets", 6000), (2, "random", 6000), (3, "all+subsets", 20000)])
+def test_shared_group_wider_than_k_select_s_register_tile_on_gpu(built, seed, lay, J):
+    """An "ALL" partition over a cluster of 12 000 nodes next to subsets of it: one group of ~19 000 - 22 000 (partition, node)
+    slots, more than k_select's tile holds (16 576).  It runs on k_wide's home workgroup alone (KParams::serial_only: the
+    sequential protocol with the tester waves as memory scanners) — round 3 refused it.  Bit-exact vs the oracle incl. every
+    (partition, node) cost and the shared time maps; the disjoint partition beside the group keeps its fast kernel."""
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    c, j, now, run = overlap_case(seed, N=12000, J=J, layout=lay)
+    assert int(c.part_offsets[-1]) > 16_576
+    ref = pyoracle.select(c, j, now, running=run)
+    eng = GpuNodeSelector(device=0)
+    try:
+        eng.set_nodes(c)
+        eng.set_running(run)
+        got = eng.node_select(now, j)
+        assert "k_mem" in eng.last_kernel(), eng.last_kernel()
+        helpers.assert_same(eng, got, ref, c, sample_nodes=600, tag=f"wide group {seed} {lay}")
+    finally:
+        eng.close()
