@@ -10,7 +10,7 @@ stay together; a rank's snapshot lists only its own partitions) and each step en
 placement buffers; total work is fixed ("strong").  A partition is ONE sequential chain; k_wide spreads its per-job node scan
 over 16 more workgroups of the SAME XCD (exchange through that XCD's L2, ~0.4 us per job), so C4's 8 partitions occupy 136 of
 256 CUs and run concurrently on one GPU: more GPUs do not add chains there and the curve is flat by construction (an exchange
-over xGMI would cost more per job than the whole chain does now, DESIGN.md 6).  --config C4p64 / C4p256 (the same cluster cut
+over xGMI would cost more per job than the whole chain does now, DESIGN.md 7).  --config C4p64 / C4p256 (the same cluster cut
 into 64 / 256 partitions) are the layouts on which more GPUs DO add chains: the engine sizes its launch by the partitions that
 have pending jobs on the rank, so fewer partitions per rank get the wider k_wide build.
 
@@ -275,7 +275,7 @@ def main():
                          "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); the node "
                                  "tile is register-resident, so HBM traffic is ~1 % of this: the kernel is bound by the latency "
                                  "of a partition's sequential chain (scan -> cross-CU exchange -> decision -> row update, "
-                                 "DESIGN.md 4c/5i), not by HBM"},
+                                 "DESIGN.md 4.2/5.2), not by HBM"},
         }
         if incl is not None:
             line["incl_h2d_d2h"] = incl

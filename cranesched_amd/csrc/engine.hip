@@ -112,6 +112,8 @@ struct cns_engine {
   std::vector<uint8_t> pre_part;                // cycle with preemption: engine partition has a pending job whose qos may preempt
   DevBuf d_params2, d_pmap_a, d_pmap_b, d_wide_last;
   DevBuf d_params3, d_pmap_c, d_wide_mem;       // the serial-only launch of k_wide (groups wider than k_select's tile)
+  DevBuf d_flen, d_tag_off, d_tag_base;         // ... its compact map lengths, and the slot range of every member partition of a group
+  std::vector<u32> tag_off, tag_base;
   bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
   u32 wide_retries = 0;                         // cycles that were re-run on k_pipe / k_select after a k_wide fault (lifetime of the handle)
   // MultiFactorPriority (priority_host.inc)
@@ -210,6 +212,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.f_mem = h->d_fmem.as<u32>();
   K.f_cnt = h->d_fcnt.as<u64>();
   K.dip_t = h->d_dipt.as<u32>(); K.dip_cm = h->d_dipcm.as<u32>(); K.dip_g = h->d_dipg.as<u32>();
+  if (h->shared) { K.f_len = h->d_flen.as<u32>(); K.tag_off = h->d_tag_off.as<u32>(); K.tag_base = h->d_tag_base.as<u32>(); }
   K.rn_off = h->d_rn_off.as<u32>();
   K.rn_end = h->d_rn_end.as<i64>();
   K.rn_res = h->d_rn_res.as<Res>();
@@ -472,6 +475,13 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
   HIPCHK(h, h->d_fmem.ensure(S1 * sizeof(u32)));
   HIPCHK(h, h->d_fcnt.ensure(S1 * sizeof(u64)));
   HIPCHK(h, h->d_dipt.ensure(S1 * sizeof(u32))); HIPCHK(h, h->d_dipcm.ensure(S1 * sizeof(u32))); HIPCHK(h, h->d_dipg.ensure(S1 * sizeof(u32)));
+  if (h->shared) {
+    HIPCHK(h, h->d_flen.ensure(S1 * sizeof(u32)));
+    std::vector<u32> tb = h->tag_base;
+    tb.resize(std::max<size_t>(h->P, 1), 0);   // (the virtual partitions of reservations share nothing: never read)
+    if (int rc = upload(h, h->d_tag_base, tb)) return rc;
+    if (int rc = upload(h, h->d_tag_off, h->tag_off)) return rc;
+  }
   HIPCHK(h, h->d_first_resv.ensure(S1 * sizeof(i64)));
   HIPCHK(h, h->d_heap.ensure((size_t)(S + h->P + 1) * sizeof(HeapEnt)));
   HIPCHK(h, h->d_bfj.ensure(S1 * sizeof(u32)));
@@ -550,7 +560,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_slot_end, &h->d_slot_type, &h->d_rv_off, &h->d_rv_start, &h->d_rv_end, &h->d_rv_res,
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
-  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last, &h->d_params3, &h->d_pmap_c, &h->d_wide_mem}) b->release();
+  for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last, &h->d_params3, &h->d_pmap_c, &h->d_wide_mem, &h->d_flen, &h->d_tag_off, &h->d_tag_base}) b->release();
   for (void* p : h->host_bufs) (void)hipHostFree(p);   // cns_host_alloc
   h->host_bufs.clear();
   for (DevBuf& b : h->d_prio) b.release();
@@ -656,6 +666,15 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
     max_np = std::max<u32>(max_np, (u32)slot_node.size() - part_off[e]);
   }
   part_off[PE] = (u32)slot_node.size();
+  // the slots of a group are its member partitions' lists one after the other: member t (its tag) owns [tag_off[b + t], tag_off[b + t + 1])
+  // relative to the group's first slot, b = tag_base[group]
+  h->tag_off.clear(); h->tag_base.assign(PE, 0);
+  for (u32 e = 0; e < PE; ++e) {
+    h->tag_base[e] = (u32)h->tag_off.size();
+    u32 o = 0;
+    for (u32 p : members[e]) { h->tag_off.push_back(o); o += (u32)plist[p].size(); }
+    h->tag_off.push_back(o);
+  }
   const u32 S = (u32)slot_node.size();
   // k_select / k_pipe tiles hold 16 576 / 8 192 slots; k_wide (64 scanner waves x 16 rows) 65 536 — but only partitions that
   // share no node with another one run on it (groups run on k_select), and only while the device can hold its workgroups
@@ -1133,7 +1152,7 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
 // Such a fault says nothing about the INPUT: the cycle is re-run once on k_pipe / k_select, which live inside one
 // workgroup per partition (every run starts from the caller's tables: k_init_nodes, k_prep_jobs and the result buffers
 // are part of the pass).  Faults below 20 are data invariants of the shared routines (e.g. 3: the input class on which
-// the reference itself asserts, DESIGN.md 7) and would recur: they fail the call.
+// the reference itself asserts, DESIGN.md 8) and would recur: they fail the call.
 int cns_run_resident(cns_handle* h, int64_t now) {
   if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_run_resident: null handle");
   if (!h->have_nodes || !h->have_jobs) return fail(h, CNS_ERR_STATE, "cns_run_resident before set_nodes/upload_jobs");
@@ -1229,7 +1248,7 @@ int cns_select(cns_handle* h, int64_t now, const cns_job_soa* jobs, cns_placemen
 // commits).  A cycle with preemption enabled therefore runs k_select with every job on its general path
 // (KParams::general_only) and the device form of TryPreempt_ / PreemptSegTree between the res_total selection and the
 // backfill (csrc/preempt_dev.inc).  Reservations are served (their virtual nodes carry their own job lists, cpp:6705), and
-// so are partitions that share nodes (node-level job lists, DESIGN.md 5j).
+// so are partitions that share nodes (node-level job lists, DESIGN.md 6.7).
 int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, const cns_preempt_soa* pre,
                        cns_placement_soa* out, cns_preempt_out* pout) {
   if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: null handle");

@@ -197,6 +197,12 @@ struct KParams {
   // workgroup (group) i of a launch serves engine partition part_map[i]; null: i itself.
   const u32* part_map;
   u32 launch_parts, pad_lp;
+  // ---- the serial-only mode of k_wide (wide groups of partitions that share nodes): compact per-slot map length, kept by
+  // k_init_nodes and commit_selection (the only commit path of that mode), and the slot range of every member partition of a
+  // group — a job only ever looks at the slots of its own partition: [tag_off[tag_base[part] + tag], ... + 1) relative to the group
+  u32* f_len;              // [S]
+  const u32* tag_off;
+  const u32* tag_base;     // [P_real]
   PreParams pre;
   GresDev gres;
   // ---- partitions that share nodes (null otherwise) ----------------------------------------------------------------

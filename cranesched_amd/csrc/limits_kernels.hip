@@ -23,7 +23,7 @@
 //            the 16 slots.  Per job: load the usage components (the only loads that depend on earlier admissions;
 //            limits and the next records are prefetched two jobs ahead), compare against the limits, ballots ->
 //            admit or first failing check in the reference's order -> store usage + 1 job.  The chain is serial
-//            by definition (every admission changes what the next job sees); see DESIGN.md §5d for the plan that
+//            by definition (every admission changes what the next job sees); see DESIGN.md §6.4 for the plan that
 //            replaces it by bounded two-sided iterations over key-sorted segments.
 //
 // Included by engine.hip (one translation unit, namespace cns).

@@ -348,6 +348,7 @@ __global__ __launch_bounds__(256) void k_init_nodes(const KParams* __restrict__ 
     { TlEntry z; z.t = end_h; z.r = res_zero(); T[i] = z; }
   }
   hd->len = len;
+  if (P.f_len) P.f_len[q] = len;
   hd->node = n;
   hd->type = P.slot_type[q];
   hd->pad = 0;
@@ -896,6 +897,7 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
     if (lane == 0) {
       P.cost[q] = ncost;
       if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
+      if (P.f_len) P.f_len[q] = newlen;
       s_upd[i] = u;
     }
     if (P.sib_off) {
@@ -909,6 +911,7 @@ __device__ __noinline__ void commit_selection(const KParams& P, const JobCtx& J,
           us.p = ((ps / kS) << 10) | (ps % kS);
           us.has_front = u.has_front | 2u;
           if (u.has_front) { P.f_cpu[qs] = u.fcpu; P.f_mem[qs] = u.fmem; P.f_cnt[qs] = u.fcnt; }
+          if (P.f_len) P.f_len[qs] = newlen;
           s_upd[nup] = us;
         }
         ++nup;

@@ -25,11 +25,11 @@ CONFIGS = {
     "C4": dict(idx=4, J=1_000_000, N=65_536, P=8, gres=True, Q=600, LM=24),
     "C5": dict(idx=5, J=1_000_000, N=65_536, P=8, gres=False, Q=675, LM=32),
     # C4's cluster and job mix cut into 64 partitions of 1 024 nodes: the configuration on which more GPUs DO add chains
-    # (one GPU: 64 chains on k_pipe, one CU each; 8 GPUs: 8 chains per GPU on k_wide x64) — bench.py --config C4p64, DESIGN.md 6
+    # (one GPU: 64 chains on k_pipe, one CU each; 8 GPUs: 8 chains per GPU on k_wide x64) — bench.py --config C4p64, DESIGN.md 7
     "C4p64": dict(idx=6, J=1_000_000, N=65_536, P=64, gres=True, Q=600, LM=24),
     # ... and into 256 partitions of 256 nodes: beyond k_wide's 80 partitions on ONE GPU (k_pipe, one workgroup per partition);
     # 4 GPUs: 64 busy partitions each -> k_wide x8, 8 GPUs: 32 each -> k_wide x16 (the launch is sized by the partitions that
-    # have pending jobs on that rank) — bench.py --config C4p256, DESIGN.md 6
+    # have pending jobs on that rank) — bench.py --config C4p256, DESIGN.md 7
     "C4p256": dict(idx=7, J=1_000_000, N=65_536, P=256, gres=True, Q=600, LM=24),
 }
 
@@ -208,7 +208,10 @@ def running_of_partitions(cluster: Cluster, running: Running, parts: list[int], 
 #          shares; 3 % of the partition's jobs are submitted into it) and a FUTURE one (starts in an hour, for two hours) over the 256
 #          nodes before those: jobs whose window crosses it wait behind it ("Resource Reserved"); a few jobs name the future
 #          reservation (its scheduler does not exist yet) or a reservation nobody created ("Reservation Not Found").
-MIXED = ("C4all", "C4rp", "C4v")
+#   C4all64k: C4 plus an "ALL" partition (index 8) over ALL 65 536 nodes — the ordinary CraneSched layout on a large site; every ninth
+#          job is submitted to it.  ALL connects every partition: one group of 131 072 (partition, node) slots, one chain for the
+#          whole queue — wider than k_select's tile: k_wide's home workgroup alone (k_mem).
+MIXED = ("C4all", "C4rp", "C4v", "C4all64k")
 
 
 def mixed_reservations(name: str, cluster: Cluster, now: int = NOW):
@@ -245,6 +248,16 @@ def make_mixed(name: str, J: int | None = None, N: int | None = None):
                           np.concatenate([c.part_nodes, p0]).astype(np.uint32), gres=c.gres)
         part = j.partition.copy()
         part[(part == 0) & (np.arange(j.num_jobs) % 2 == 1)] = P
+        j.partition = part.astype(np.uint32)
+        return cluster, j, now, None, None
+    if name == "C4all64k":
+        c, j, now = make_config("C4", J=J, N=N)
+        Nn = c.num_nodes
+        cluster = Cluster(c.cpu_total_raw, c.mem_total, c.core_lo, c.core_hi, c.gres_slots,
+                          np.concatenate([c.part_offsets, [int(c.part_offsets[-1]) + Nn]]).astype(np.uint32),
+                          np.concatenate([c.part_nodes, np.arange(Nn, dtype=np.uint32)]).astype(np.uint32), gres=c.gres)
+        part = j.partition.copy()
+        part[np.arange(j.num_jobs) % 9 == 8] = c.num_partitions
         j.partition = part.astype(np.uint32)
         return cluster, j, now, None, None
     if name == "C4rp":

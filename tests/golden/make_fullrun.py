@@ -102,9 +102,13 @@ CASES = {
     "c4all": ("C4all", None, None, None), "c4rp": ("C4rp", None, None, None),
     # C4 with 8 active and 8 future reservations (24 schedulers: k_wide's nine-workgroup build)
     "c4v": ("C4v", None, None, None),
-    # C4's cluster and mix cut into 64 partitions of 1 024 nodes (the configuration on which more GPUs add chains, DESIGN 6): on one
+    # C4's cluster and mix cut into 64 partitions of 1 024 nodes (the configuration on which more GPUs add chains, DESIGN 7): on one
     # GPU the three-workgroup build of k_wide (8 scanner waves per partition), k_pipe under CNS_SELECT_KERNEL=pipe
     "c4p64": ("C4p64", None, None, None),
+    # C4 + an ALL partition over all 65 536 nodes (synth.MIXED C4all64k): ONE group of 131 072 slots, the whole queue one chain — on
+    # k_wide's home workgroup alone (k_mem).  The first 300 000 jobs of the queue (the oracle's single process: minutes; the engine's
+    # chain: ~20 s); the cluster is at full size, which is what the case is about.
+    "c4all64k": ("C4all64k", 300_000, None, None),
 }
 
 

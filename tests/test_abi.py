@@ -40,7 +40,7 @@ def test_header_symbols_exported(built):
     assert set(snames) == set(engine.STEPS_ABI_SYMBOLS)
     for n in snames:
         assert hasattr(lib, n), f"{n} declared in steps.h but not exported"
-    # ... and preempt.h (preemption inside the cycle, SURVEY 8f-4: served on the device, DESIGN.md 5j)
+    # ... and preempt.h (preemption inside the cycle, SURVEY 8f-4: served on the device, DESIGN.md 6.7)
     qnames = header_functions("preempt.h")
     assert set(qnames) == set(engine.PREEMPT_ABI_SYMBOLS)
     for n in qnames:

@@ -57,7 +57,7 @@ def test_launch_is_sized_by_the_partitions_that_have_pending_jobs(built):
 def test_c4p256_shards_get_the_k_wide_build_the_plan_predicts(built, world, expect):
     """C4p256 (256 partitions of 256 nodes): what each rank of an N-GPU run executes — its own snapshot (sharding.shard_cluster),
     its own jobs — run here rank after rank on ONE GPU, merged like bench.py's all-gather, compared with the single-engine run.
-    One GPU: 256 partitions -> k_pipe; 4 GPUs: 64 per rank -> k_wide x8; 8 GPUs: 32 per rank -> k_wide x16 (DESIGN.md 6)."""
+    One GPU: 256 partitions -> k_pipe; 4 GPUs: 64 per rank -> k_wide x8; 8 GPUs: 32 per rank -> k_wide x16 (DESIGN.md 7)."""
     import numpy as np
     from cranesched_amd import sharding, synth
     from cranesched_amd.engine import GpuNodeSelector

@@ -25,6 +25,8 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
     if tag == "c4rp" and os.environ.get("CNS_SELECT_KERNEL") in ("pipe", "wide32"):
         pytest.skip("the preempting partition runs on k_select's general path under every setting (25 s each): legacy and wide cover "
                     "the two shapes of the cycle (one launch / split), the other partitions are C4r's")
+    if tag == "c4all64k" and os.environ.get("CNS_SELECT_KERNEL") != "wide":
+        pytest.skip("the one group of 131 072 slots runs on k_wide's home workgroup alone (k_mem) under every setting: once is enough")
     ref = dict(np.load(path))
     name, J, N, P = CASES[tag]
     cluster, jobs, now, running, pre = load_case5(name, J, N, P)

@@ -159,3 +159,31 @@ def test_wide_tile_heterogeneous_serial_paths(engine_default, seed, N):
         assert eng.wide_stats()["serial_jobs"] > 50
     finally:
         eng.close()
+
+
+def c4_with_all_partition(J):
+    """synth.MIXED "C4all64k": C4's cluster and queue plus an "ALL" partition over all 65 536 nodes (one group of 131 072 slots)."""
+    return synth.make_mixed("C4all64k", J=J)[:3]
+
+
+def test_c4_with_an_all_partition_over_the_whole_cluster(built):
+    """c4all64k: round 3 refused this snapshot (a group above k_select's 16 576 slots).  Now the group runs on k_wide's home workgroup
+    alone (k_mem: the sequential protocol, tester waves scanning the committed HBM arrays): the first 60 000 jobs of C4's queue on
+    the full 65 536-node cluster, whole result and every (partition, node) cost against the oracle, time maps of a node sample."""
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    from tests import helpers
+    c, j, now = c4_with_all_partition(60_000)
+    assert int(c.part_offsets[-1]) == 131_072
+    ref = pyoracle.select(c, j, now)
+    eng = GpuNodeSelector(device=0)
+    try:
+        eng.set_nodes(c)
+        got = eng.node_select(now, j)
+        t = eng.timing()["select_ms"]
+        assert eng.last_kernel().startswith("k_mem"), eng.last_kernel()
+        helpers.assert_same(eng, got, ref, c, sample_nodes=256, tag="c4all64k")
+        print(f"c4all64k: {j.num_jobs} jobs x {c.num_nodes} nodes, one group of {int(c.part_offsets[-1])} slots: {eng.last_kernel()} "
+              f"{t:.1f} ms = {1e3 * t / j.num_jobs:.1f} us per decision")
+    finally:
+        eng.close()

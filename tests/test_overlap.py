@@ -106,3 +106,32 @@ def test_shared_group_wider_than_k_select_s_register_tile_on_gpu(built, seed, la
         helpers.assert_same(eng, got, ref, c, sample_nodes=600, tag=f"wide group {seed} {lay}")
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_one_cycle_on_three_kernels_wide_group_small_group_plain_partition(built):
+    """One snapshot, one cycle: a group too wide for k_select (ALL over 12 000 nodes + two subsets -> k_mem), a small group (two
+    partitions sharing 1 000 nodes -> k_select) and a plain partition (-> k_wide), launched side by side; every result against
+    the oracle."""
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    N = 24000
+    c, j, now, run = helpers.random_case(11, N=N, J=9000, P=6, running=60)
+    rng = np.random.default_rng(777)
+    parts = [np.arange(12000), np.sort(rng.choice(12000, 4000, replace=False)), np.sort(rng.choice(12000, 3000, replace=False)),
+             np.arange(12000, 18000), np.arange(18000, 24000), np.arange(23000, 24000)]
+    off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint32)
+    c = abi.Cluster(c.cpu_total_raw, c.mem_total, c.core_lo, c.core_hi, c.gres_slots, off, np.concatenate(parts).astype(np.uint32),
+                    gres=c.gres, schedulable=c.schedulable)
+    j.partition[:] = np.where(j.partition >= 6, j.partition, rng.integers(0, 6, j.num_jobs)).astype(np.uint32)
+    ref = pyoracle.select(c, j, now, running=run)
+    eng = GpuNodeSelector(device=0)
+    try:
+        eng.set_nodes(c)
+        eng.set_running(run)
+        got = eng.node_select(now, j)
+        k = eng.last_kernel()
+        assert k.startswith("k_wide") and "k_select" in k and "k_mem" in k, k
+        helpers.assert_same(eng, got, ref, c, sample_nodes=600, tag="three kernels")
+    finally:
+        eng.close()

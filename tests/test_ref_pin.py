@@ -139,7 +139,7 @@ def test_reservations_random(seed):
     try:
         both(f"resv {seed}", c, j, now, running=run, reservations=rv)
     except pyoracle.RefAsserted as e:
-        # DESIGN.md §7: node lists inside reservations can reach the reference's own CRANE_ASSERT_MSG
+        # DESIGN.md §8: node lists inside reservations can reach the reference's own CRANE_ASSERT_MSG
         # (JobScheduler.cpp:6313-6317): the oracle keeps that assertion, so it must fail on the same input
         with pytest.raises(Exception):
             pyoracle.select(c, j, now, running=run, reservations=rv)
@@ -292,7 +292,7 @@ def test_reference_code_reproduces_the_committed_fullrun_digest():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# DESIGN.md §7: the input class on which the REFERENCE ITSELF asserts (CRANE_ASSERT_MSG, JobScheduler.cpp:6313-6317):
+# DESIGN.md §8: the input class on which the REFERENCE ITSELF asserts (CRANE_ASSERT_MSG, JobScheduler.cpp:6313-6317):
 # get_max_tasks counts 0.5-cpu tasks one by one (no core ids asked), the distribution composes them into one whole-cpu
 # request that needs core ids the node's leftover set does not have
 # ---------------------------------------------------------------------------------------------------------------------

@@ -66,7 +66,7 @@ def _worker(rank, world, port, q, cfg=("C4", 6000, 512, 8)):
 
 
 # C4: 8 partitions (rank r owns partitions p % world == r); C4p64: the same cluster cut into 64 partitions of 1 024 nodes — the
-# configuration on which more GPUs add chains (bench.py --config C4p64, DESIGN.md 6); C4r: the loaded cluster
+# configuration on which more GPUs add chains (bench.py --config C4p64, DESIGN.md 7); C4r: the loaded cluster
 # C4p256: 256 partitions (one GPU: k_pipe; 4 / 8 GPUs: 64 / 32 busy partitions per rank -> k_wide x8 / x16)
 @pytest.mark.parametrize("world,cfg", [(2, ("C4", 6000, 512, 8)), (2, ("C4p64", 8000, 1024, 64)), (4, ("C4p64", 8000, 1024, 64)),
                                        (2, ("C4r", 6000, 512, 8)), (2, ("C4p256", 12000, 2048, 256)), (4, ("C4p256", 12000, 2048, 256)),
