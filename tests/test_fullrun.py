@@ -38,11 +38,13 @@ def test_committed_digests_well_formed(tag):
     assert os.path.exists(path), f"{path} missing: run tests/golden/make_fullrun.py {tag}"
     d = np.load(path)
     name, J, N, P = make_fullrun.CASES[tag]
-    base = {"C4all": "C4", "C4rp": "C4", "C4v": "C4"}.get(name, synth.LOADED.get(name, (name,))[0])
+    base = {"C4all": "C4", "C4rp": "C4", "C4v": "C4", "C4all64k": "C4"}.get(name, synth.LOADED.get(name, (name,))[0])
     J = J or synth.CONFIGS[base]["J"]
     assert int(d["jobs"][0]) == J and int(d["nodes"][0]) == (N or synth.CONFIGS[base]["N"])
     assert len(d["chunk_crc"]) == (J + fullrun.CHUNK - 1) // fullrun.CHUNK
     assert int(d["counts"].sum()) == J
-    if tag != "c5":  # the frozen C5 queue does not fill its 64 k nodes (see make_fullrun.CASES["c5deep"])
+    if tag == "c4all64k":   # a prefix of C4's queue on the FULL cluster (the case is about the 131 072-slot group): 10.6 % backfilled
+        assert d["counts"][1] >= J // 12
+    elif tag != "c5":  # the frozen C5 queue does not fill its 64 k nodes (see make_fullrun.CASES["c5deep"])
         # later starts: "Priority", or "Resource" with a start time on a loaded cluster (allocation > cycle-start res_avail)
         assert d["counts"][1] + (d["counts"][2] if (name in synth.LOADED or name == "C4rp") else 0) >= J // 5, "the queue must reach the backfill regime (>= 20 % backfilled)"
