@@ -79,7 +79,8 @@ struct UpdRec {  // what the owning scanner lane must refresh after a commit
   u32 pad;
 };
 
-enum JobFlags : u32 { kJfExclusive = 1, kJfIncl = 2, kJfExcl = 4, kJfGres = 8 };
+enum JobFlags : u32 { kJfExclusive = 1, kJfIncl = 2, kJfExcl = 4, kJfGres = 8,
+                      kJfMayPreempt = 16 };   // (set per cycle by k_prep_jobs: the job's qos lists a qos it may preempt, JobScheduler.cpp:6384-6385)
 
 // Preemption tables (include/crane_gpu/preempt.h; null / 0 unless the cycle runs with preemption enabled, which forces
 // k_select's general path: TryPreempt_ RELEASES resources, the one thing every fast path excludes).

@@ -48,6 +48,17 @@ __device__ __forceinline__ u64 cost_key_m(double c, u64 smode) {
   return b ^ (smode & ((u64)((i64)b >> 63) | 0x8000000000000000ull));
 }
 
+__device__ __forceinline__ double cost_of_key_m(u64 key, u64 smode) {   // the cost behind such a key
+  return __longlong_as_double((long long)(key ^ (smode & ((u64)((i64)~key >> 63) | 0x8000000000000000ull))));
+}
+// A cycle with preemption (KParams::general_only) sends every job through k_select's general path — except the jobs that can
+// preempt nobody (kJfMayPreempt clear: TryPreempt_ returns at once for them, JobScheduler.cpp:6384-6385) and have the shape of
+// the inline path: one node, ntasks == node_num, tpn_min == 1, not exclusive.  Worker and scanners evaluate this on the same
+// record, so both sides agree per job on the path, the barrier schedule and where the owner updates go (LDS / HBM).
+__device__ __forceinline__ bool inline_in_preempt_cycle(u32 flags, u32 k, bool general, bool tmin1) {
+  return k == 1 && !general && tmin1 && !(flags & (kJfExclusive | kJfMayPreempt));
+}
+
 __device__ __forceinline__ u32 uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni32((u32)(v >> 32)) << 32) | uni32((u32)v); }
 __device__ __forceinline__ u32 rl32(u32 v, u32 idx) { return (u32)__builtin_amdgcn_readlane((int)v, (int)idx); }
@@ -77,6 +88,28 @@ __device__ __forceinline__ const __attribute__((address_space(1))) T* as_global(
 }
 #else   // (A/B builds)
 template <class T> __device__ __forceinline__ const T* as_global(const T* p) { return p; }
+#endif
+
+// ... and kparams_scalar() brings the block itself back into SCALAR registers inside such a routine: a copy through the constant
+// address space at a readfirstlane'd address, which the compiler splits into s_load's of the fields the routine uses (batched at the
+// entry, served by the scalar cache) — instead of one flat_load + `s_waitcnt vmcnt(0) lgkmcnt(0)` per pointer read from *Pg, each of
+// which also waited for every store in flight (the testers' commit: ten of them in a row behind the time-map stores; profiles/
+// r04_tester_phases.txt).  Rules for the copy: hand it only to __forceinline__ routines (its address must not escape), and index
+// nothing in it dynamically — the GRES tables are read through Pg->gres.  (The block is written by the host before the launch
+// and by nobody during it.)
+#ifndef CNS_NO_KPARAMS_SCALAR
+__device__ __forceinline__ KParams kparams_scalar(const KParams* Pg) {
+  typedef const __attribute__((address_space(4))) u64* ConstU64;
+  static_assert(sizeof(KParams) % 8 == 0, "copied as 64-bit words");
+  const ConstU64 s = (ConstU64)(uintptr_t)uni64((u64)(uintptr_t)Pg);
+  KParams P;
+  u64* const d = (u64*)&P;
+#pragma unroll
+  for (u32 i = 0; i < (u32)(sizeof(KParams) / 8); ++i) d[i] = s[i];
+  return P;
+}
+#else   // (A/B builds: the routines read the block in HBM field by field, as before)
+__device__ __forceinline__ const KParams& kparams_scalar(const KParams* Pg) { return *Pg; }
 #endif
 
 // wave-uniform values -> SGPRs, so that the worker's GetFeasibleResourceInNode arithmetic runs on the
@@ -547,7 +580,13 @@ __global__ __launch_bounds__(256) void k_prep_jobs(const KParams* __restrict__ P
   auto g64 = [&](u32 f) { return ((u64)rec[f + 1] << 32) | rec[f]; };
   Req nv;
   nv.cpu = (i64)g64(kJrNcpu); nv.mem = g64(kJrNmem); nv.gtot = rec[kJrGtot]; nv.gspec = g64(kJrGspec);
-  const u32 k = rec[kJrK], ntasks = rec[kJrNtasks], tmin = rec[kJrTmin], flags = rec[kJrFlags];
+  const u32 k = rec[kJrK], ntasks = rec[kJrNtasks], tmin = rec[kJrTmin];
+  u32 flags = rec[kJrFlags] & ~(u32)kJfMayPreempt;
+  if (P.pre.enabled) {   // TryPreempt_ returns at once for a job whose qos may preempt nobody (:6384-6385): such a job of a cycle with
+    const u32 jq = P.pre.pj_qos[rec[kJrOrig]];   // preemption keeps k_select's inline path (the worker's and the scanners' `shared_nodes`)
+    if (jq < P.pre.num_qos && P.pre.qp_off[jq] != P.pre.qp_off[jq + 1]) flags |= kJfMayPreempt;
+  }
+  rec[kJrFlags] = flags;
   const Req mv = compose(nv, (i64)g64(kJrTcpu), g64(kJrTmem), tmin);
   const bool possible = !req_impossible(mv);
   const u32 rq = nibbles_of(nv.gspec);
@@ -956,10 +995,20 @@ struct NodeSum {
   u64 fcnt;
 };
 
+// UpdateNodeSelectorWithScheduledJob (h:636-642) for a job committed by the inline path in a cycle with preemption (lane 0 of the
+// worker; what commit_selection does for the general path): the job joins its node's qos_job_map.  Out of line: the inline path of
+// every other cycle must not carry its registers.
+__device__ __noinline__ void pre_join_single(const KParams& P, u32 q, u64 poff, u32 orig, i64 end) {
+  const u32 hq = P.slot_block ? P.slot_block[q] : q;
+  P.pre.rec_orig[poff] = orig; P.pre.rec_slot[poff] = q; P.pre.rec_gone[poff] = 0;
+  P.pre.rec_next[poff] = P.pre.slot_head[hq];
+  P.pre.slot_head[hq] = (u32)poff;
+  P.pre.pj_rec0[orig] = (u32)poff; P.pre.pj_k[orig] = 1; P.pre.pj_end[orig] = end;
+}
 __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 orig, u64 poff, NodeHdr* hd,
                                                    const NodeHdr& h, const TlEntry& e, u32 q, u32 code, double cost,
                                                    const Res& alloc, i64 start, int reason, u32 lane, UpdRec* s_upd,
-                                                   int* s_nupd, NodeSum& ns) {
+                                                   int* s_nupd, NodeSum& ns, const KParams& Pmem) {   // (Pmem: the block's copy in HBM)
   const i64 end = start + L;
   const u32 newlen = tl_commit_regs(P, hd, tl_of(P, hd), e, h.len, start, end, alloc, lane, orig);
   const double ratio = ((double)alloc.cpu / 256.0) / ((double)h.total.cpu / 256.0);
@@ -994,6 +1043,7 @@ __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 
     if (P.o_c2) { P.o_c2[poff] = alloc.c2; P.o_c3[poff] = alloc.c3; }
     P.o_start[orig] = start;
     P.o_reason[orig] = (uint8_t)reason;
+    if (P.pre.enabled) pre_join_single(Pmem, q, poff, orig, end);
   }
 }
 
@@ -1071,6 +1121,7 @@ struct WorkerShared {
   UpdRec* upd;
   HeapEnt* heap;
   u32 part;   // engine partition this workgroup serves (k_select / k_pipe: blockIdx.x; k_wide: several workgroups per partition)
+  u32* pre_cache;   // LDS: the segment-tree cache of TryPreempt_ (preempt_dev.inc; k_select only — the other kernels refuse such cycles)
 };
 
 #ifdef CNS_PROF
@@ -1107,7 +1158,9 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   }
   const u32 orig = J.orig;
   HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
-  UpdRec* const s_upd = (J.k <= (u32)kMaxUpd && !P.sib_off && !P.general_only) ? sh.upd : P.g_upd + qbeg;  // long lists (sibling slots of shared nodes, releases of a preemption) go through HBM
+  // (a job of the inline path's shape that can preempt nobody, diverted to here by a long time map: the scanners expect its update in LDS)
+  const bool via_hbm = J.k > (u32)kMaxUpd || P.sib_off || (P.general_only && !inline_in_preempt_cycle(J.flags, J.k, J.general, J.tmin == 1));
+  UpdRec* const s_upd = !via_hbm ? sh.upd : P.g_upd + qbeg;  // long lists (sibling slots of shared nodes, releases of a preemption) go through HBM
   int* const s_nupd = sh.nupd;
 
   // ---- Phase A: start now (GetNodesAndTrySchedule_, JobScheduler.cpp:6188-6333) -------------
@@ -1159,7 +1212,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
         code = 2;
       }
     }
-    if (J.k > (u32)kMaxUpd || P.sib_off || P.general_only) __threadfence_block();  // the owner updates went through HBM (g_upd)
+    if (via_hbm) __threadfence_block();  // the owner updates went through HBM (g_upd)
     if (lane == 0) *sh.flag = code;
     wg_barrier();  // B2: verdict (and, on success, the owner updates) visible to the scanners
     if (code == 2) return par;
@@ -1227,7 +1280,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     bool preempted = false;
     if (P.pre.enabled) {
       u32 pf = 0;
-      const int nch = pre_try<kS>(P, J, H, qbeg, sh.part, &pf);
+      const int nch = pre_try<kS>(P, J, H, qbeg, sh.part, sh.pre_cache, &pf);
       if (pf && lane == 0) set_fault(P, pf, orig, J.k, 0);
       if (nch >= 0) {
         const u32 nn = P.part_off[sh.part + 1] - qbeg;
@@ -1305,7 +1358,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     }
   }
   if (code == 0 && lane == 0) { P.o_start[orig] = 0; P.o_reason[orig] = 2; }  // "Resource", :6768
-  if (J.k > (u32)kMaxUpd || P.sib_off || P.general_only) __threadfence_block();  // the owner updates went through HBM (g_upd)
+  if (via_hbm) __threadfence_block();  // the owner updates went through HBM (g_upd)
   if (lane == 0) *sh.flag = code;
   wg_barrier();  // B3
   return par;
@@ -1770,6 +1823,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ UpdRec s_upd[kMaxUpd];
   __shared__ HeapEnt s_heap[kLdsHeap];
   __shared__ JobCtx s_job;
+  __shared__ __attribute__((aligned(16))) u32 s_pre_cache[kPreCacheDw];   // TryPreempt_'s tree nodes (preempt_dev.inc): 100 KB, used in cycles with preemption only
   __shared__ int s_ty_cpu[CNS_MAX_NODE_TYPES_DEV];  // per node type: what "completely free" looks like
   __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
   __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
@@ -1806,7 +1860,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     }
     wg_barrier();  // type tables visible to the scanners
     WorkerShared sh;
-    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap; sh.part = part;
+    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap; sh.part = part; sh.pre_cache = s_pre_cache;
     HeapEnt* const gheap = P.heap + qbeg + part;
     // The worker is the serial chain of the whole partition and shares its SIMD with three scanner waves
     // that pre-scan the next job at the same time: let its instructions issue first.
@@ -1823,8 +1877,11 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       PROF_T(p0);
       const FastJob F = make_fast_job(P, raw);
       const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
-      const bool shared_nodes = P.sib_off != nullptr || P.general_only;   // partitions that share nodes / a cycle with preemption: everything through the general path
+      // partitions that share nodes / a cycle with preemption: everything through the general path — but for the jobs of such a
+      // cycle that can preempt nobody (inline_in_preempt_cycle)
+      const bool shared_nodes = P.sib_off != nullptr || (P.general_only && !inline_in_preempt_cycle(F.flags, F.k, F.ntasks != F.k, F.tmin == 1));
       const bool fast = simple && F.k == 1 && F.tmin == 1 && !shared_nodes;
+      const u64 wsmode = P.general_only ? ~0ull : 0ull;   // (the scanners' keys are in signed form in such a cycle: cost_key_m)
 
       if (!pre_valid) {
         wg_barrier();  // B1 (round 0): A and T argmins published by the scanners
@@ -1883,8 +1940,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_T(a2);
           PROF_ADD(2, a1, a2);  // window-min + feasibility
           if (ok) {  // tpn_min == 1: the minimum view is the 1-task view, f is the allocation (:6312-6320)
-            commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, __longlong_as_double((long long)wc), f,
-                               P.now, 0, lane, s_upd, &s_nupd, cn);
+            commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, cost_of_key_m(wc, wsmode), f,
+                               P.now, 0, lane, s_upd, &s_nupd, cn, PG);
             code = 2;
           }
           PROF_T(a3);
@@ -1959,8 +2016,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
                   else reason = res_le(alloc, h.avail0) ? 1 /*Priority*/ : 2 /*Resource*/;
                 }
                 PROF_T(b0c);
-                commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, __longlong_as_double((long long)tc),
-                                   alloc, st, reason, lane, s_upd, &s_nupd, cn);
+                commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, cost_of_key_m(tc, wsmode),
+                                   alloc, st, reason, lane, s_upd, &s_nupd, cn, PG);
                 PROF_T(b0d);
                 PROF_ADD(10, b0c, b0d);  // phase B: commit
                 code = 2;
@@ -2072,7 +2129,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       raw = raw_n;
       raw_n = ji + 2 < jend ? fetch_job(P, ji + 2) : 0u;
       const u32 nflags = rl32(raw, kJrFlags);
-      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl));
+      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl)) && !P.general_only;   // (no pre-scan in a cycle with preemption: its merge compares raw keys)
       if (nv) {
         const FastJob Fn = make_fast_job(P, raw);
         u64 ac = s_pc[lane & (kRed - 1)];
@@ -2418,8 +2475,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       ScanJob Jn = J;
       u64 typeok_n = typeok;
       const bool have_next = ji + 1 < jend;
-      const bool shared_nodes = P.sib_off != nullptr || P.general_only;
-      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes;  // this job touches one node, a round-0 winner
+      const bool shared_nodes = P.sib_off != nullptr || (P.general_only && !inline_in_preempt_cycle(J.flags, kk, general, (J.shape & 2u) != 0));
+      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes && !P.general_only;  // this job touches one node, a round-0 winner
       RM skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= kOne << (wcode >> 10);
       if ((tcode & 1023u) == t && tcode != kNone) {

@@ -288,10 +288,11 @@ static int cycle_bench(int n_nodes, int n_jobs, int threads = 1) {
 // One whole NodeSelect through the adapter at full size, on the GPU: what an integrator's ScheduleThread sees between entering and
 // leaving m_node_selection_algo_->NodeSelect (JobScheduler.cpp:1439-1447) — packing, cns_select, write-back — P partitions of N / P nodes
 // (64 cores, 256 GiB), J pending jobs of 1..8 cores for 10..170 minutes, spread over the partitions.
-static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred) {
+static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred, int threads) {
   GpuNodeSelectionAlgo algo(0);
   if (!algo.Ok()) { printf("engine: %s\n", algo.LastError().c_str()); return 2; }
   algo.SetDeferredWriteBack(deferred);
+  algo.SetHostThreads(threads);
   ClusterSnapshot snap;
   std::vector<std::vector<CranedId>> ids(n_parts);
   for (int i = 0; i < n_nodes; ++i) {
@@ -304,8 +305,8 @@ static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred) {
   algo.SetClusterSnapshot(snap);
   if (!algo.Ok()) { printf("snapshot: %s\n", algo.LastError().c_str()); return 2; }
   std::vector<std::unique_ptr<RnJobInScheduler>> running;
-  printf("e2e-bench: %d nodes in %d partitions, %d pending jobs, %s write-back, one NodeSelect per line (1 host thread + 1 GPU)\n", n_nodes, n_parts, n_jobs,
-         deferred ? "deferred (allocated_res on demand)" : "lazy (default)");
+  printf("e2e-bench: %d nodes in %d partitions, %d pending jobs, %s write-back, one NodeSelect per line (%d host thread%s + 1 GPU)\n", n_nodes, n_parts, n_jobs,
+         deferred ? "deferred (allocated_res on demand)" : "lazy (default)", threads, threads == 1 ? "" : "s");
   for (int rep = 0; rep < 4; ++rep) {
     std::vector<std::unique_ptr<PdJobInScheduler>> pd;
     uint64_t x = 0x9E3779B97F4A7C15ull;
@@ -446,7 +447,7 @@ static int wire_dump(const char* path, int n, bool jobtod) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000, argc > 4 ? atoi(argv[4]) : 1);
-  if (argc > 1 && !strcmp(argv[1], "--e2e-bench")) return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"));
+  if (argc > 1 && !strcmp(argv[1], "--e2e-bench")) return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"), argc > 6 ? atoi(argv[6]) : 1);
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
   if (argc > 2 && !strcmp(argv[1], "--wire-dump")) return wire_dump(argv[2], argc > 3 ? atoi(argv[3]) : 600, argc > 4 && !strcmp(argv[4], "jobtod"));
   if (argc > 1 && !strcmp(argv[1], "--mirror-check")) return mirror_check(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 20000);

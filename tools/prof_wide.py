@@ -46,3 +46,12 @@ if m[15]:
     print(f"  tester 0: {m[15]:.0f} retirements with progress at {m[6]/m[15]:.0f} cycles (incl. commits); {m[31]:.0f} idle naps")
 if m[9]:
     print(f"  tester 0: {m[9]:.0f} tasks tested, {m[8]/m[9]:.0f} cyc/test (incl. dependency waits); 7 testers => {m[8]/m[9]/7:.0f} cyc/job of test capacity used")
+if os.environ.get("CNS_PROF_TESTER"):   # a -DCNS_PROF_TESTER build: tester 0's test and commit by phase (in the leader's slots)
+    n0 = max(m[0], 1)
+    print(f"  tester 0, node_num 1 start now: {m[0]:.0f} tests; job record {m[1]/n0:.0f} | dependency wait {m[2]/n0:.0f} | node block {m[3]/n0:.0f} | "
+          f"window minimum + exact test {m[4]/n0:.0f} cycles; verdict into the slot {m[5]/max(m[9],1):.0f} (all kinds)")
+    print(f"  tester 0, node_num 1 backfill: {m[10]:.0f} tests at {m[11]/max(m[10],1):.0f} cycles; node_num > 1: {m[12]:.0f} tests at {m[13]/max(m[12],1):.0f} cycles; "
+          f"dropped before the test {m[14]:.0f}")
+    nc = max(m[16], 1)
+    print(f"  tester 0, commits: {m[16]:.0f}; claim + task fields {m[17]/nc:.0f} | node blocks {m[18]/nc:.0f} | map + cost + arrays + record {m[19]/nc:.0f} | "
+          f"start/reason + drain + state {m[20]/nc:.0f} cycles per commit")
