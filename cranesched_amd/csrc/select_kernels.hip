@@ -1143,8 +1143,9 @@ struct WorkerShared {
 // round-0 barrier with the A and T winners, leaves after the job's last barrier; returns the LDS
 // double-buffer parity.
 template <u32 kS = kScan>
-__device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared sh, const JobCtx* Jp, int par,
+__device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShared sh, const JobCtx* Jp, int par,
                                             u64 wc, u32 wcode, u64 tc, u32 tcode, u32 qbeg, HeapEnt* gheap) {
+  const auto& P = kparams_scalar(&Pm);   // (Pm: the block's copy in HBM — what the out-of-line routines and the GRES tables are given)
   const JobCtx J = *Jp;
   const u32 lane = threadIdx.x & 63u;
   drain_stores();
@@ -1153,8 +1154,8 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
   int tt_lane = 0;
   if (lane < P.num_types) {
     const Res ttot = P.type_total[lane];
-    if (J.general) tt_lane = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, ttot, P.gres);
-    else { Res tmp; tt_lane = feasible(J.min_view, ttot, tmp, P.gres) ? (int)J.tmin : 0; }
+    if (J.general) tt_lane = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, ttot, Pm.gres);
+    else { Res tmp; tt_lane = feasible(J.min_view, ttot, tmp, Pm.gres) ? (int)J.tmin : 0; }
   }
   const u32 orig = J.orig;
   HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
@@ -1178,10 +1179,10 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
     if (!excl_job) {
       const Res a0 = hd->avail0;
       Res f;
-      if (feasible(J.min_view, a0, f, P.gres)) {             // :6274
+      if (feasible(J.min_view, a0, f, Pm.gres)) {             // :6274
         m = window_min(T, len, a0, J.E, lane);               // :6278-6283
-        if (J.general) ta = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, m, P.gres);  // :6285
-        else ta = feasible(J.min_view, m, f, P.gres) ? (int)J.tmin : 0;
+        if (J.general) ta = max_tasks(J.min_view, J.tcpu, J.tmem, J.tmin, J.tmax, m, Pm.gres);  // :6285
+        else ta = feasible(J.min_view, m, f, Pm.gres) ? (int)J.tmin : 0;
         ok = ta > 0;
       }
     } else {
@@ -1206,8 +1207,8 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       __threadfence_block();
       code = 1;
       if (hsize == (int)J.k && (u32)hsum >= J.ntasks) {                   // :6294-6297
-        if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 2, orig, n, 2); }
-        commit_selection<kS>(P, J, H, qbeg, P.now, lane, s_upd, s_nupd);      // start_time = now (:6326)
+        if (!distribute_and_alloc(Pm, J, H, lane)) { if (lane == 0) set_fault(P, 2, orig, n, 2); }
+        commit_selection<kS>(Pm, J, H, qbeg, P.now, lane, s_upd, s_nupd);      // start_time = now (:6326)
         if (lane == 0) { P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
         code = 2;
       }
@@ -1275,20 +1276,20 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
       P.bf_j[qbeg + i] = 0;
     }
     __threadfence_block();
-    if (!distribute_and_alloc(P, J, H, lane)) { if (lane == 0) set_fault(P, 3, orig, 0, 1); }
+    if (!distribute_and_alloc(Pm, J, H, lane)) { if (lane == 0) set_fault(P, 3, orig, 0, 1); }
     // TryPreempt_ before Backfill_ (JobScheduler.cpp:6140-6143), only in a cycle that was started with preemption
     bool preempted = false;
     if (P.pre.enabled) {
       u32 pf = 0;
-      const int nch = pre_try<kS>(P, J, H, qbeg, sh.part, sh.pre_cache, &pf);
+      const int nch = pre_try<kS>(Pm, J, H, qbeg, sh.part, sh.pre_cache, &pf);
       if (pf && lane == 0) set_fault(P, pf, orig, J.k, 0);
       if (nch >= 0) {
         const u32 nn = P.part_off[sh.part + 1] - qbeg;
         u32* const touched = P.bf_j + qbeg;   // (the backfill cursors are not needed on this branch)
-        const u32 nt = pre_release(P, J, qbeg, nn, sh.part, (u32)nch, touched);
+        const u32 nt = pre_release(Pm, J, qbeg, nn, sh.part, (u32)nch, touched);
         for (u32 i = lane; i < J.k; i += 64) H[i].cost = P.cost[qbeg + slot_of_code_t<kS>(H[i].p)];   // the releases lowered costs
         __threadfence_block();
-        commit_selection<kS>(P, J, H, qbeg, P.now, lane, s_upd, s_nupd);   // start_time = now (:6501), h:630-634
+        commit_selection<kS>(Pm, J, H, qbeg, P.now, lane, s_upd, s_nupd);   // start_time = now (:6501), h:630-634
         // the scanners' rows of the nodes that were released on (other than the job's own: their records are final)
         u32 nup = (u32)*s_nupd;
         for (u32 x = 0; x < nt; ++x) {
@@ -1352,7 +1353,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& P, const WorkerShared
         const bool resv_part = sh.part >= P.num_real_parts;
         reason = (!resv_part && __any(reserved)) ? 3 /*Resource Reserved*/ : (__any(notle) ? 2 /*Resource*/ : 1 /*Priority*/);
       }
-      commit_selection<kS>(P, J, H, qbeg, t, lane, s_upd, s_nupd);
+      commit_selection<kS>(Pm, J, H, qbeg, t, lane, s_upd, s_nupd);
       if (lane == 0) { P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
       code = 2;
     }

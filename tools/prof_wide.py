@@ -55,3 +55,10 @@ if os.environ.get("CNS_PROF_TESTER"):   # a -DCNS_PROF_TESTER build: tester 0's 
     nc = max(m[16], 1)
     print(f"  tester 0, commits: {m[16]:.0f}; claim + task fields {m[17]/nc:.0f} | node blocks {m[18]/nc:.0f} | map + cost + arrays + record {m[19]/nc:.0f} | "
           f"start/reason + drain + state {m[20]/nc:.0f} cycles per commit")
+if os.environ.get("CNS_PROF_FAST"):   # a -DCNS_PROF_FAST build: the scanners' steady-state loop, summed over the waves of a partition
+    for w, what in ((0, "a wave that did not win the job before"), (1, "the wave that won the job before")):
+        n = max(m[0 + w], 1)
+        print(f"  steady-state loop, {what}: {m[0+w]:.0f} wave-jobs; record + rows + argmin + publish {m[2+w]/n:.0f} | publish -> exchange complete {m[4+w]/n:.0f} | "
+              f"decision + row write {m[6+w]/n:.0f} cycles")
+    n = max(m[0] + m[1], 1)
+    print(f"  wave-jobs that recomputed the res_total argmin {m[8]/n:.3f}; first poll found the exchange complete {m[9]/n:.3f}")
