@@ -1121,7 +1121,6 @@ struct WorkerShared {
   UpdRec* upd;
   HeapEnt* heap;
   u32 part;   // engine partition this workgroup serves (k_select / k_pipe: blockIdx.x; k_wide: several workgroups per partition)
-  u32* pre_cache;   // LDS: the segment-tree cache of TryPreempt_ (preempt_dev.inc; k_select only — the other kernels refuse such cycles)
 };
 
 #ifdef CNS_PROF
@@ -1281,7 +1280,12 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
     bool preempted = false;
     if (P.pre.enabled) {
       u32 pf = 0;
-      const int nch = pre_try<kS>(Pm, J, H, qbeg, sh.part, sh.pre_cache, &pf);
+      int nch = -1;
+      // (only k_select runs cycles with preemption, and only its instantiation reaches g_pre_cache: the 100 KB of LDS are allocated
+      // in k_select's kernels alone — a pointer through WorkerShared cost every kernel two more argument registers at each call of
+      // an out-of-line worker routine, and k_select its spill-free allocation)
+      if constexpr (kS == kScan) nch = pre_try<kS>(Pm, J, H, qbeg, sh.part, &pf);
+      else pf = 33;
       if (pf && lane == 0) set_fault(P, pf, orig, J.k, 0);
       if (nch >= 0) {
         const u32 nn = P.part_off[sh.part + 1] - qbeg;
@@ -1824,7 +1828,6 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ UpdRec s_upd[kMaxUpd];
   __shared__ HeapEnt s_heap[kLdsHeap];
   __shared__ JobCtx s_job;
-  __shared__ __attribute__((aligned(16))) u32 s_pre_cache[kPreCacheDw];   // TryPreempt_'s tree nodes (preempt_dev.inc): 100 KB, used in cycles with preemption only
   __shared__ int s_ty_cpu[CNS_MAX_NODE_TYPES_DEV];  // per node type: what "completely free" looks like
   __shared__ u32 s_ty_m16[CNS_MAX_NODE_TYPES_DEV];
   __shared__ u32 s_ty_gn[CNS_MAX_NODE_TYPES_DEV];
@@ -1861,7 +1864,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     }
     wg_barrier();  // type tables visible to the scanners
     WorkerShared sh;
-    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap; sh.part = part; sh.pre_cache = s_pre_cache;
+    sh.wc = s_wc; sh.wp = s_wp; sh.flag = &s_flag; sh.nupd = &s_nupd; sh.upd = s_upd; sh.heap = s_heap; sh.part = part;
     HeapEnt* const gheap = P.heap + qbeg + part;
     // The worker is the serial chain of the whole partition and shares its SIMD with three scanner waves
     // that pre-scan the next job at the same time: let its instructions issue first.
