@@ -1391,6 +1391,8 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
   Q.pool = misc; Q.pool_nodes = pool_nodes; Q.cand_cap = cand_cap;
   Q.cand = (u32*)(misc + off_cand); Q.chosen = (u32*)(misc + off_chosen);
   Q.out_cnt = (u32*)(misc + off_cnt); Q.out = (u32*)(misc + off_out); Q.out_cap = out_cap;
+  // CNS_PREEMPT_TREE=literal: TryPreempt_ on the node-for-node trees only (else: the fall-back of a call that runs out of compressed records)
+  { const char* tr = getenv("CNS_PREEMPT_TREE"); Q.literal_tree = (tr && !strcmp(tr, "literal")) ? 1u : ((tr && !strcmp(tr, "tiny")) ? 2u : 0u); }   // tiny: a handful of compressed records per call, the rest falls back
   // the partitions that have a pending job whose qos may preempt: only they run on k_select's general path (run_resident_once)
   h->pre_part.assign(h->P, 0);
   for (u64 j = 0; j < J; ++j) {

@@ -121,7 +121,8 @@ struct PreParams {
   u32* chosen;             // [P * cand_cap] preempted_jobs of the job at hand
   u32* out_cnt;            // [1] pairs appended so far
   u32* out;                // [2 * out_cap] (pending job (orig), reference) in push_back order per job
-  u32 out_cap, pad0;
+  u32 out_cap;
+  u32 literal_tree;        // debug / tests: 1 skip the compressed trees (preempt_dev.inc), run every call node for node; 2 give them room for a handful of records only
 };
 
 struct KParams {

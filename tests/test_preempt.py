@@ -235,6 +235,26 @@ def test_engine_preempt_random_cases(built, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(0, 40, 3))
+def test_engine_preempt_on_the_node_for_node_trees(built, seed, monkeypatch):
+    """TryPreempt_'s trees run in a compressed form on the device (tests/seg_compact.py); a call that needs more records than fit
+    is redone node for node.  CNS_PREEMPT_TREE=literal sends every call down that path, =tiny leaves the compressed form room for
+    a handful of records, so that calls run out of them half way and start again."""
+    monkeypatch.setenv("CNS_PREEMPT_TREE", "literal" if seed % 3 == 0 and seed % 2 == 0 else "tiny")
+    from oracle import pyoracle
+    if seed % 2:
+        c, j, now, run, pre = random_preempt_case(900 + seed, N=48 + 8 * (seed % 6), J=500, P=2, running=120)
+    else:
+        c, j, now, run, pre = random_preempt_case(500 + seed, N=6 + seed % 7, J=50 + seed % 40, P=1 + seed % 2, running=10 + seed % 11)
+    ref = pyoracle.select(c, j, now, running=run, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, now, run, pre)
+    try:
+        compare_engine(f"literal trees {seed}", c, j, ref, eng, pl, po)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(6))
 def test_engine_preempt_larger_cases(built, seed):
     """More nodes, multi-partition, many running jobs: long candidate lists, deep trees, several releases per job."""
