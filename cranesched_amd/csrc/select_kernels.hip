@@ -58,6 +58,13 @@ __device__ __forceinline__ double cost_of_key_m(u64 key, u64 smode) {   // the c
 __device__ __forceinline__ bool inline_in_preempt_cycle(u32 flags, u32 k, bool general, bool tmin1) {
   return k == 1 && !general && tmin1 && !(flags & (kJfExclusive | kJfMayPreempt));
 }
+// ... and in a group of partitions that share nodes the jobs of that shape keep the inline path too (the commit then lists the node's
+// other slots among the owner updates: commit_single_shared); everything else of such a group, and all of it in a cycle with
+// preemption, takes the general path.  true = general path ("shared_nodes" in worker and scanners).
+__device__ __forceinline__ bool general_path_job(bool general_only, bool shared_group, u32 flags, u32 k, bool general, bool tmin1) {
+  if (general_only) return shared_group || !inline_in_preempt_cycle(flags, k, general, tmin1);
+  return shared_group && !(k == 1 && !general && tmin1 && !(flags & kJfExclusive));
+}
 
 __device__ __forceinline__ u32 uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ u64 uni64(u64 v) { return ((u64)uni32((u32)(v >> 32)) << 32) | uni32((u32)v); }
@@ -1005,10 +1012,30 @@ __device__ __noinline__ void pre_join_single(const KParams& P, u32 q, u64 poff, 
   P.pre.slot_head[hq] = (u32)poff;
   P.pre.pj_rec0[orig] = (u32)poff; P.pre.pj_k[orig] = 1; P.pre.pj_end[orig] = end;
 }
+// The owner updates of a job the inline path committed on a node that several partitions list (one time map per node, a cost per
+// partition: JobScheduler.cpp:6563,6609-6617): the own record, then one "keep cost" record per other slot of the node (new length and
+// front summary), through the HBM list — where the scanners of a group of partitions that share nodes look — as commit_selection
+// writes them.  Lane 0 of the worker; out of line: every other cycle's inline path must not carry its registers.
+__device__ __noinline__ void commit_single_shared(const KParams& P, u32 q, u32 qbeg, UpdRec u, int* s_nupd) {
+  UpdRec* const upd = P.g_upd + qbeg;
+  upd[0] = u;
+  u32 nup = 1;
+  for (u32 a = P.sib_off[q]; a < P.sib_off[q + 1]; ++a) {
+    const u32 qs = P.sib[a];
+    UpdRec us = u;
+    const u32 ps = qs - qbeg;
+    us.p = ((ps / kScan) << 10) | (ps % kScan);
+    us.has_front = u.has_front | 2u;
+    if (u.has_front) { P.f_cpu[qs] = u.fcpu; P.f_mem[qs] = u.fmem; P.f_cnt[qs] = u.fcnt; }
+    if (P.f_len) P.f_len[qs] = u.len;
+    upd[nup++] = us;
+  }
+  *s_nupd = (int)nup;
+}
 __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 orig, u64 poff, NodeHdr* hd,
                                                    const NodeHdr& h, const TlEntry& e, u32 q, u32 code, double cost,
                                                    const Res& alloc, i64 start, int reason, u32 lane, UpdRec* s_upd,
-                                                   int* s_nupd, NodeSum& ns, const KParams& Pmem) {   // (Pmem: the block's copy in HBM)
+                                                   int* s_nupd, NodeSum& ns, const KParams& Pmem, u32 qbeg) {   // (Pmem: the block's copy in HBM)
   const i64 end = start + L;
   const u32 newlen = tl_commit_regs(P, hd, tl_of(P, hd), e, h.len, start, end, alloc, lane, orig);
   const double ratio = ((double)alloc.cpu / 256.0) / ((double)h.total.cpu / 256.0);
@@ -1031,8 +1058,8 @@ __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 
     u.pad = 0;
     P.cost[q] = ncost;
     if (has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
-    s_upd[0] = u;
-    *s_nupd = 1;
+    if (P.sib_off) commit_single_shared(Pmem, q, qbeg, u, s_nupd);
+    else { s_upd[0] = u; *s_nupd = 1; }
     P.o_node[poff] = h.node;
     P.o_ntasks[poff] = 1;
     P.o_cpu[poff] = alloc.cpu;
@@ -1045,6 +1072,7 @@ __device__ __forceinline__ void commit_single_regs(const KParams& P, i64 L, u32 
     P.o_reason[orig] = (uint8_t)reason;
     if (P.pre.enabled) pre_join_single(Pmem, q, poff, orig, end);
   }
+  if (P.sib_off) __threadfence_block();   // (the records went through HBM)
 }
 
 // Would node `ns` be a candidate of job X?  b: may host it at all, a: may start it now.  Same meaning as the
@@ -1883,7 +1911,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       const bool simple = !(F.flags & kJfExclusive) && F.ntasks == F.k;  // ntasks == node_num on shared nodes
       // partitions that share nodes / a cycle with preemption: everything through the general path — but for the jobs of such a
       // cycle that can preempt nobody (inline_in_preempt_cycle)
-      const bool shared_nodes = P.sib_off != nullptr || (P.general_only && !inline_in_preempt_cycle(F.flags, F.k, F.ntasks != F.k, F.tmin == 1));
+      const bool shared_nodes = general_path_job(P.general_only != 0, P.sib_off != nullptr, F.flags, F.k, F.ntasks != F.k, F.tmin == 1);
       const bool fast = simple && F.k == 1 && F.tmin == 1 && !shared_nodes;
       const u64 wsmode = P.general_only ? ~0ull : 0ull;   // (the scanners' keys are in signed form in such a cycle: cost_key_m)
 
@@ -1945,7 +1973,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_ADD(2, a1, a2);  // window-min + feasibility
           if (ok) {  // tpn_min == 1: the minimum view is the 1-task view, f is the allocation (:6312-6320)
             commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, cost_of_key_m(wc, wsmode), f,
-                               P.now, 0, lane, s_upd, &s_nupd, cn, PG);
+                               P.now, 0, lane, s_upd, &s_nupd, cn, PG, qbeg);
             code = 2;
           }
           PROF_T(a3);
@@ -2021,7 +2049,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
                 }
                 PROF_T(b0c);
                 commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, cost_of_key_m(tc, wsmode),
-                                   alloc, st, reason, lane, s_upd, &s_nupd, cn, PG);
+                                   alloc, st, reason, lane, s_upd, &s_nupd, cn, PG, qbeg);
                 PROF_T(b0d);
                 PROF_ADD(10, b0c, b0d);  // phase B: commit
                 code = 2;
@@ -2133,7 +2161,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       raw = raw_n;
       raw_n = ji + 2 < jend ? fetch_job(P, ji + 2) : 0u;
       const u32 nflags = rl32(raw, kJrFlags);
-      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl)) && !P.general_only;   // (no pre-scan in a cycle with preemption: its merge compares raw keys)
+      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl)) && !P.general_only && !P.sib_off;   // (no pre-scan in a cycle with preemption: its merge compares raw keys; nor on shared nodes: a commit changes more rows than the two winners')
       if (nv) {
         const FastJob Fn = make_fast_job(P, raw);
         u64 ac = s_pc[lane & (kRed - 1)];
@@ -2479,8 +2507,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       ScanJob Jn = J;
       u64 typeok_n = typeok;
       const bool have_next = ji + 1 < jend;
-      const bool shared_nodes = P.sib_off != nullptr || (P.general_only && !inline_in_preempt_cycle(J.flags, kk, general, (J.shape & 2u) != 0));
-      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes && !P.general_only;  // this job touches one node, a round-0 winner
+      const bool shared_nodes = general_path_job(P.general_only != 0, P.sib_off != nullptr, J.flags, kk, general, (J.shape & 2u) != 0);
+      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes && !P.general_only && !P.sib_off;  // this job touches one node, a round-0 winner
       RM skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= kOne << (wcode >> 10);
       if ((tcode & 1023u) == t && tcode != kNone) {
@@ -2602,7 +2630,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       // ---- owners refresh their registers ---------------------------------------------------------------
       if (verdict == 2) {
         const int nu = s_nupd;
-        const UpdRec* const ub = (nu <= kMaxUpd && !shared_nodes) ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);
+        const UpdRec* const ub = (nu <= kMaxUpd && !shared_nodes && !P.sib_off) ? (const UpdRec*)s_upd : (const UpdRec*)(P.g_upd + qbeg);   // (a group that shares nodes: always the HBM list)
         for (int i = 0; i < nu; ++i) {
           const u32 up = uni32(ub[i].p);
           if (owner_wave(up) == wave) apply_upd(ub[i], up);  // only the owner's wave does any work
