@@ -63,7 +63,8 @@ __device__ __forceinline__ bool inline_in_preempt_cycle(u32 flags, u32 k, bool g
 // preemption, takes the general path.  true = general path ("shared_nodes" in worker and scanners).
 __device__ __forceinline__ bool general_path_job(bool general_only, bool shared_group, u32 flags, u32 k, bool general, bool tmin1) {
   if (general_only) return shared_group || !inline_in_preempt_cycle(flags, k, general, tmin1);
-  return shared_group && !(k == 1 && !general && tmin1 && !(flags & kJfExclusive));
+  // (node_num 2 .. kMultiK of that shape: the parallel protocol, whose helper waves list the sibling slots as well)
+  return shared_group && !(k >= 1 && k <= (u32)kMultiK && !general && tmin1 && !(flags & kJfExclusive));
 }
 
 __device__ __forceinline__ u32 uni32(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
@@ -1624,7 +1625,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
 // Commit of candidate i from the helper's registers + owner update i + its placement record.
 __device__ __forceinline__ void helper_commit_regs(const KParams& P, const GresDev& G, const JobCtx& J, const HeapEnt* H, u32 i, u32 p,
                                                    double cost0, NodeHdr* hd, const NodeHdr& h, const TlEntry& e,
-                                                   const Res& res, i64 start, u32 lane, UpdRec* upd, u32 q) {
+                                                   const Res& res, i64 start, u32 lane, UpdRec* upd, u32 q, u32 sib_at, u32 qbeg) {
   const i64 end = start + J.L;
   const Res e0 = rl_res(e.r, 0);  // entry at `now`
   u32 newlen;
@@ -1643,6 +1644,19 @@ __device__ __forceinline__ void helper_commit_regs(const KParams& P, const GresD
     P.cost[q] = ncost;
     if (u.has_front) { P.f_cpu[q] = u.fcpu; P.f_mem[q] = u.fmem; P.f_cnt[q] = u.fcnt; }
     upd[i] = u;
+    if (P.sib_off) {   // the node's slots in the other partitions of the group: "keep cost" records behind the k own ones, from sib_at
+      u32 x = sib_at;
+      for (u32 a = P.sib_off[q]; a < P.sib_off[q + 1]; ++a) {
+        const u32 qs = P.sib[a];
+        UpdRec us = u;
+        const u32 ps = qs - qbeg;
+        us.p = ((ps / kScan) << 10) | (ps % kScan);
+        us.has_front = u.has_front | 2u;
+        if (u.has_front) { P.f_cpu[qs] = u.fcpu; P.f_mem[qs] = u.fmem; P.f_cnt[qs] = u.fcnt; }
+        if (P.f_len) P.f_len[qs] = newlen;
+        upd[x++] = us;
+      }
+    }
     u32 rank = 0;  // placement records are listed by ascending node index
     for (u32 m = 0; m < J.k; ++m) rank += H[m].node < h.node ? 1u : 0u;
     const u64 o = J.poff + rank;
@@ -1680,17 +1694,24 @@ __device__ __noinline__ bool multi_verify_commit(const KParams& P, const GresDev
       const u32 nc0 = cores_count(h.avail0);
       if (req_int * 256 == J.min_view.cpu && nc0 != 0 && nc0 < (u32)req_int) ok = false;   // :528-534 on res_avail
     }
-    if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; }
+    if (lane == 0) { H[i].node = h.node; H[i].ntasks = ok ? 1 : 0; H[i].res = f; H[i].pad = P.sib_off ? (P.sib_off[q + 1] - P.sib_off[q]) << 8 : 0u; }
   }
   wg_barrier();  // M3: verdicts in
   u32 nok = 0;
   for (u32 m = 0; m < J.k; ++m) nok += H[m].ntasks != 0 ? 1u : 0u;
   if (nok != J.k) return false;  // (rare) the caller falls back to the sequential protocol
-  if (active) {
-    helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, f, P.now, lane, upd, q);
-    drain_stores();  // the worker reads this block again in later jobs
+  // a group of partitions that shares nodes: the records go through the HBM list, the sibling slots of helper m's node behind the k own ones
+  u32 sib_at = J.k, total = J.k;
+  if (P.sib_off) {
+    upd = P.g_upd + qbeg;
+    for (u32 m = 0; m < J.k; ++m) { const u32 ns = H[m].pad >> 8; sib_at += m < i ? ns : 0u; total += ns; }
   }
-  if (threadIdx.x == 0) *nupd = (int)J.k;
+  if (active) {
+    helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, f, P.now, lane, upd, q, sib_at, qbeg);
+    drain_stores();  // the worker reads this block again in later jobs
+    if (P.sib_off) __threadfence_block();
+  }
+  if (threadIdx.x == 0) *nupd = (int)total;
   wg_barrier();  // M4: commits + owner updates visible
   return true;
 }
@@ -1720,7 +1741,7 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const GresDev* 
     }
     if (lane == 0) {
       H[i].node = h.node; H[i].ntasks = 1; H[i].res = alloc;
-      H[i].pad = (res_le(alloc, h.avail0) ? 0u : 1u) | (P.first_resv[q] < P.now + J.L ? 2u : 0u);
+      H[i].pad = (res_le(alloc, h.avail0) ? 0u : 1u) | (P.first_resv[q] < P.now + J.L ? 2u : 0u) | (P.sib_off ? (P.sib_off[q + 1] - P.sib_off[q]) << 8 : 0u);
     }
   }
   i64 t = P.now;
@@ -1745,11 +1766,17 @@ __device__ __noinline__ i64 multi_backfill_par(const KParams& P, const GresDev* 
   bool notle = false, reserved = false;
   for (u32 m = 0; m < J.k; ++m) { notle = notle || (H[m].pad & 1u) != 0; reserved = reserved || (H[m].pad & 2u) != 0; }
   if (qbeg >= P.part_off[P.num_real_parts]) reserved = false;  // jobs of a reservation (its slots lie behind the real partitions'): no "Resource Reserved" (:6798,6818)
-  if (found && active) {
-    helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q);
-    drain_stores();
+  u32 sib_at = J.k, total = J.k;
+  if (P.sib_off) {
+    upd = P.g_upd + qbeg;
+    for (u32 m = 0; m < J.k; ++m) { const u32 ns = H[m].pad >> 8; sib_at += m < i ? ns : 0u; total += ns; }
   }
-  if (found && threadIdx.x == 0) *nupd = (int)J.k;
+  if (found && active) {
+    helper_commit_regs(P, G, J, H, i, p, cost0, hd, h, e, alloc, t, lane, upd, q, sib_at, qbeg);
+    drain_stores();
+    if (P.sib_off) __threadfence_block();
+  }
+  if (found && threadIdx.x == 0) *nupd = (int)total;
   wg_barrier();  // commits + owner updates visible (or: nothing happened)
   *reason_out = (found && t != P.now) ? (reserved ? 3 : (notle ? 2 : 1)) : 0;  // :6797-6831
   return found ? t : kInf;
@@ -2137,7 +2164,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2;  // not even k nodes fit res_total (:6335-6343)
             }
           }
-          if (fallback) par = worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
+          if (fallback) par = P.sib_off ? worker_job_slow(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg, gheap)   // (sibling slots among the updates)
+                                        : worker_job_multi(PG, sh, &s_job, par, wc, wcode, tc, tcode, qbeg);
           PROF_T(p8);
           PROF_ADD(6, d0, p8);
           PROF_CNT(15);
