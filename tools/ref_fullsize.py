@@ -8,7 +8,7 @@ the restated oracle; everything compared exactly (placements, fp64 cost bit patt
                                                  # about 600 s (its cost per decision grows steeply once the partition fills), the
                                                  # oracle on the same prefix beside it -> profiles/r04_ref_prefix_by_config.txt
 
-Test infrastructure only (drives oracle/, never the product).  Appends one line to profiles/r03_ref_vs_oracle_fullsize.txt.
+Test infrastructure only (drives oracle/, never the product).  Appends one line to profiles/r04_ref_vs_oracle_fullsize.txt (round 3: r03_...).
 """
 import os
 import sys
@@ -95,7 +95,7 @@ def main():
         dg = fullrun.digest(b.placements, b.costs().view(np.uint64), b.timeline, c.num_nodes)
         line += f"; committed digest (tests/golden/fullrun_{tag.lower()}.npz): {fullrun.compare(dg, golden) or 'reproduced by the reference build'}"
     print(line, flush=True)
-    with open(os.path.join(ROOT, "profiles", "r03_ref_vs_oracle_fullsize.txt"), "a") as f:
+    with open(os.path.join(ROOT, "profiles", "r04_ref_vs_oracle_fullsize.txt"), "a") as f:
         f.write(line + "\n")
 
 
