@@ -2,7 +2,7 @@
 """One partition of a synthetic configuration, full size, through the REFERENCE's own code (oracle/_ref) and through
 the restated oracle; everything compared exactly (placements, fp64 cost bit patterns, every node's final time map).
 
-    python tools/ref_fullsize.py C4 0            # partition 0 of C4: 125 k jobs x 8 192 nodes (about an hour of CPU)
+    python tools/ref_fullsize.py C4 0            # partition 0 of C4: 125 k jobs x 8 192 nodes (the reference build needs MORE than 7 hours for it: stopped unfinished in round 4; use --budget)
     python tools/ref_fullsize.py tile10          # a tests/golden/make_fullrun.py case: also checks the committed digest
     python tools/ref_fullsize.py C4 0 --budget 600   # the longest PREFIX of that partition's queue the reference build finishes in
                                                  # about 600 s (its cost per decision grows steeply once the partition fills), the
