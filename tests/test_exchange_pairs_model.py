@@ -90,3 +90,163 @@ def test_one_exchange_resolves_two_jobs_like_the_sequential_rule(seed):
     jobs = [dict(cpu=rng.choice([1, 1, 2, 4, 8, 32]), mem=rng.choice([1, 2, 16, 64]), L=rng.choice([600, 600, 1200, 3600])) for _ in range(rng.randrange(1, 400))]
     a, b = sequential(cluster(), jobs), paired(cluster(), jobs, W)
     assert a == b
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# General B (round 5): ONE exchange for a WINDOW of up to B consecutive one-node jobs (k_wide: wide_kernel.inc, "A WINDOW OF
+# JOBS PER EXCHANGE").  Per job i of the window every wave publishes i + 1 entries, all computed on its rows AS THEY ARE at
+# the window's start:
+#   E_i^0        "I have won nothing earlier in this window": its start-now argmin A, else its res_total argmin T (a
+#                backfill), else nothing;
+#   E_i^(1+j)    j < i, "I have won exactly job j (with E_j^0)": only the row R_j of E_j^0 differs from the tile (costlier;
+#                emptier if job j starts there), so this is E_i^0 unless E_i^0 sits on R_j; then it is the lesser of the
+#                wave's SECOND best start-now row and the changed R_j if job i still fits it.  If no start-now row is left
+#                the entry falls back to the T argmin, which is only a LOWER BOUND when it sits on R_j itself.
+# All waves resolve the jobs in order from the same granules: a wave's entry for job i is E_i^0 while it has won nothing,
+# E_i^(1+j) after one win (exact unless flagged), and a lower bound after two or more (a touched row only gets costlier and
+# emptier: JobScheduler.h:526-538,567-575).  The least entry decides job i if it is exact; a least entry that is only a
+# lower bound CLOSES the window in front of job i, which opens the next one.  A window always resolves its first job.
+# ---------------------------------------------------------------------------------------------------------------------
+def fits_total(node, job):
+    return node["total"] >= job["cpu"] and node["mtotal"] >= job["mem"]
+
+
+def best_total(nodes, idx, job):
+    b = None
+    for i in idx:
+        if fits_total(nodes[i], job) and (b is None or (nodes[i]["cost"], i) < b):
+            b = (nodes[i]["cost"], i)
+    return b
+
+
+def bump(node, job):
+    node["cost"] += job["L"] * (job["cpu"] / node["total"])
+
+
+def sequential_bf(nodes, jobs):
+    """start now on the least (cost, index) that fits; else reserve (cost only) on the least whose TOTAL fits; else nothing."""
+    out = []
+    for job in jobs:
+        b = best(nodes, range(len(nodes)), job)
+        if b is not None:
+            out.append(("start", b[1])); place(nodes[b[1]], job)
+            continue
+        t = best_total(nodes, range(len(nodes)), job)
+        if t is not None:
+            out.append(("backfill", t[1])); bump(nodes[t[1]], job)
+        else:
+            out.append(("none", None))
+    return out
+
+
+def best2(nodes, idx, job):
+    """the two least (cost, index) among the rows that fit, on DISTINCT rows"""
+    c = sorted((nodes[i]["cost"], i) for i in idx if fits(nodes[i], job))
+    return (c[0] if c else None), (c[1] if len(c) > 1 else None)
+
+
+def windowed(nodes, jobs, W, B, owner, stats):
+    rows = [[i for i in range(len(nodes)) if owner(i) == w] for w in range(W)]
+    out, j0 = [], 0
+    while j0 < len(jobs):
+        n = min(B, len(jobs) - j0)
+        # ---- what every wave publishes: E[w][i][h] = (kind 0 A / 1 T, cost, node, lower_bound) or None ----
+        E = []
+        for w in range(W):
+            Ew, base = [], []
+            for i in range(n):
+                job = jobs[j0 + i]
+                a1, a2 = best2(nodes, rows[w], job)
+                t1 = best_total(nodes, rows[w], job)
+                e0 = (0,) + a1 + (False,) if a1 else ((1,) + t1 + (False,) if t1 else None)
+                ent = [e0]
+                for j in range(i):
+                    ej = base[j]
+                    if ej is None:                   # the wave cannot have won job j
+                        ent.append(e0); continue
+                    Rj = ej[2]
+                    hyp = dict(nodes[Rj])
+                    place(hyp, jobs[j0 + j]) if ej[0] == 0 else bump(hyp, jobs[j0 + j])
+                    if a1 is None: ah = None
+                    elif a1[1] != Rj: ah = a1
+                    else:
+                        r = (hyp["cost"], Rj) if fits(hyp, job) else None
+                        ah = min([x for x in (a2, r) if x is not None], default=None)
+                    if ah is not None: ent.append((0,) + ah + (False,))
+                    elif t1 is not None: ent.append((1,) + t1 + (t1[1] == Rj,))
+                    else: ent.append(None)
+                Ew.append(ent); base.append(e0)
+            E.append(Ew)
+        # ---- what every wave computes from them ----
+        wins = [[] for _ in range(W)]
+        done = 0
+        for i in range(n):
+            cand = []
+            for w in range(W):
+                e = E[w][i][0] if not wins[w] else E[w][i][1 + wins[w][-1]]
+                if e is None: continue
+                lb = e[3] or len(wins[w]) >= 2
+                cand.append((e[:3], w, lb))
+            if not cand:
+                out.append(("none", None)); done += 1
+                continue
+            key, w, lb = min(cand)
+            if lb:
+                break
+            job = jobs[j0 + i]
+            if key[0] == 0:
+                out.append(("start", key[2])); place(nodes[key[2]], job)
+            else:
+                out.append(("backfill", key[2])); bump(nodes[key[2]], job)
+            wins[w].append(i)
+            done += 1
+        assert done >= 1
+        stats["windows"] += 1; stats["jobs"] += done
+        j0 += done
+    return out
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_one_exchange_resolves_a_window_of_jobs_like_the_sequential_rule(seed):
+    rng = random.Random(1000 + seed)
+    N, W, B = rng.choice([5, 16, 64, 257, 600]), rng.choice([1, 2, 4, 8, 16]), rng.choice([2, 3, 4, 8])
+    interleaved = rng.random() < 0.5           # node -> wave: i % W (consecutive nodes on different waves) or blocks of consecutive nodes
+    per = (N + W - 1) // W
+    owner = (lambda i: i % W) if interleaved else (lambda i: i // per)
+    def cluster():
+        r = random.Random(seed + 1)
+        out = []
+        for _ in range(N):
+            tot = r.choice([16.0, 64.0, 64.0])
+            out.append(dict(cost=r.choice([0.0, 0.0, r.random() * 100]), total=tot, mtotal=256, cpu=r.randrange(0, int(tot) + 1), mem=r.randrange(0, 257)))
+        return out
+    jobs = [dict(cpu=rng.choice([1, 1, 2, 4, 8, 32, 70]), mem=rng.choice([1, 2, 16, 64, 300]), L=rng.choice([600, 600, 1200, 3600])) for _ in range(rng.randrange(1, 500))]
+    stats = dict(windows=0, jobs=0)
+    a, b = sequential_bf(cluster(), jobs), windowed(cluster(), jobs, W, B, owner, stats)
+    assert a == b
+    assert stats["jobs"] == len(jobs)
+
+
+def test_window_fill_on_a_cold_and_on_a_warm_cluster():
+    """How full the windows get (the model's own statistics, B = 4, 64 waves).  Cold cluster (all costs 0): ties go to the lowest node
+    index, consecutive jobs take consecutive nodes; blocks of consecutive nodes per wave make one wave win again and again (its
+    third win in a window is only a lower bound: ~2 jobs per window), node i on wave i % W resolves every window whole."""
+    N, W, B = 4096, 64, 4
+    jobs = [dict(cpu=64, mem=1, L=600) for _ in range(1024)]
+    def cluster():
+        return [dict(cost=0.0, total=64.0, mtotal=256, cpu=64, mem=256) for _ in range(N)]
+    s_blk, s_int = dict(windows=0, jobs=0), dict(windows=0, jobs=0)
+    a = windowed(cluster(), jobs, W, B, lambda i: i // (N // W), s_blk)
+    b = windowed(cluster(), jobs, W, B, lambda i: i % W, s_int)
+    assert a == b == sequential_bf(cluster(), jobs)
+    assert s_int["windows"] == 1024 // B
+    assert s_blk["windows"] == 1024 // 2
+    # warm: random costs, small jobs — a window closes early only when one wave holds three of its four winners
+    rng = random.Random(5)
+    def warm():
+        r = random.Random(6)
+        return [dict(cost=r.random() * 1000, total=64.0, mtotal=256, cpu=64, mem=256) for _ in range(N)]
+    jobs = [dict(cpu=rng.choice([1, 2, 4, 8]), mem=rng.choice([2, 4, 8, 16]), L=600 * rng.randrange(1, 25)) for _ in range(4000)]
+    s = dict(windows=0, jobs=0)
+    assert windowed(warm(), jobs, W, B, lambda i: i % W, s) == sequential_bf(warm(), jobs)
+    assert s["jobs"] / s["windows"] > 3.9
