@@ -192,6 +192,9 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
   if (const char* inj = getenv("CNS_WIDE_INJECT_STALL")) K.wide_inject_stall = (u32)strtoul(inj, nullptr, 10) + 1u;
+  K.wide_window = w64::kWB;   // jobs per exchange of k_wide's 64-wave build (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE")
+  if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWB ? v : w64::kWB; }
+  if (K.wide_inject_stall) K.wide_window = 0;
   K.part_off = h->d_part_off.as<u32>();
   K.slot_node = h->d_slot_node.as<u32>();
   K.slot_total = h->d_slot_total.as<Res>();

@@ -239,6 +239,35 @@ __device__ __forceinline__ void wave_argmin2(u64& c1, u32& p1, u64& c2, u32& p2)
   c1 = ((u64)mh1 << 32) | ml1; p1 = mp1;
   c2 = ((u64)mh2 << 32) | ml2; p2 = mp2;
 }
+// N independent argmins in one pass (k_wide's windows: the candidates of N jobs): every DPP step of the N cascades back to back
+template <int N>
+__device__ __forceinline__ void wave_umin32xN(u32 (&v)[N]) {
+#define CNS_DPP_STEPN(ctrl, rmask) _Pragma("unroll") for (int x = 0; x < N; ++x) CNS_DPP_STEP32(op_umin, v[x], 0xFFFFFFFFu, ctrl, rmask)
+  CNS_DPP_STEPN(0x111, 0xF);
+  CNS_DPP_STEPN(0x112, 0xF);
+  CNS_DPP_STEPN(0x114, 0xF);
+  CNS_DPP_STEPN(0x118, 0xF);
+  CNS_DPP_STEPN(0x142, 0xA);
+  CNS_DPP_STEPN(0x143, 0xC);
+#undef CNS_DPP_STEPN
+#pragma unroll
+  for (int x = 0; x < N; ++x) v[x] = rl32(v[x], 63);
+}
+template <int N>
+__device__ __forceinline__ void wave_argminN(u64 (&c)[N], u32 (&p)[N]) {
+  u32 mh[N], ml[N], mp[N];
+#pragma unroll
+  for (int x = 0; x < N; ++x) mh[x] = (u32)(c[x] >> 32);
+  wave_umin32xN<N>(mh);
+#pragma unroll
+  for (int x = 0; x < N; ++x) ml[x] = (u32)(c[x] >> 32) == mh[x] ? (u32)c[x] : 0xFFFFFFFFu;
+  wave_umin32xN<N>(ml);
+#pragma unroll
+  for (int x = 0; x < N; ++x) mp[x] = (((u32)(c[x] >> 32) == mh[x]) & ((u32)c[x] == ml[x])) ? p[x] : 0xFFFFFFFFu;
+  wave_umin32xN<N>(mp);
+#pragma unroll
+  for (int x = 0; x < N; ++x) { c[x] = ((u64)mh[x] << 32) | ml[x]; p[x] = mp[x]; }
+}
 // the same over 16 per-wave slots replicated in every row
 __device__ __forceinline__ void reduce16(u64& c, u32& p) {
   const u32 hi = (u32)(c >> 32), lo = (u32)c;

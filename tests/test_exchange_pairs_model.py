@@ -103,8 +103,9 @@ def test_one_exchange_resolves_two_jobs_like_the_sequential_rule(seed):
 #                wave's SECOND best start-now row and the changed R_j if job i still fits it.  If no start-now row is left
 #                the entry falls back to the T argmin, which is only a LOWER BOUND when it sits on R_j itself.
 # All waves resolve the jobs in order from the same granules: a wave's entry for job i is E_i^0 while it has won nothing,
-# E_i^(1+j) after one win (exact unless flagged), and a lower bound after two or more (a touched row only gets costlier and
-# emptier: JobScheduler.h:526-538,567-575).  The least entry decides job i if it is exact; a least entry that is only a
+# E_i^(1+j) after one win (exact unless flagged), and E_i^0 as a mere lower bound after two or more (a touched row only gets
+# costlier and emptier: JobScheduler.h:526-538,567-575; a hypothesis "won exactly job j2" is NOT one then: the wave may have
+# won j2 on another row than the one that hypothesis changes).  The least entry decides job i if it is exact; a least entry that is only a
 # lower bound CLOSES the window in front of job i, which opens the next one.  A window always resolves its first job.
 # ---------------------------------------------------------------------------------------------------------------------
 def fits_total(node, job):
@@ -183,7 +184,7 @@ def windowed(nodes, jobs, W, B, owner, stats):
         for i in range(n):
             cand = []
             for w in range(W):
-                e = E[w][i][0] if not wins[w] else E[w][i][1 + wins[w][-1]]
+                e = E[w][i][1 + wins[w][0]] if len(wins[w]) == 1 else E[w][i][0]   # (two wins: no published hypothesis covers the wave; E^0 bounds it from below)
                 if e is None: continue
                 lb = e[3] or len(wins[w]) >= 2
                 cand.append((e[:3], w, lb))
@@ -250,3 +251,17 @@ def test_window_fill_on_a_cold_and_on_a_warm_cluster():
     s = dict(windows=0, jobs=0)
     assert windowed(warm(), jobs, W, B, lambda i: i % W, s) == sequential_bf(warm(), jobs)
     assert s["jobs"] / s["windows"] > 3.9
+
+
+def test_a_wave_that_won_twice_is_bounded_by_its_untouched_entry_only():
+    """Small clusters on two waves, jobs of very different sizes: a wave wins job j1 (small) and job j2 (big) whose best rows coincide,
+    the second one on its SECOND best row.  The hypothesis "won exactly j2" then describes a tile that never existed and may lie ABOVE
+    the wave's true entry (157 of 30 000 such cases resolve wrongly with it); only E_i^0 bounds a two-win wave from below."""
+    for seed in range(4000):
+        rng = random.Random(seed)
+        N, W, B = rng.choice([3, 4, 6]), 2, 4
+        def cluster():
+            r = random.Random(seed + 7)
+            return [dict(cost=r.choice([0.0, 1.0, 5.0, r.random() * 10]), total=64.0, mtotal=256, cpu=r.randrange(8, 65), mem=256) for _ in range(N)]
+        jobs = [dict(cpu=rng.choice([1, 2, 16, 32]), mem=1, L=rng.choice([60, 600, 6000])) for _ in range(8)]
+        assert windowed(cluster(), jobs, W, B, lambda i: i % W, dict(windows=0, jobs=0)) == sequential_bf(cluster(), jobs), seed
