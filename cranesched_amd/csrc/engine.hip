@@ -192,8 +192,14 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
   if (const char* inj = getenv("CNS_WIDE_INJECT_STALL")) K.wide_inject_stall = (u32)strtoul(inj, nullptr, 10) + 1u;
-  K.wide_window = w64::kWB;   // jobs per exchange of k_wide's 64-wave build (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE")
-  if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWB ? v : w64::kWB; }
+  // jobs per pool exchange of k_wide's 64-wave build at most (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE"); 0 / 1: off.  Off by default
+  // (-DCNS_WIDE_WINDOW_DEFAULT=16 turns it on): bit-exact and 1.8x shorter on the scanners' chain, but the home workgroup — the supervisor's
+  // 2 500 cycles per task, testers 76 % busy — then paces the pipeline: C5 -9 %, C4 +4 %, C2 +6 % (profiles/r05_pool_windows_ab.txt)
+#ifndef CNS_WIDE_WINDOW_DEFAULT
+#define CNS_WIDE_WINDOW_DEFAULT 0
+#endif
+  K.wide_window = CNS_WIDE_WINDOW_DEFAULT < w64::kWJ ? CNS_WIDE_WINDOW_DEFAULT : w64::kWJ;
+  if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWJ ? v : w64::kWJ; }
   if (K.wide_inject_stall) K.wide_window = 0;
   K.part_off = h->d_part_off.as<u32>();
   K.slot_node = h->d_slot_node.as<u32>();

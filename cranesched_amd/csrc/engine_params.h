@@ -132,7 +132,7 @@ struct KParams {
   u32 wide_cores;          // a node of the snapshot has a core id above 127: the TlExt arrays and the o_c2 / o_c3 planes are live
   u32 wide_inject_stall;   // test hook (CNS_WIDE_INJECT_STALL=<job>): job index + 1 of partition 0 whose exchange the leader scanner of k_wide
                            // never publishes — every other wave's wait then runs out (fault 28) and the cycle is re-run on k_pipe / k_select
-  u32 wide_window;         // k_wide, 64-wave build: jobs decided per exchange (0 / 1: one, as in rounds 2-4; up to CNS_WIDE_WIN).  CNS_WIDE_WINDOW=<n>
+  u32 wide_window;         // k_wide, 64-wave build: jobs decided per pool exchange at most (0 / 1: one job per exchange, as in rounds 2-4; up to CNS_WIDE_WIN).  CNS_WIDE_WINDOW=<n>
                            // overrides the default (= CNS_WIDE_WIN) for A/B runs and the parity tests; off whenever wide_inject_stall is set
   i64 now, max_window;
   const u32* part_off;     // [P+1] slot range of each partition

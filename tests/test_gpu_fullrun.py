@@ -54,7 +54,7 @@ def test_full_run_matches_oracle_digest(engine_cls, tag):
         print(f"{tag}: {jobs.num_jobs} jobs x {cluster.num_nodes} nodes identical to the oracle "
               f"(start-now {d['counts'][0]}, backfilled {d['counts'][1]}, failed {d['counts'][2]}); "
               f"{eng.last_kernel()} {t['select_ms']:.1f} ms = {1e3 * jobs.num_jobs / t['select_ms']:.0f} decisions/s"
-              + (f"; windows {ws['windows']} decided {ws['jobs_decided_in_windows']} voided {ws['exchange_numbers_voided']} flushes {ws['flushes']}"
+              + (f"; windows {ws['windows']} decided {ws['jobs_decided_in_windows']} dry {ws['windows_that_decided_nothing']} flushes {ws['flushes']}"
                  if eng.last_kernel().startswith("k_wide") and (ws := eng.wide_stats()) else ""))
     finally:
         eng.close()

@@ -1,0 +1,7 @@
+export TMPDIR=/tmp
+out=gpurun_out/r05c; mkdir -p $out
+for v in "" b768; do for w in 16 0; do
+  lib=""; [ -n "$v" ] && lib=build_var/v_$v.so
+  echo "== lib ${v:-default} CNS_WIDE_WINDOW=$w"
+  CNS_ENGINE_LIB=$lib CNS_WIDE_WINDOW=$w timeout 600 python -m pytest tests/test_gpu_fullrun.py -q -m gpu -s -k "wide and not wide32 and (c2 or c4] or c5 or c4r])" 2>&1 | grep "identical\|passed\|failed\|rror\|differs" | sed 's/identical to the oracle.*; k_wide/k_wide/' | tee -a $out/fullrun_${v:-default}_w$w.log
+done; done

@@ -22,11 +22,12 @@ t = e.timing(); pr = e.prof().astype(np.float64)
 m = pr.sum(axis=0)
 W = 64.0
 nw = max(m[0], 1)
-seg = ["queue + length", "decode + rows", "cascades + payloads", "res_total argmin", "entries + hypotheticals", "lap guard + publish", "poll (wait)", "resolve + apply"]
+seg = ["queue + this wave's rows", "lap guard + publish + poll", "pool -> registers + bound", "the jobs on the pool"]
 print(f"{name} {e.last_kernel()} {t['select_ms']:.1f} ms; windows per wave {m[0]/W/c.num_partitions:.0f} per partition, jobs per window {m[10]/nw:.2f}, polls per window {m[9]/nw:.2f}")
 tot = 0
 for i, s in enumerate(seg):
     print(f"  {s:28s} {m[1+i]/nw:9.0f} cycles per window and wave")
     tot += m[1 + i] / nw
-print(f"  {'sum':28s} {tot:9.0f}  = {tot/max(m[10]/nw,1e-9):.0f} per job;  clock: {100e6:.0f} Hz assumed for clock64 => {tot/100:.2f} us per window")
+jw = max(m[10] / nw, 1e-9)
+print(f"  {'sum':28s} {tot:9.0f}  = {tot/jw:.0f} per job; the jobs alone {m[4]/nw/jw:.0f} per job")
 print("  wide_stats:", e.wide_stats())
