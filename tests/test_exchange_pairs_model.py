@@ -93,8 +93,8 @@ def test_one_exchange_resolves_two_jobs_like_the_sequential_rule(seed):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# General B (round 5): ONE exchange for a WINDOW of up to B consecutive one-node jobs (k_wide: wide_kernel.inc, "A WINDOW OF
-# JOBS PER EXCHANGE").  Per job i of the window every wave publishes i + 1 entries, all computed on its rows AS THEY ARE at
+# General B (round 5, first design — built, bit-exact on the GPU, measured at 4 800 cycles per job and REPLACED by the pool rule at the
+# end of this file: profiles/r05_window_hypotheticals_*.txt): ONE exchange for a WINDOW of up to B consecutive one-node jobs.  Per job i of the window every wave publishes i + 1 entries, all computed on its rows AS THEY ARE at
 # the window's start:
 #   E_i^0        "I have won nothing earlier in this window": its start-now argmin A, else its res_total argmin T (a
 #                backfill), else nothing;
@@ -207,7 +207,7 @@ def windowed(nodes, jobs, W, B, owner, stats):
     return out
 
 
-@pytest.mark.parametrize("seed", range(120))
+@pytest.mark.parametrize("seed", range(40))
 def test_one_exchange_resolves_a_window_of_jobs_like_the_sequential_rule(seed):
     rng = random.Random(1000 + seed)
     N, W, B = rng.choice([5, 16, 64, 257, 600]), rng.choice([1, 2, 4, 8, 16]), rng.choice([2, 3, 4, 8])
@@ -265,3 +265,70 @@ def test_a_wave_that_won_twice_is_bounded_by_its_untouched_entry_only():
             return [dict(cost=r.choice([0.0, 1.0, 5.0, r.random() * 10]), total=64.0, mtotal=256, cpu=r.randrange(8, 65), mem=256) for _ in range(N)]
         jobs = [dict(cpu=rng.choice([1, 2, 16, 32]), mem=1, L=rng.choice([60, 600, 6000])) for _ in range(8)]
         assert windowed(cluster(), jobs, W, B, lambda i: i % W, dict(windows=0, jobs=0)) == sequential_bf(cluster(), jobs), seed
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The POOL rule (round 5, what k_wide runs: wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE").  Every job moves exactly one row,
+# and only towards "costlier and emptier" — so the next several decisions fall among the few cheapest rows.  A window
+# exchanges the candidate POOL once: every wave publishes its M cheapest rows WITH THEIR STATE and the key of its next row
+# (the bound).  Every wave then decides job after job on its copy of the pool, with no further communication: the least
+# (cost, index) among the pool rows the job fits, applied to the copy (and by the owner to its tile).  A decision is exact
+# while its key lies below every wave's bound: no row outside the pool can come before it (their keys are >= the bounds and
+# do not move).  The first job that finds no pool row, or whose key is not below the bound, closes the window and goes
+# through the single-job exchange.
+# ---------------------------------------------------------------------------------------------------------------------
+def pooled(nodes, jobs, W, M, JMAX, owner, stats):
+    rows = [[i for i in range(len(nodes)) if owner(i) == w] for w in range(W)]
+    out, j = [], 0
+    def single(job):
+        out.extend(sequential_bf(nodes, [job]))
+    while j < len(jobs):
+        pool, bound = {}, None
+        for w in range(W):
+            srt = sorted((nodes[i]["cost"], i) for i in rows[w])
+            for c, i in srt[:M]:
+                pool[i] = dict(nodes[i])
+            if len(srt) > M and (bound is None or srt[M] < bound): bound = srt[M]
+        done = 0
+        while j < len(jobs) and done < JMAX:
+            job = jobs[j]
+            cand = [(r["cost"], i) for i, r in pool.items() if fits(r, job)]
+            if not cand: break
+            key = min(cand)
+            if bound is not None and not key < bound: break
+            place(pool[key[1]], job)           # every wave: its copy of the row
+            place(nodes[key[1]], job)          # the owner: its tile
+            out.append(("start", key[1]))
+            j += 1; done += 1
+        stats["windows"] += 1; stats["jobs"] += done
+        if done == 0:
+            single(jobs[j]); j += 1; stats["single"] += 1
+    return out
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_jobs_decided_on_an_exchanged_pool_follow_the_sequential_rule(seed):
+    rng = random.Random(7000 + seed)
+    N, W, M = rng.choice([5, 16, 64, 257, 600]), rng.choice([1, 2, 4, 8, 16]), rng.choice([1, 2, 3])
+    per = (N + W - 1) // W
+    owner = (lambda i: i % W) if rng.random() < 0.5 else (lambda i: i // per)
+    def cluster():
+        r = random.Random(seed + 1)
+        return [dict(cost=r.choice([0.0, 0.0, r.random() * 100]), total=r.choice([16.0, 64.0]), mtotal=256, cpu=r.randrange(0, 17), mem=r.randrange(0, 257)) for _ in range(N)]
+    jobs = [dict(cpu=rng.choice([1, 1, 2, 4, 8, 32]), mem=rng.choice([1, 2, 16, 64, 300]), L=rng.choice([600, 1200, 3600])) for _ in range(rng.randrange(1, 400))]
+    st = dict(windows=0, jobs=0, single=0)
+    assert pooled(cluster(), jobs, W, M, rng.choice([4, 16]), owner, st) == sequential_bf(cluster(), jobs)
+
+
+def test_pool_windows_fill_on_a_partition_like_c5():
+    """8 192 nodes x 64 cores on 64 waves, jobs of 1..8 cpus (the first 6 000 of a C5-like queue, cold start included): two rows per wave
+    fill a window of 16 almost always; one row per wave already decides ~11 jobs per exchange."""
+    rng = random.Random(1)
+    jobs = [dict(cpu=c, mem=2 * c, L=675 * rng.randrange(1, 33)) for c in (rng.choice([1, 2, 4, 8]) for _ in range(6000))]
+    fill = {}
+    for M in (1, 2):
+        nodes = [dict(cost=0.0, total=64.0, mtotal=256, cpu=64, mem=256) for _ in range(8192)]
+        st = dict(windows=0, jobs=0, single=0)
+        pooled(nodes, jobs, 64, M, 16, lambda i: i % 64, st)
+        fill[M] = st["jobs"] / st["windows"]
+    assert fill[1] > 9 and fill[2] > 15
