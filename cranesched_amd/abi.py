@@ -91,6 +91,17 @@ class CnsTiming(C.Structure):
                 ("algorithmic_bytes", C.c_uint64)]
 
 
+class CnsResultsOffsets(C.Structure):   # cns_results_offsets
+    _fields_ = [("num_jobs", C.c_uint64), ("num_places", C.c_uint64), ("wide_cores", C.c_uint32), ("reserved0", C.c_uint32)] + \
+               [(f, C.c_uint64) for f in ("start_sec", "cpu_raw", "mem", "core_lo", "core_hi", "gres", "node_idx", "ntasks", "reason",
+                                          "core_w2", "core_w3", "total_bytes")]
+
+
+class CnsGroupInfo(C.Structure):        # cns_group_info
+    _fields_ = [("num_devices", C.c_uint32), ("gather_mode", C.c_uint32), ("shards_ms", C.c_double), ("max_select_ms", C.c_double),
+                ("allgather_ms", C.c_double), ("download_ms", C.c_double), ("scatter_ms", C.c_double), ("slot_bytes", C.c_uint64)]
+
+
 def _ptr(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_P)
 

@@ -25,6 +25,7 @@
 #include "../../include/crane_gpu/steps.h"
 #include <limits>
 #include "engine_params.h"
+#include <rccl/rccl.h>          // several devices: group_host.inc (the engine library links RCCL)
 #include "select_kernels.hip"  // single translation unit: kernels + their launches (no -fgpu-rdc needed)
 #include "priority_kernels.hip"
 #include "limits_kernels.hip"
@@ -114,6 +115,12 @@ struct cns_engine {
   DevBuf d_params3, d_pmap_c, d_wide_mem;       // the serial-only launch of k_wide (groups wider than k_select's tile)
   DevBuf d_flen, d_tag_off, d_tag_base;         // ... its compact map lengths, and the slot range of every member partition of a group
   std::vector<u32> tag_off, tag_base;
+  // several devices (group_host.inc): this engine's rank in a communicator, the all-gathered results of every rank
+  void* comm = nullptr;                         // ncclComm_t
+  u32 comm_nranks = 0, comm_rank = 0;
+  DevBuf d_gather;
+  double gather_ms = 0.0;
+  u64 gather_bytes = 0;
   bool wide_off = false;                        // this run must not use k_wide (the retry after a k_wide protocol fault)
   u32 wide_retries = 0;                         // cycles that were re-run on k_pipe / k_select after a k_wide fault (lifetime of the handle)
   // MultiFactorPriority (priority_host.inc)
@@ -578,6 +585,8 @@ void cns_destroy(cns_handle* h) {
   for (DevBuf& b : h->d_limpar) b.release();
   for (DevBuf& b : h->d_step) b.release();
   for (DevBuf& b : h->d_pre) b.release();
+  h->d_gather.release();
+  if (h->comm) (void)ncclCommDestroy((ncclComm_t)h->comm);
   for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
   for (auto& ev : h->ev2) if (ev) (void)hipEventDestroy(ev);
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -1537,3 +1546,5 @@ int cns_debug_get_timeline_cores(cns_handle* h, uint32_t node, uint32_t capacity
 #include "steps_host.inc"
 
 }  // extern "C"
+
+#include "group_host.inc"

@@ -27,7 +27,12 @@ _LIB = None
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
                "cns_set_reservations", "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
                "cns_device_results", "cns_host_alloc", "cns_host_free", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
-               "cns_debug_last_kernel", "cns_debug_get_prof")
+               "cns_debug_last_kernel", "cns_debug_get_prof",
+               # several devices (csrc/group_host.inc)
+               "cns_results_layout", "cns_comm_unique_id", "cns_comm_init_rank", "cns_comm_destroy", "cns_allgather_results",
+               "cns_download_gathered", "cns_gather_timing", "cns_group_create", "cns_group_destroy", "cns_group_last_error",
+               "cns_group_size", "cns_group_handle", "cns_group_set_nodes", "cns_group_set_reservations", "cns_group_set_running",
+               "cns_group_select", "cns_group_get_info", "cns_group_device_of_partition")
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
 # ... and include/crane_gpu/run_limits.h
@@ -60,6 +65,16 @@ def lib():
         L.cns_destroy.argtypes = [C.c_void_p]
         L.cns_debug_last_kernel.restype = C.c_char_p
         L.cns_debug_last_kernel.argtypes = [C.c_void_p]
+        L.cns_group_last_error.restype = C.c_char_p
+        L.cns_group_last_error.argtypes = [C.c_void_p]
+        L.cns_group_destroy.restype = None
+        L.cns_group_destroy.argtypes = [C.c_void_p]
+        L.cns_group_handle.restype = C.c_void_p
+        L.cns_group_handle.argtypes = [C.c_void_p, C.c_uint32]
+        L.cns_group_size.restype = C.c_uint32
+        L.cns_group_size.argtypes = [C.c_void_p]
+        L.cns_group_device_of_partition.restype = C.c_uint32
+        L.cns_group_device_of_partition.argtypes = [C.c_void_p, C.c_uint32]
         _LIB = L
     return _LIB
 
@@ -297,6 +312,45 @@ class GpuNodeSelector:
         self._check(self._L.cns_device_results(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
+    # -- one process per device: the all-gather of the packed results over RCCL (csrc/group_host.inc) ----------------
+    def results_layout(self) -> dict:
+        """Byte offsets of the packed result buffer of the last upload (cns_results_layout)."""
+        o = abi.CnsResultsOffsets()
+        self._check(self._L.cns_results_layout(self._h, C.byref(o)))
+        return {f: getattr(o, f) for f, _ in abi.CnsResultsOffsets._fields_}
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the communicator's id (ship it to every rank: torch.distributed's store, MPI, a file)"""
+        buf = (C.c_uint8 * 128)()
+        rc = lib().cns_comm_unique_id(buf)
+        if rc != 0:
+            raise EngineError(rc, (lib().cns_last_error(None) or b"").decode())
+        return bytes(buf)
+
+    def comm_init_rank(self, nranks: int, rank: int, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        self._check(self._L.cns_comm_init_rank(self._h, C.c_uint32(nranks), C.c_uint32(rank), buf))
+
+    def comm_destroy(self):
+        self._check(self._L.cns_comm_destroy(self._h))
+
+    def allgather_results(self, slot_bytes: int) -> int:
+        """collective: every rank's packed results, rank r at [r * slot_bytes) of a device buffer of this engine -> its address"""
+        p = C.c_void_p()
+        self._check(self._L.cns_allgather_results(self._h, C.c_uint64(slot_bytes), C.byref(p)))
+        return p.value
+
+    def download_gathered(self, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, np.uint8)
+        self._check(self._L.cns_download_gathered(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint64(nbytes)))
+        return out
+
+    def gather_timing(self):
+        ms, b = C.c_double(), C.c_uint64()
+        self._L.cns_gather_timing(self._h, C.byref(ms), C.byref(b))
+        return ms.value, b.value
+
     def timing(self) -> dict:
         t = abi.CnsTiming()
         self._check(self._L.cns_get_timing(self._h, C.byref(t)))
@@ -346,3 +400,85 @@ class GpuNodeSelector:
         self._check(self._L.cns_debug_get_timeline_cores(self._h, C.c_uint32(node), C.c_uint32(cap), p(w2), p(w3)))
         return {"t": t[:k], "cpu_raw": cpu[:k], "mem": mem[:k], "core_lo": lo[:k], "core_hi": hi[:k], "gres": g[:k],
                 "core_w2": w2[:k], "core_w3": w3[:k]}
+
+
+class GpuNodeSelectorGroup:
+    """ONE process, N devices (cns_group_*: what the C++ adapter's GpuNodeSelectionAlgo(std::vector<int> devices) drives): the groups of
+    partitions dealt over the devices, every shard on its own host thread, the packed results all-gathered on the devices (RCCL when the
+    devices are distinct) and merged back into queue order.  A repeated ordinal ([0, 0]) exercises the path on a one-GPU box."""
+
+    def __init__(self, devices, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0, max_time_window_sec: int = 0):
+        self._L = lib()
+        self._g = C.c_void_p()
+        cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, 0, scheduled_batch_size, max_job_num_per_node, 0, max_time_window_sec)
+        dev = (C.c_int32 * len(devices))(*devices)
+        rc = self._L.cns_group_create(C.byref(cfg), dev, C.c_uint32(len(devices)), C.byref(self._g))
+        if rc != 0:
+            msg = self._L.cns_group_last_error(None)
+            self._g = C.c_void_p()
+            raise EngineError(rc, msg.decode() if msg else "")
+        self._cluster = None
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._L.cns_group_last_error(self._g)
+            raise EngineError(rc, msg.decode() if msg else "")
+
+    def close(self):
+        if self._g:
+            self._L.cns_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_nodes(self, cluster: abi.Cluster):
+        c = cluster.to_c()
+        self._check(self._L.cns_group_set_nodes(self._g, C.byref(c)))
+        self._cluster = cluster
+
+    def set_reservations(self, reservations):
+        if reservations is None:
+            self._check(self._L.cns_group_set_reservations(self._g, None))
+        else:
+            r = reservations.to_c()
+            self._check(self._L.cns_group_set_reservations(self._g, C.byref(r)))
+
+    def set_running(self, running):
+        if running is None:
+            self._check(self._L.cns_group_set_running(self._g, None))
+        else:
+            r = running.to_c()
+            self._check(self._L.cns_group_set_running(self._g, C.byref(r)))
+
+    def node_select(self, now: int, jobs: abi.Jobs, out: "abi.Placements | None" = None) -> abi.Placements:
+        if out is None:
+            out = abi.Placements(jobs.num_jobs, jobs.total_places())
+        cj, co = jobs.to_c(), out.to_c()
+        self._check(self._L.cns_group_select(self._g, C.c_int64(now), C.byref(cj), C.byref(co)))
+        return out
+
+    def info(self) -> dict:
+        i = abi.CnsGroupInfo()
+        self._check(self._L.cns_group_get_info(self._g, C.byref(i)))
+        d = {f: getattr(i, f) for f, _ in abi.CnsGroupInfo._fields_}
+        d["gather_mode"] = {1: "rccl", 2: "device-copies"}.get(d["gather_mode"], d["gather_mode"])
+        return d
+
+    def device_of_partition(self, p: int) -> int:
+        return int(self._L.cns_group_device_of_partition(self._g, C.c_uint32(p)))
+
+    def last_kernels(self):
+        n = self._L.cns_group_size(self._g)
+        return [(self._L.cns_debug_last_kernel(self._L.cns_group_handle(self._g, d)) or b"").decode() for d in range(n)]
+
+    def costs_of_device(self, d: int, n: int) -> np.ndarray:
+        c = np.zeros(n, np.float64)
+        h = self._L.cns_group_handle(self._g, d)
+        rc = self._L.cns_debug_get_costs(C.c_void_p(h), c.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise EngineError(rc, (self._L.cns_last_error(C.c_void_p(h)) or b"").decode())
+        return c

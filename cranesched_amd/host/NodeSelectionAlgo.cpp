@@ -59,7 +59,9 @@ template <class T> using PinVec = std::vector<T, PinAlloc<T>>;
 }
 
 struct GpuNodeSelectionAlgo::Impl {
-  cns_handle* h = nullptr;
+  cns_handle* h = nullptr;     // the engine (several devices: the first device's, for page-locked buffers and the kernels either side of the path)
+  cns_group* grp = nullptr;    // several devices (include/crane_gpu/node_select.h "several devices"): snapshot, running set and cycle go through it
+  std::vector<int> devices;
   // dense indices of the current snapshot
   std::vector<CranedId> node_name;
   std::vector<uint64_t> node_mem_sw;   // res_total.memory_sw_bytes per node (what an exclusive job is allocated)
@@ -100,16 +102,16 @@ struct GpuNodeSelectionAlgo::Impl {
     nd.part_offsets = n_poff.data(); nd.part_nodes = n_pnodes.data();
     nd.gres = layout;
     nd.core_w2 = n_w2.data(); nd.core_w3 = n_w3.data();
-    int st = cns_set_nodes(h, &nd);
-    if (st != 0) { err = cns_last_error(h); return st; }
+    int st = grp ? cns_group_set_nodes(grp, &nd) : cns_set_nodes(h, &nd);
+    if (st != 0) { err = grp ? cns_group_last_error(grp) : cns_last_error(h); return st; }
     if (!v_start.empty()) {
       cns_resv_soa rv{};
       rv.num_resv = (uint32_t)v_start.size(); rv.num_allocs = (uint32_t)v_node.size();
       rv.start_sec = v_start.data(); rv.end_sec = v_end.data(); rv.alloc_offsets = v_off.data(); rv.alloc_node = v_node.data();
       rv.alloc_cpu_raw = v_cpu.data(); rv.alloc_mem = v_mem.data(); rv.alloc_core_lo = v_lo.data(); rv.alloc_core_hi = v_hi.data();
       rv.alloc_gres = v_g.data(); rv.alloc_core_w2 = v_w2.data(); rv.alloc_core_w3 = v_w3.data();
-      st = cns_set_reservations(h, &rv);
-      if (st != 0) { err = cns_last_error(h); return st; }
+      st = grp ? cns_group_set_reservations(grp, &rv) : cns_set_reservations(h, &rv);
+      if (st != 0) { err = grp ? cns_group_last_error(grp) : cns_last_error(h); return st; }
     }
     return 0;
   }
@@ -632,6 +634,36 @@ GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(int device, uint64_t scheduled_batch_
   impl_->pin.h = impl_->h;   // (null without an engine: the cycle's arrays are then plain memory)
 }
 
+// Several devices of one node (BASELINE.json: "job-sharded across 8 x MI355X"): ONE algorithm object, as in the reference
+// (JobScheduler.cpp:158-159), over one engine per device; the groups of partitions connected through shared nodes are dealt round robin
+// (their LocalSchedulers are independent: :6723-6732,6746-6761), every device runs its shard on its own host thread, the packed results
+// are all-gathered on the devices and merged back into the PdJobInSchedulers in queue order (cns_group_select).  The cycle with preemption
+// and the kernels either side of the path (run limits, steps) stay on the first device.
+GpuNodeSelectionAlgo::GpuNodeSelectionAlgo(const std::vector<int>& devices, uint64_t scheduled_batch_size) : impl_(new Impl) {
+  cns_config cfg{};
+  cfg.abi_version = CNS_ABI_VERSION;
+  cfg.device = devices.empty() ? 0 : devices[0];
+  cfg.scheduled_batch_size = scheduled_batch_size;
+  batch_ = scheduled_batch_size;
+  impl_->devices = devices.empty() ? std::vector<int>{0} : devices;
+  if (impl_->devices.size() == 1) {
+    status_ = cns_create(&cfg, &impl_->h);
+    if (status_ != 0) error_ = cns_last_error(nullptr);
+  } else {
+    std::vector<int32_t> dev(impl_->devices.begin(), impl_->devices.end());
+    status_ = cns_group_create(&cfg, dev.data(), (uint32_t)dev.size(), &impl_->grp);
+    if (status_ != 0) error_ = cns_group_last_error(nullptr);
+    else impl_->h = cns_group_handle(impl_->grp, 0);
+  }
+  impl_->pin.h = impl_->h;
+}
+
+size_t GpuNodeSelectionAlgo::NumDevices() const { return impl_->devices.empty() ? 1 : impl_->devices.size(); }
+
+bool GpuNodeSelectionAlgo::LastGroupInfo(cns_group_info* out) const {
+  return impl_->grp && out && cns_group_get_info(impl_->grp, out) == 0;
+}
+
 void GpuNodeSelectionAlgo::SetCranedState(const CranedId& craned_id, bool alive, bool drain) {
   Impl& I = *impl_;
   auto it = I.node_idx.find(craned_id);
@@ -713,7 +745,8 @@ GpuNodeSelectionAlgo::~GpuNodeSelectionAlgo() {
     impl_->last = Impl::PlacementStore(nullptr);
     impl_->pin.h = nullptr;
   }
-  if (impl_ && impl_->h) cns_destroy(impl_->h);
+  if (impl_ && impl_->grp) cns_group_destroy(impl_->grp);   // (its engines, the first one — impl_->h — included)
+  else if (impl_ && impl_->h) cns_destroy(impl_->h);
 }
 
 void GpuNodeSelectionAlgo::LastCycleMs(double* pack_ms, double* engine_ms, double* write_back_ms) const {
@@ -957,8 +990,8 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   rs.alloc_cpu_raw = r_cpu.data(); rs.alloc_mem = r_mem.data(); rs.alloc_core_lo = r_lo.data();
   rs.alloc_core_hi = r_hi.data(); rs.alloc_gres = r_g.data(); rs.reservation = r_resv.data();
   rs.alloc_core_w2 = I.r_w2.data(); rs.alloc_core_w3 = I.r_w3.data();
-  int st = cns_set_running(I.h, rs.num_jobs ? &rs : nullptr);
-  if (st != 0) return fail_all(st, cns_last_error(I.h));
+  int st = I.grp ? cns_group_set_running(I.grp, rs.num_jobs ? &rs : nullptr) : cns_set_running(I.h, rs.num_jobs ? &rs : nullptr);
+  if (st != 0) return fail_all(st, I.grp ? cns_group_last_error(I.grp) : cns_last_error(I.h));
 
   // ---- pending jobs, in the sorter's order (JobScheduler.cpp:6735) ---------------------------------------
   std::vector<PdJobInScheduler*> ord;
@@ -1039,8 +1072,10 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
   const auto tp1 = std::chrono::steady_clock::now();
   I.t_pack_ms = std::chrono::duration<double, std::milli>(tp1 - tp0).count();
   if (!I.preempt_enabled) {
-    st = cns_select(I.h, now, &js, &out);
-    if (st != 0) return fail_all(st, cns_last_error(I.h));
+    st = I.grp ? cns_group_select(I.grp, now, &js, &out) : cns_select(I.h, now, &js, &out);
+    if (st != 0) return fail_all(st, I.grp ? cns_group_last_error(I.grp) : cns_last_error(I.h));
+  } else if (I.grp) {
+    return fail_all(CNS_ERR_UNSUPPORTED, "a cycle with preemption runs on ONE device (TryPreempt_ releases resources inside the cycle: csrc/preempt_dev.inc): build the algorithm over one device for it");
   } else {
     // ---- the cycle with preemption (include/crane_gpu/preempt.h): qos ids, the fields TryPreempt_ reads, the set ------
     if (!I.r_src_valid || I.r_src.size() != I.r_end.size())

@@ -29,6 +29,7 @@
 #include <vector>
 
 struct cns_engine;
+struct cns_group_info;
 
 namespace crane {
 
@@ -285,6 +286,12 @@ class INodeSelectionAlgo {
 class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
  public:
   explicit GpuNodeSelectionAlgo(int device = 0, uint64_t scheduled_batch_size = 0);
+  // Several devices of one node: the groups of partitions connected through shared nodes are dealt over them (group g -> devices[g % N]),
+  // every device runs its shard of the ordered queue on its own host thread, ONE all-gather (RCCL) merges the packed results
+  // (include/crane_gpu/node_select.h, "several devices").  {d} is the one-device form.
+  explicit GpuNodeSelectionAlgo(const std::vector<int>& devices, uint64_t scheduled_batch_size = 0);
+  size_t NumDevices() const;
+  bool LastGroupInfo(cns_group_info* out) const;   // false on one device
   ~GpuNodeSelectionAlgo() override;
   GpuNodeSelectionAlgo(const GpuNodeSelectionAlgo&) = delete;
   GpuNodeSelectionAlgo& operator=(const GpuNodeSelectionAlgo&) = delete;

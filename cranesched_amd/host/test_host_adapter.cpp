@@ -12,6 +12,7 @@
 #include <string>
 
 #include "NodeSelectionAlgo.h"
+#include "../../include/crane_gpu/node_select.h"   // cns_group_info (several devices)
 
 using namespace crane;
 
@@ -288,8 +289,83 @@ static int cycle_bench(int n_nodes, int n_jobs, int threads = 1) {
 // One whole NodeSelect through the adapter at full size, on the GPU: what an integrator's ScheduleThread sees between entering and
 // leaving m_node_selection_algo_->NodeSelect (JobScheduler.cpp:1439-1447) — packing, cns_select, write-back — P partitions of N / P nodes
 // (64 cores, 256 GiB), J pending jobs of 1..8 cores for 10..170 minutes, spread over the partitions.
-static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred, int threads) {
-  GpuNodeSelectionAlgo algo(0);
+static std::vector<int> parse_devices(const char* s) {   // "0,1,2" (a repeated ordinal — "0,0" — runs several engines on one GPU)
+  std::vector<int> d;
+  for (const char* p = s; p && *p;) {
+    d.push_back(atoi(p));
+    p = strchr(p, ',');
+    if (p) ++p;
+  }
+  return d.empty() ? std::vector<int>{0} : d;
+}
+
+// Several devices inside the product: ONE GpuNodeSelectionAlgo over `devices` against one over a single device, the same snapshot and queue
+// (random partitions, 1..8 cores, one job in seven on two nodes): every job's reason, start, end, nodes, task counts and allocated resources
+// must be identical — the shards run on their own host threads, the packed results are all-gathered on the devices and merged in queue order.
+static int group_check(int n_nodes, int n_parts, int n_jobs, const std::vector<int>& devices) {
+  GpuNodeSelectionAlgo multi(devices), one(devices[0]);
+  if (!multi.Ok() || !one.Ok()) { printf("engine: %s%s\n", multi.LastError().c_str(), one.LastError().c_str()); return 2; }
+  ClusterSnapshot snap;
+  std::vector<std::vector<CranedId>> ids(n_parts);
+  for (int i = 0; i < n_nodes; ++i) {
+    char name[16];
+    snprintf(name, sizeof name, "cn%05d", i);
+    snap.craned_metas.push_back(node(name, 64, 256));
+    ids[i / ((n_nodes + n_parts - 1) / n_parts)].push_back(name);
+  }
+  for (int p = 0; p < n_parts; ++p) snap.partitions.push_back({"P" + std::to_string(p), ids[p]});
+  multi.SetClusterSnapshot(snap); one.SetClusterSnapshot(snap);
+  CHECK(multi.Ok() && one.Ok());
+  multi.SetFullWriteBack(true); one.SetFullWriteBack(true);
+  std::vector<std::unique_ptr<RnJobInScheduler>> running;
+  for (int cycle = 0; cycle < 2; ++cycle) {
+    std::vector<std::unique_ptr<PdJobInScheduler>> pa, pb;
+    uint64_t x = 0x9E3779B97F4A7C15ull + (uint64_t)cycle;
+    for (int j = 0; j < n_jobs; ++j) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      const double cpus = (double)(1 << (x & 3));
+      const int64_t L = 600 * (1 + (int)((x >> 8) % 17));
+      const std::string part = (j % 97 == 5) ? std::string("nowhere") : "P" + std::to_string((x >> 16) % n_parts);
+      pa.push_back(job((job_id_t)(j + 1), cpus, L, part));
+      pb.push_back(job((job_id_t)(j + 1), cpus, L, part));
+      if (j % 7 == 0) { pa.back()->node_num = pb.back()->node_num = 2; pa.back()->ntasks = pb.back()->ntasks = 2; }
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    multi.NodeSelect(1000, running, pa);
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    one.NodeSelect(1000, running, pb);
+    CHECK(multi.Ok() && one.Ok());
+    if (!multi.Ok()) printf("multi: %s\n", multi.LastError().c_str());
+    size_t same = 0, started = 0;
+    for (int j = 0; j < n_jobs; ++j) {
+      bool ok = pa[j]->reason == pb[j]->reason && pa[j]->start_time == pb[j]->start_time && pa[j]->end_time == pb[j]->end_time &&
+                pa[j]->craned_ids == pb[j]->craned_ids && pa[j]->craned_id_to_task_num == pb[j]->craned_id_to_task_num &&
+                pa[j]->allocated_res.size() == pb[j]->allocated_res.size();
+      if (ok)
+        for (const auto& [cid, rb] : pb[j]->allocated_res) {
+          auto it = pa[j]->allocated_res.find(cid);
+          ok = ok && it != pa[j]->allocated_res.end() && it->second.cpu_set.cpu_count == rb.cpu_set.cpu_count && it->second.cpu_set.core_ids == rb.cpu_set.core_ids &&
+               it->second.memory_bytes == rb.memory_bytes && it->second.gres == rb.gres;
+        }
+      same += ok;
+      started += pb[j]->reason.empty();
+    }
+    CHECK(same == (size_t)n_jobs);
+    cns_group_info gi{};
+    const bool have = multi.LastGroupInfo(&gi);
+    CHECK(have == (devices.size() > 1));
+    printf("  cycle %d: %zu of %d jobs identical on %zu device%s and on one (%zu start now); the multi-device NodeSelect %.1f ms", cycle, same, n_jobs,
+           multi.NumDevices(), multi.NumDevices() == 1 ? "" : "s", started, ms);
+    if (have) printf(" (shards %.1f | all-gather %.2f [%s, %llu bytes per rank] | download %.2f | scatter %.2f ms; slowest selection kernel %.1f ms)", gi.shards_ms, gi.allgather_ms,
+                     gi.gather_mode == CNS_GATHER_RCCL ? "RCCL" : "device-to-device copies", (unsigned long long)gi.slot_bytes, gi.download_ms, gi.scatter_ms, gi.max_select_ms);
+    printf("\n");
+  }
+  printf("%s\n", g_fail ? "FAIL" : "ok");
+  return g_fail != 0;
+}
+
+static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred, int threads, const std::vector<int>& devices = {0}) {
+  GpuNodeSelectionAlgo algo(devices);
   if (!algo.Ok()) { printf("engine: %s\n", algo.LastError().c_str()); return 2; }
   algo.SetDeferredWriteBack(deferred);
   algo.SetHostThreads(threads);
@@ -305,8 +381,8 @@ static int e2e_bench(int n_nodes, int n_parts, int n_jobs, bool deferred, int th
   algo.SetClusterSnapshot(snap);
   if (!algo.Ok()) { printf("snapshot: %s\n", algo.LastError().c_str()); return 2; }
   std::vector<std::unique_ptr<RnJobInScheduler>> running;
-  printf("e2e-bench: %d nodes in %d partitions, %d pending jobs, %s write-back, one NodeSelect per line (%d host thread%s + 1 GPU)\n", n_nodes, n_parts, n_jobs,
-         deferred ? "deferred (allocated_res on demand)" : "lazy (default)", threads, threads == 1 ? "" : "s");
+  printf("e2e-bench: %d nodes in %d partitions, %d pending jobs, %s write-back, one NodeSelect per line (%d host thread%s + %zu engine%s)\n", n_nodes, n_parts, n_jobs,
+         deferred ? "deferred (allocated_res on demand)" : "lazy (default)", threads, threads == 1 ? "" : "s", devices.size(), devices.size() == 1 ? "" : "s");
   for (int rep = 0; rep < 4; ++rep) {
     std::vector<std::unique_ptr<PdJobInScheduler>> pd;
     uint64_t x = 0x9E3779B97F4A7C15ull;
@@ -447,7 +523,13 @@ static int wire_dump(const char* path, int n, bool jobtod) {
 
 int main(int argc, char** argv) {
   if (argc > 1 && !strcmp(argv[1], "--cycle-bench")) return cycle_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 200000, argc > 4 ? atoi(argv[4]) : 1);
-  if (argc > 1 && !strcmp(argv[1], "--e2e-bench")) return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"), argc > 6 ? atoi(argv[6]) : 1);
+  if (argc > 1 && !strcmp(argv[1], "--e2e-bench")) {   // ... [--devices 0,0] at the end: several engines (cns_group)
+    std::vector<int> dev{0};
+    for (int a = 2; a + 1 < argc; ++a) if (!strcmp(argv[a], "--devices")) { dev = parse_devices(argv[a + 1]); argc = a; break; }
+    return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"), argc > 6 ? atoi(argv[6]) : 1, dev);
+  }
+  if (argc > 1 && !strcmp(argv[1], "--group-check"))
+    return group_check(argc > 2 ? atoi(argv[2]) : 8192, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 60000, parse_devices(argc > 5 ? argv[5] : "0,0"));
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
   if (argc > 2 && !strcmp(argv[1], "--wire-dump")) return wire_dump(argv[2], argc > 3 ? atoi(argv[3]) : 600, argc > 4 && !strcmp(argv[4], "jobtod"));
   if (argc > 1 && !strcmp(argv[1], "--mirror-check")) return mirror_check(argc > 2 ? atoi(argv[2]) : 4096, argc > 3 ? atoi(argv[3]) : 20000);

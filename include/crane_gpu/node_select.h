@@ -227,6 +227,36 @@ typedef struct cns_timing {
 
 typedef struct cns_engine cns_handle;
 
+/* ---- several devices ------------------------------------------------------------------------------------------------
+ * The reference owns the algorithm through ONE object built at one place and called once per cycle
+ * (JobScheduler.cpp:158-159,1441); independent LocalSchedulers per partition are its natural shards (:6723-6732,
+ * 6746-6761).  The unit of sharding is the group of partitions connected through shared nodes (one NodeState per
+ * craned, :6563,6609-6617); group g runs on device g % N, its slice of the queue keeps its order, and ONE all-gather of
+ * the packed result buffers per cycle leaves every device with the merged claim list — RCCL's ncclAllGather (ring over
+ * xGMI) whenever every rank has a device of its own; groups never interact, so the merge has no claim to resolve.
+ *   cns_group_*            one process drives N devices (the C++ adapter: GpuNodeSelectionAlgo(std::vector<int>));
+ *   cns_comm_* + cns_allgather_results   one process per device; the caller ships rank 0's id to the other ranks. */
+#define CNS_COMM_ID_BYTES 128u
+typedef enum cns_gather_mode {
+  CNS_GATHER_RCCL = 1,            /* ncclAllGather, in place, one call per cycle                                    */
+  CNS_GATHER_DEVICE_COPIES = 2    /* the group lists a device ordinal twice (RCCL refuses two ranks on one device: how
+                                     the path is exercised on a one-GPU box): the same bytes, device-to-device copies */
+} cns_gather_mode;
+typedef struct cns_results_offsets { /* byte offsets of the packed result buffer (cns_device_results) of the last upload */
+  uint64_t num_jobs, num_places;
+  uint32_t wide_cores, reserved0;
+  uint64_t start_sec, cpu_raw, mem, core_lo, core_hi, gres, node_idx, ntasks, reason, core_w2, core_w3, total_bytes;
+} cns_results_offsets;
+typedef struct cns_group_info {     /* the last cns_group_select */
+  uint32_t num_devices;
+  uint32_t gather_mode;             /* cns_gather_mode */
+  double shards_ms;                 /* deal + pack + upload + run of every device (host threads, wall clock) */
+  double max_select_ms;             /* the slowest device's selection kernel (HIP events) */
+  double allgather_ms, download_ms, scatter_ms;
+  uint64_t slot_bytes;              /* bytes every rank contributes to the all-gather (padded to the largest shard) */
+} cns_group_info;
+typedef struct cns_group cns_group;
+
 int cns_abi_version(void);
 /* Human readable message of the last error on this handle (or of the last failed cns_create when h==NULL). */
 const char* cns_last_error(const cns_handle* h);
@@ -249,6 +279,27 @@ int cns_run_resident(cns_handle* h, int64_t now_sec);          /* init + select 
 int cns_download(cns_handle* h, cns_placement_soa* out);
 /* Device pointer + byte size of the packed placement buffer of the last run (for RCCL allgather). */
 int cns_device_results(cns_handle* h, void** dptr, uint64_t* bytes);
+int cns_results_layout(const cns_handle* h, cns_results_offsets* out);   /* where the arrays sit in that buffer */
+/* one process per device: a communicator over the ranks' engines, and the all-gather of their packed results */
+int cns_comm_unique_id(uint8_t id[CNS_COMM_ID_BYTES]);                    /* rank 0; ship the bytes to every rank */
+int cns_comm_init_rank(cns_handle* h, uint32_t nranks, uint32_t rank, const uint8_t id[CNS_COMM_ID_BYTES]);   /* collective */
+int cns_comm_destroy(cns_handle* h);
+int cns_allgather_results(cns_handle* h, uint64_t slot_bytes, void** gathered_dptr);   /* collective, after a run: rank r's buffer
+                                                                                          (padded to slot_bytes, a multiple of 16) at [r * slot_bytes) */
+int cns_download_gathered(cns_handle* h, void* dst, uint64_t bytes);
+int cns_gather_timing(const cns_handle* h, double* ms, uint64_t* bytes);
+/* one process, N devices */
+int cns_group_create(const cns_config* cfg, const int32_t* devices, uint32_t num_devices, cns_group** out);   /* cfg->device is ignored */
+void cns_group_destroy(cns_group* g);
+const char* cns_group_last_error(const cns_group* g);
+uint32_t cns_group_size(const cns_group* g);
+cns_handle* cns_group_handle(cns_group* g, uint32_t device_index);          /* e.g. for cns_host_alloc, cns_debug_* of one device */
+int cns_group_set_nodes(cns_group* g, const cns_node_soa* nodes);          /* deals the groups of partitions: group i -> device i % N */
+int cns_group_set_reservations(cns_group* g, const cns_resv_soa* resv);    /* every device; the jobs of reservation v run on (active) device v % N */
+int cns_group_set_running(cns_group* g, const cns_running_soa* running);   /* every device (allocations on nodes it does not schedule are dropped there) */
+int cns_group_select(cns_group* g, int64_t now_sec, const cns_job_soa* jobs, cns_placement_soa* out);   /* = cns_select, merged in queue order */
+int cns_group_get_info(const cns_group* g, cns_group_info* out);
+uint32_t cns_group_device_of_partition(const cns_group* g, uint32_t partition);
 
 /* Page-locked host memory for the caller's job arrays and result arrays (optional).  Every host buffer stays the caller's
  * (ownership); buffers from here are copied by the DMA engines directly — pageable memory goes through the

@@ -59,3 +59,20 @@ def test_event_fed_mirror_equals_running_vector_walk(built):
     tables as the per-cycle walk over the running vector (after churn, an end-time change and a new snapshot)."""
     r = subprocess.run([EXE, "--mirror-check", "2048", "20000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0", "0,0", "0,0,0,0"])
+def test_one_algorithm_object_over_several_devices_on_gpu(built, devices):
+    """GpuNodeSelectionAlgo(std::vector<int> devices): one engine per device behind ONE algorithm object (the reference builds one,
+    JobScheduler.cpp:158-159), the groups of partitions dealt over them, shards on their own host threads, the packed results
+    all-gathered on the devices (a repeated ordinal runs the engines side by side on one GPU and gathers with device-to-device
+    copies; "0": ncclAllGather is not involved at all) and merged into the PdJobInSchedulers in queue order — against one engine, job by job."""
+    r = subprocess.run([EXE, "--group-check", "4096", "8", "40000", devices], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_whole_cycle_through_the_adapter_on_two_engines(built):
+    r = subprocess.run([EXE, "--e2e-bench", "4096", "8", "40000", "lazy", "2", "--devices", "0,0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
