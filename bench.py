@@ -116,21 +116,42 @@ def main():
         limits = synth.make_limits(args.config, cluster, jobs)
         eng.set_run_limits(limits[0])
 
+    # The all-gather of the packed placements is the ENGINE's (cns_comm_init_rank + cns_allgather_results: one in-place ncclAllGather on the
+    # engine's stream, csrc/group_host.inc); torch.distributed only ships rank 0's communicator id, and carries the barrier and the
+    # max-over-ranks of the timing.  Should the engine's communicator not come up on this node, the same bytes go through
+    # torch.distributed's all-gather and the line says so ("allgather").
     gather_in = gather_out = None
+    gather_via = None
     if use_dist:
         ptr, nbytes = eng.device_results()
-        mx = torch.tensor([nbytes], device=dev, dtype=torch.int64)
+        mx = torch.tensor([(nbytes + 15) & ~15], device=dev, dtype=torch.int64)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         pad = int(mx.item())
-        src = sharding.device_bytes_tensor(ptr, nbytes, dev)
-        gather_in = torch.zeros(pad, dtype=torch.uint8, device=dev)
-        gather_out = torch.empty(pad * world, dtype=torch.uint8, device=dev)
+        try:
+            uid = [GpuNodeSelector.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0, device=dev)
+            eng.comm_init_rank(world, rank, uid[0])
+            ok = torch.tensor([1], device=dev, dtype=torch.int64)
+            gather_via = "engine: ncclAllGather inside libcrane_gpu_nodeselect.so (cns_allgather_results)"
+        except Exception as ex:   # noqa: BLE001 — reported in the line, never silent
+            ok = torch.tensor([0], device=dev, dtype=torch.int64)
+            gather_via = f"torch.distributed fallback ({type(ex).__name__}: {ex})"
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:   # (every rank takes the same path)
+            if not gather_via.startswith("torch"):
+                gather_via = "torch.distributed fallback (another rank's engine communicator did not come up)"
+            src = sharding.device_bytes_tensor(ptr, nbytes, dev)
+            gather_in = torch.zeros(pad, dtype=torch.uint8, device=dev)
+            gather_out = torch.empty(pad * world, dtype=torch.uint8, device=dev)
 
     def step():
         eng.run_resident(now)                      # init kernel + persistent selection kernel (synchronous)
         if use_dist:                               # merge per-shard node claims: one all-gather over xGMI
-            gather_in[:nbytes].copy_(src)
-            dist.all_gather_into_tensor(gather_out, gather_in)
+            if gather_out is None:
+                eng.allgather_results(pad)
+            else:
+                gather_in[:nbytes].copy_(src)
+                dist.all_gather_into_tensor(gather_out, gather_in)
 
     for _ in range(args.warmup):
         step()
@@ -163,7 +184,7 @@ def main():
     gather_check = None
     if use_dist and rank == 0:
         torch.cuda.synchronize()
-        host = gather_out.cpu().numpy()
+        host = eng.download_gathered(pad * world) if gather_out is None else gather_out.cpu().numpy()
         shards = []
         for rk in range(world):
             sj, sidx = sharding.shard(cluster, jobs, rk, world) if world > 1 else (jobs, np.arange(jobs.num_jobs))   # (partition ids are not in the packed buffer)
@@ -281,6 +302,11 @@ def main():
             line["incl_h2d_d2h"] = incl
         if gather_check is not None:
             line["allgather_merged_identical_to_single_gpu"] = bool(gather_check)
+            line["allgather"] = gather_via
+            if gather_out is None:
+                gms, gbytes = eng.gather_timing()
+                line["allgather_ms"] = gms
+                line["allgather_bytes_per_rank"] = int(gbytes // max(world, 1))
         if lim_line is not None:
             from cranesched_amd import limits as lm
             lim_line["rejected_by"] = {lm.LIMIT_REASON_STR[int(k)]: v for k, v in lim_line["rejected_by"].items()}

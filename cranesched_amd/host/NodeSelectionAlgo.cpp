@@ -966,6 +966,38 @@ void GpuNodeSelectionAlgo::NodeSelect(const TimeSec& now,
 }
 
 // the cycle proper, on the running allocations already packed in Impl::r_*
+// LicenseManager::CheckLicenseCountSufficient (LicenseManager.cpp:167-221), the pre-pass NodeSelect runs between ordering and selection
+// (JobScheduler.cpp:6739): a sequential counter pass over the ordered jobs on the cycle's working copy of the license table.  Host-only
+// and static, so that it is pinned to the reference's own compiled function without a device (tests/test_ref_pin.py).
+void GpuNodeSelectionAlgo::CheckLicenseCountSufficient(const std::unordered_map<std::string, License>& licenses, const std::vector<PdJobInScheduler*>& ord) {
+  std::unordered_map<std::string, License> avail = licenses;  // the cycle's working copy (:169-176)
+  for (PdJobInScheduler* job : ord) {
+    if (job->req_licenses.empty()) continue;
+    job->actual_licenses.clear();
+    if (job->is_license_or) {  // first alternative that fits (:183-194)
+      for (const auto& [key, count] : job->req_licenses) {
+        auto it = avail.find(key);
+        if (it == avail.end()) continue;
+        const License& lic = it->second;
+        if ((uint32_t)(count + lic.reserved + lic.used + lic.last_deficit) <= lic.total) {   // (uint32 arithmetic, as the reference's: :188-189)
+          job->actual_licenses.emplace(key, count);
+          break;
+        }
+      }
+    } else {                   // all of them (:195-210)
+      for (const auto& [key, count] : job->req_licenses) {
+        auto it = avail.find(key);
+        if (it == avail.end()) { job->actual_licenses.clear(); break; }
+        const License& lic = it->second;
+        if ((uint32_t)(count + lic.reserved + lic.used + lic.last_deficit) > lic.total) { job->actual_licenses.clear(); break; }
+        job->actual_licenses.emplace(key, count);
+      }
+    }
+    if (job->actual_licenses.empty()) { job->reason = "License"; continue; }  // :212-215
+    for (const auto& [key, count] : job->actual_licenses) avail[key].used += count;  // :217-219
+  }
+}
+
 void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs,
                                          const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs) {
   Impl& I = *impl_;
@@ -1001,35 +1033,8 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
     ord.reserve(pending_jobs.size());
     for (const auto& j : pending_jobs) ord.push_back(j.get());
   }
-  // ---- license pre-pass (JobScheduler.cpp:6739; LicenseManager::CheckLicenseCountSufficient, LicenseManager.cpp:167-221)
-  {
-    std::unordered_map<std::string, License> avail = licenses_;  // the cycle's working copy (:169-176)
-    for (PdJobInScheduler* job : ord) {
-      if (job->req_licenses.empty()) continue;
-      job->actual_licenses.clear();
-      if (job->is_license_or) {  // first alternative that fits (:183-194)
-        for (const auto& [key, count] : job->req_licenses) {
-          auto it = avail.find(key);
-          if (it == avail.end()) continue;
-          const License& lic = it->second;
-          if ((uint64_t)count + lic.reserved + lic.used + lic.last_deficit <= lic.total) {
-            job->actual_licenses.emplace(key, count);
-            break;
-          }
-        }
-      } else {                   // all of them (:195-210)
-        for (const auto& [key, count] : job->req_licenses) {
-          auto it = avail.find(key);
-          if (it == avail.end()) { job->actual_licenses.clear(); break; }
-          const License& lic = it->second;
-          if ((uint64_t)count + lic.reserved + lic.used + lic.last_deficit > lic.total) { job->actual_licenses.clear(); break; }
-          job->actual_licenses.emplace(key, count);
-        }
-      }
-      if (job->actual_licenses.empty()) { job->reason = "License"; continue; }  // :212-215
-      for (const auto& [key, count] : job->actual_licenses) avail[key].used += count;  // :217-219
-    }
-  }
+  // ---- license pre-pass (JobScheduler.cpp:6739) ---------------------------------------------------------------------------------
+  CheckLicenseCountSufficient(licenses_, ord);
   const size_t J = ord.size();
   const auto tp0 = std::chrono::steady_clock::now();
   Impl::PackedJobs& B = I.packed;

@@ -326,6 +326,8 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // sequential counter pass over the ordered jobs, done on the host; jobs it rejects get reason "License" and are
   // not given to the device.  Empty table + no requests = no-op.
   void SetLicenses(std::unordered_map<std::string, License> licenses) { licenses_ = std::move(licenses); }
+  // ... the pass itself (host-only; NodeSelect calls it with the table of SetLicenses and the sorter's order)
+  static void CheckLicenseCountSufficient(const std::unordered_map<std::string, License>& licenses, const std::vector<PdJobInScheduler*>& ord);
 
   void NodeSelect(const TimeSec& now, const std::vector<std::unique_ptr<RnJobInScheduler>>& running_jobs,
                   const std::vector<std::unique_ptr<PdJobInScheduler>>& pending_jobs) override;

@@ -289,6 +289,51 @@ static int cycle_bench(int n_nodes, int n_jobs, int threads = 1) {
 // One whole NodeSelect through the adapter at full size, on the GPU: what an integrator's ScheduleThread sees between entering and
 // leaving m_node_selection_algo_->NodeSelect (JobScheduler.cpp:1439-1447) — packing, cns_select, write-back — P partitions of N / P nodes
 // (64 cores, 256 GiB), J pending jobs of 1..8 cores for 10..170 minutes, spread over the partitions.
+// The license pre-pass on a case from a file (tests/test_ref_pin.py writes it and runs the reference's own compiled
+// LicenseManager::CheckLicenseCountSufficient on the same arrays): "L J", L lines "total used reserved last_deficit", J lines
+// "is_or n (license count) x n" with license indices (>= L: unknown to the table).  Prints per job "rejected n (license count) x n",
+// the actual licenses sorted by index.
+static int license_file(const char* path) {
+  FILE* f = fopen(path, "r");
+  if (!f) { printf("cannot open %s\n", path); return 2; }
+  unsigned L = 0, J = 0;
+  if (fscanf(f, "%u %u", &L, &J) != 2) { fclose(f); return 2; }
+  std::unordered_map<std::string, License> table;
+  for (unsigned l = 0; l < L; ++l) {
+    License lic;
+    if (fscanf(f, "%u %u %u %u", &lic.total, &lic.used, &lic.reserved, &lic.last_deficit) != 4) { fclose(f); return 2; }
+    table["lic" + std::to_string(l)] = lic;
+  }
+  std::vector<std::unique_ptr<PdJobInScheduler>> pd;
+  std::vector<PdJobInScheduler*> ord;
+  for (unsigned j = 0; j < J; ++j) {
+    unsigned is_or = 0, n = 0;
+    if (fscanf(f, "%u %u", &is_or, &n) != 2) { fclose(f); return 2; }
+    auto p = std::make_unique<PdJobInScheduler>();
+    p->job_id = j; p->is_license_or = is_or != 0;
+    for (unsigned x = 0; x < n; ++x) {
+      unsigned lic = 0, cnt = 0;
+      if (fscanf(f, "%u %u", &lic, &cnt) != 2) { fclose(f); return 2; }
+      p->req_licenses.emplace_back("lic" + std::to_string(lic), cnt);
+    }
+    p->actual_licenses.emplace("stale", 1u);
+    ord.push_back(p.get());
+    pd.push_back(std::move(p));
+  }
+  fclose(f);
+  GpuNodeSelectionAlgo::CheckLicenseCountSufficient(table, ord);
+  for (const auto& p : pd) {
+    std::vector<std::pair<unsigned, unsigned>> a;
+    if (!p->req_licenses.empty())
+      for (const auto& [id, cnt] : p->actual_licenses) a.emplace_back((unsigned)strtoul(id.c_str() + 3, nullptr, 10), cnt);
+    std::sort(a.begin(), a.end());
+    printf("%d %zu", p->reason == "License" ? 1 : 0, a.size());
+    for (const auto& [l, c] : a) printf(" %u %u", l, c);
+    printf("\n");
+  }
+  return 0;
+}
+
 static std::vector<int> parse_devices(const char* s) {   // "0,1,2" (a repeated ordinal — "0,0" — runs several engines on one GPU)
   std::vector<int> d;
   for (const char* p = s; p && *p;) {
@@ -528,6 +573,7 @@ int main(int argc, char** argv) {
     for (int a = 2; a + 1 < argc; ++a) if (!strcmp(argv[a], "--devices")) { dev = parse_devices(argv[a + 1]); argc = a; break; }
     return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"), argc > 6 ? atoi(argv[6]) : 1, dev);
   }
+  if (argc > 2 && !strcmp(argv[1], "--license-file")) return license_file(argv[2]);
   if (argc > 1 && !strcmp(argv[1], "--group-check"))
     return group_check(argc > 2 ? atoi(argv[2]) : 8192, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 60000, parse_devices(argc > 5 ? argv[5] : "0,0"));
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);

@@ -287,3 +287,29 @@ def schedule_steps(layout: abi.GresLayout, step_jobs, steps, algebra: int = MASK
     if rc != 0:
         raise RuntimeError(f"ora_schedule_steps ({backend}) failed: {rc}: {L.ref_last_error().decode() if backend != 'oracle' else ''}")
     return out
+
+
+def license_check(total, used, reserved, last_deficit, requests, is_or, backend: str = "ref"):
+    """THE REFERENCE'S OWN LicenseManager::CheckLicenseCountSufficient (LicenseManager.cpp:167-221, sliced at build time) on
+    a license table (four uint32 columns) and the ordered jobs' requests: requests[j] = [(license index, count), ...] in
+    request order (an index >= len(total): a license the table does not know).  -> (rejected [J] bool, actual [J] lists of
+    (license index, count) sorted by index).  There is no restated oracle of this pass: the product's host pass is compared
+    with the reference build directly (tests/test_ref_pin.py)."""
+    L = ref_lib(backend)
+    u32 = lambda a: np.ascontiguousarray(a, np.uint32)
+    total, used, reserved, last_deficit = u32(total), u32(used), u32(reserved), u32(last_deficit)
+    J = len(requests)
+    off = np.zeros(J + 1, np.uint32)
+    off[1:] = np.cumsum([len(r) for r in requests])
+    flat = [x for r in requests for x in r]
+    rl = u32([x[0] for x in flat] or [0]); rc = u32([x[1] for x in flat] or [0])
+    io = np.ascontiguousarray(is_or, np.uint8)
+    rej = np.zeros(max(J, 1), np.uint8)
+    aoff = np.zeros(J + 1, np.uint32)
+    al = np.zeros(max(len(flat), 1), np.uint32); ac = np.zeros(max(len(flat), 1), np.uint32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc_ = L.ref_license_check(C.c_uint32(len(total)), p(total), p(used), p(reserved), p(last_deficit), C.c_uint32(J), p(off), p(rl), p(rc), p(io),
+                              p(rej), p(aoff), p(al), p(ac))
+    if rc_ != 0:
+        raise RuntimeError(f"ref_license_check: {L.ref_last_error().decode()}")
+    return rej[:J].astype(bool), [[(int(al[x]), int(ac[x])) for x in range(aoff[j], aoff[j + 1])] for j in range(J)]

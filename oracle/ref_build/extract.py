@@ -25,6 +25,9 @@ What is sliced:
                    CheckQosRunLimitsForEntity_, CheckPartitionRunLimitsForEntity_, CheckEntityRunLimits_,
                    CheckRunLimits_, CheckGres_, LockAccountStripes_, DoMallocResource_}
   CtldPublicDefs.cpp        JobInCtld::SchedulePendingSteps (SURVEY.md §8f-4)
+  AccountDefs.h             struct License
+  LicenseManager.cpp        LicenseManager::CheckLicenseCountSufficient — the license pre-pass NodeSelect runs between ordering and
+                   selection (JobScheduler.cpp:6739)
 
 Every slice is located by ANCHOR TEXT (a changed reference fails loudly) and the line
 ranges found are written to oracle/_ref/gen/MANIFEST.txt.  No line of a slice is edited.
@@ -45,6 +48,8 @@ JS_CPP = "src/CraneCtld/JobScheduler.cpp"
 AMC_H = "src/CraneCtld/Accounting/AccountMetaContainer.h"
 AMC_CPP = "src/CraneCtld/Accounting/AccountMetaContainer.cpp"
 CPD_CPP = "src/CraneCtld/CtldPublicDefs.cpp"
+ACD_H = "src/CraneCtld/Account/AccountDefs.h"
+LM_CPP = "src/CraneCtld/Accounting/LicenseManager.cpp"
 
 
 def read(rel):
@@ -232,11 +237,20 @@ def main():
     ranges = [definition_range(cc, "JobInCtld::SchedulePendingSteps(")]
     emit("steps_impl.inc", CPD_CPP, ranges, cc, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
 
+    # ---- AccountDefs.h: struct License; LicenseManager.cpp: the pre-pass of NodeSelect ---------------------------------
+    ad = read(ACD_H)
+    b = find_line(ad, "struct License {", exact=True)
+    e = find_line(ad, "};", b, exact=True)
+    emit("license_types.inc", ACD_H, [(b, e)], ad, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
+    lm = read(LM_CPP)
+    ranges = [definition_range(lm, "LicenseManager::CheckLicenseCountSufficient(")]
+    emit("license_impl.inc", LM_CPP, ranges, lm, prologue="namespace Ctld {\n", epilogue="}  // namespace Ctld\n")
+
     sha = hashlib.sha256()
-    for rel in (PH_H, PH_CPP, JS_H, JS_CPP, AMC_H, AMC_CPP, CPD_CPP):
+    for rel in (PH_H, PH_CPP, JS_H, JS_CPP, AMC_H, AMC_CPP, CPD_CPP, ACD_H, LM_CPP):
         with open(os.path.join(REF, rel), "rb") as f:
             sha.update(f.read())
-    manifest.append("sha256 of the seven reference files: " + sha.hexdigest())
+    manifest.append("sha256 of the nine reference files: " + sha.hexdigest())
     with open(os.path.join(args.out, "MANIFEST.txt"), "w") as f:
         f.write("\n".join(manifest) + "\n")
     print("\n".join(manifest))

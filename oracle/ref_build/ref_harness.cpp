@@ -61,6 +61,7 @@ class crane_ref_ordered_map : public std::map<K, V> {
 #undef private
 #include "amc_impl.inc"
 #include "steps_impl.inc"
+#include "license_impl.inc"   // LicenseManager::CheckLicenseCountSufficient (LicenseManager.cpp)
 #undef unexpected
 
 #ifdef CRANE_REF_CANONICAL
@@ -273,7 +274,7 @@ static int ref_select_impl(const cns_config* cfg, const cns_node_soa* nodes, con
 
   CranedMetaContainer meta;
   AccountManager accounts;
-  LicensesManager licenses;
+  LicenseManager licenses;
   RefJobSchedulerStub sched_stub;
   try {
     // ---- g_meta_container: craned metas, partitions, reservations --------------------------------------
@@ -872,6 +873,57 @@ int ora_schedule_steps(const cns_gres_layout* gl, const cns_step_job_soa* jb, co
         if (out->avail_core_w2) out->avail_core_w2[n] = m.c2;
         if (out->avail_core_w3) out->avail_core_w3[n] = m.c3;
       }
+    }
+    return 0;
+  } catch (const crane_ref::RefAssertion& e) { g_last_error = std::string("reference assertion failed: ") + e.what(); return -3;
+  } catch (const std::exception& e) { g_last_error = e.what(); return -2; }
+}
+
+// ---- LicenseManager::CheckLicenseCountSufficient (LicenseManager.cpp:167-221), the pre-pass NodeSelect runs between ordering and
+// selection (JobScheduler.cpp:6739), on flat arrays.  License l = 0..L-1 is named "lic<l>" (an index >= L in a request: a license the
+// table does not know); job j asks for entries [req_off[j], req_off[j + 1]) of (req_lic, req_cnt) IN REQUEST ORDER; is_or[j]: the first
+// alternative that fits instead of all of them.  Out: rejected[j] = the job left with reason "License"; its actual_licenses as
+// (license index, count) sorted by index at [act_off[j], act_off[j + 1]).
+int ref_license_check(uint32_t L, const uint32_t* total, const uint32_t* used, const uint32_t* reserved, const uint32_t* last_deficit,
+                      uint32_t J, const uint32_t* req_off, const uint32_t* req_lic, const uint32_t* req_cnt, const uint8_t* is_or,
+                      uint8_t* rejected, uint32_t* act_off, uint32_t* act_lic, uint32_t* act_cnt) {
+  using namespace Ctld;
+  try {
+    LicenseManager lm;
+    for (uint32_t l = 0; l < L; ++l) {
+      License lic{};
+      lic.license_id = "lic" + std::to_string(l);
+      lic.total = total[l]; lic.used = used[l]; lic.reserved = reserved[l]; lic.last_deficit = last_deficit[l];
+      lic.remote = false; lic.last_consumed = 0;
+      lm.m_licenses_map_.map[lic.license_id].value = lic;
+    }
+    JobArena<PdJobInScheduler> arena(J);
+    std::vector<PdJobInScheduler*> vec;
+    for (uint32_t j = 0; j < J; ++j) {
+      JobInCtld jc;
+      jc.job_id = j;
+      PdJobInScheduler* p = arena.make(&jc);
+      for (uint32_t x = req_off[j]; x < req_off[j + 1]; ++x) {
+        auto* e = p->req_licenses.Add();
+        e->key_ = "lic" + std::to_string(req_lic[x]);
+        e->count_ = req_cnt[x];
+      }
+      p->is_license_or = is_or[j] != 0;
+      p->actual_licenses.emplace("stale", 1u);   // (the pass must clear what an earlier cycle left: :181)
+      vec.push_back(p);
+    }
+    lm.CheckLicenseCountSufficient(&vec);
+    act_off[0] = 0;
+    for (uint32_t j = 0; j < J; ++j) {
+      const PdJobInScheduler* p = vec[j];
+      rejected[j] = p->reason == "License" ? 1 : 0;
+      std::vector<std::pair<uint32_t, uint32_t>> a;
+      if (req_off[j + 1] != req_off[j])   // (a job without requests is not looked at: its map stays as it was)
+        for (const auto& [id, cnt] : p->actual_licenses) a.emplace_back((uint32_t)strtoul(id.c_str() + 3, nullptr, 10), cnt);
+      std::sort(a.begin(), a.end());
+      uint32_t o = act_off[j];
+      for (const auto& [l, c] : a) { act_lic[o] = l; act_cnt[o] = c; ++o; }
+      act_off[j + 1] = o;
     }
     return 0;
   } catch (const crane_ref::RefAssertion& e) { g_last_error = std::string("reference assertion failed: ") + e.what(); return -3;

@@ -82,7 +82,12 @@ class ResourceView;
 enum JobStatus { Pending, Running, Completed, Failed, ExceedTimeLimit, Cancelled, OutOfMemory, Deadline, Configuring };
 enum class PreemptType { PREEMPT_NONE = 0, PREEMPT_QOS = 1 };
 struct JobToCtld {
-  struct License {};
+  struct License {   // message JobToCtld.License { string key = 1; uint32 count = 2; } — what LicenseManager.cpp:183-210 reads of it
+    std::string key_;
+    uint32_t count_ = 0;
+    const std::string& key() const { return key_; }
+    uint32_t count() const { return count_; }
+  };
   int licenses_count() const { return 0; }
   bool is_licenses_or() const { return false; }
 };
@@ -90,10 +95,16 @@ struct JobToCtld {
 
 namespace google::protobuf {
 template <class T>
-class RepeatedPtrField {
+class RepeatedPtrField {   // element order = request order; the slices iterate it, test empty() and read size()
  public:
   RepeatedPtrField() = default;
   explicit RepeatedPtrField(int) {}
-  int size() const { return 0; }
+  int size() const { return (int)v_.size(); }
+  bool empty() const { return v_.empty(); }
+  typename std::vector<T>::const_iterator begin() const { return v_.begin(); }
+  typename std::vector<T>::const_iterator end() const { return v_.end(); }
+  T* Add() { v_.emplace_back(); return &v_.back(); }
+ private:
+  std::vector<T> v_;
 };
 }  // namespace google::protobuf

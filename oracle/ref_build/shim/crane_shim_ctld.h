@@ -216,11 +216,27 @@ struct AccountManager {
 inline AccountManager* g_account_manager = nullptr;
 
 struct PdJobInScheduler;
-// src/CraneCtld/Accounting/LicenseManager.h:63 — licenses are outside SURVEY.md §8
-struct LicensesManager {
-  void CheckLicenseCountSufficient(std::vector<PdJobInScheduler*>*) {}
+}  // namespace Ctld
+#include "license_types.inc"   // struct License, AccountDefs.h (generated at build time)
+namespace Ctld {
+// src/CraneCtld/Accounting/LicenseManager.h:41-123: the class around the ONE member function the path calls
+// (CheckLicenseCountSufficient, compiled from the reference's text: license_impl.inc).  m_licenses_map_ is a
+// util::AtomicHashMap<HashMap, LicenseId, License> there (crane/AtomicHashMap.h): GetMapExclusivePtr() dereferences to a map whose
+// values hand out the License through GetExclusivePtr() — the stand-in keeps exactly that shape, without the locks.
+struct ShimLicenseEntry {
+  License value;
+  const License* GetExclusivePtr() const { return &value; }
 };
-inline LicensesManager* g_license_manager = nullptr;
+struct ShimLicenseMap {
+  std::unordered_map<LicenseId, ShimLicenseEntry> map;
+  const std::unordered_map<LicenseId, ShimLicenseEntry>* GetMapExclusivePtr() const { return &map; }
+};
+class LicenseManager {
+ public:
+  void CheckLicenseCountSufficient(std::vector<PdJobInScheduler*>* job_ptr_vec);
+  ShimLicenseMap m_licenses_map_;
+};
+inline LicenseManager* g_license_manager = nullptr;
 
 // JobScheduler::EnqueuePreemptCancel, JobScheduler.h:1112
 struct RefJobSchedulerStub {

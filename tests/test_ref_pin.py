@@ -328,3 +328,68 @@ def test_reference_code_on_the_core_id_shortfall_case():
     c, j, rn, rv = core_id_shortfall_case()
     a, b = both("core id shortfall", c, j, NOW, running=rn, reservations=rv)
     assert b.placements.reason[0] == 0 and b.placements.start_sec[0] == NOW and b.placements.core_lo[0] == 0b111
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The license pre-pass of NodeSelect (JobScheduler.cpp:6739): LicenseManager::CheckLicenseCountSufficient
+# (LicenseManager.cpp:167-221) — the reference's own compiled function against the host pass of the product's adapter
+# (cranesched_amd/host/NodeSelectionAlgo.cpp: GpuNodeSelectionAlgo::CheckLicenseCountSufficient), same tables, same requests
+# ---------------------------------------------------------------------------------------------------------------------
+def _license_case(seed):
+    import random
+    rng = random.Random(seed)
+    L = rng.choice([1, 2, 3, 6])
+    big = rng.random() < 0.15      # counts near 2^32: the reference adds in uint32
+    total = [rng.choice([0, 1, 4, 10, 100, 2 ** 32 - 1 if big else 50]) for _ in range(L)]
+    used = [rng.randrange(0, t + 1) if rng.random() < 0.5 else 0 for t in total]
+    reserved = [rng.choice([0, 0, 1, 3]) for _ in range(L)]
+    deficit = [rng.choice([0, 0, 0, 2, 2 ** 31 if big else 5]) for _ in range(L)]
+    J = rng.randrange(1, 120)
+    reqs, is_or = [], []
+    for _ in range(J):
+        n = rng.choice([0, 1, 1, 2, 3])
+        reqs.append([(rng.randrange(0, L + (1 if rng.random() < 0.2 else 0)), rng.choice([1, 1, 2, 5, 2 ** 32 - 2 if big else 7])) for _ in range(n)])
+        is_or.append(rng.random() < 0.4)
+    return total, used, reserved, deficit, reqs, is_or
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_license_pre_pass_of_the_adapter_against_the_reference_code(seed, tmp_path):
+    import os
+    import subprocess
+    import __graft_entry__ as g
+    g.build_host()
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cranesched_amd", "host", "test_host_adapter")
+    total, used, reserved, deficit, reqs, is_or = _license_case(seed)
+    rej, actual = pyoracle.license_check(total, used, reserved, deficit, reqs, is_or)
+    path = tmp_path / "case.txt"
+    with open(path, "w") as f:
+        f.write(f"{len(total)} {len(reqs)}\n")
+        for l in range(len(total)):
+            f.write(f"{total[l]} {used[l]} {reserved[l]} {deficit[l]}\n")
+        for r, o in zip(reqs, is_or):
+            f.write(f"{int(o)} {len(r)} " + " ".join(f"{a} {b}" for a, b in r) + "\n")
+    out = subprocess.run([exe, "--license-file", str(path)], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == len(reqs)
+    for j, ln in enumerate(lines):
+        v = [int(x) for x in ln.split()]
+        got = [(v[2 + 2 * i], v[3 + 2 * i]) for i in range(v[1])]
+        assert bool(v[0]) == bool(rej[j]) and got == actual[j], (seed, j, reqs[j], is_or[j], ln, rej[j], actual[j])
+    # the pass does something in these cases: some job is rejected, or some license is granted
+    assert any(rej) or any(actual)
+
+
+def test_license_pre_pass_known_answers_of_the_reference_code():
+    """hand-derived from LicenseManager.cpp:183-219: AND takes all or nothing, OR the first alternative that fits, `used` accumulates
+    over the ordered jobs, `reserved` and `last_deficit` count against the total, an unknown license fails AND and is skipped by OR"""
+    rej, act = pyoracle.license_check([4, 1], [1, 0], [1, 0], [0, 0],
+                                      [[(0, 2)], [(0, 1)], [(0, 1), (1, 1)], [(0, 1), (1, 1)], [(5, 1), (1, 1)], [(5, 1), (1, 1)], []],
+                                      [False, False, True, False, True, False, False])
+    # job 0: 2 + reserved 1 + used 1 = 4 <= 4; job 1: 1 + 1 + 3 > 4; job 2 (OR): lic0 full, lic1 fits; job 3 (AND): lic0 full; job 4 (OR): the
+    # unknown license is skipped, lic1 is taken by now; job 5 (AND): an unknown license fails it; job 6: no request, not looked at
+    assert list(rej) == [False, True, False, True, True, True, False]
+    assert act == [[(0, 2)], [], [(1, 1)], [], [], [], []]
+    rej, act = pyoracle.license_check([4, 1], [0, 0], [0, 0], [0, 0], [[(0, 4)], [(0, 1), (1, 1)], [(1, 1)]], [False, True, False])
+    assert list(rej) == [False, False, True] and act == [[(0, 4)], [(1, 1)], []]

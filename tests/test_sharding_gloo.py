@@ -70,7 +70,10 @@ def _worker(rank, world, port, q, cfg=("C4", 6000, 512, 8)):
 # C4p256: 256 partitions (one GPU: k_pipe; 4 / 8 GPUs: 64 / 32 busy partitions per rank -> k_wide x8 / x16)
 @pytest.mark.parametrize("world,cfg", [(2, ("C4", 6000, 512, 8)), (2, ("C4p64", 8000, 1024, 64)), (4, ("C4p64", 8000, 1024, 64)),
                                        (2, ("C4r", 6000, 512, 8)), (2, ("C4p256", 12000, 2048, 256)), (4, ("C4p256", 12000, 2048, 256)),
-                                       (8, ("C4p256", 12000, 2048, 256))])
+                                       (8, ("C4p256", 12000, 2048, 256)),
+                                       # BASELINE.json configuration 5 ("backfill window packing ... 8 x MI355X"): C5 scaled, and its
+                                       # deep variant (a quarter of the nodes per job, as fullrun's c5deep: most of the queue is backfilled)
+                                       (2, ("C5", 6000, 512, 8)), (8, ("C5", 8000, 1024, 8)), (4, ("C5", 9000, 256, 8))])
 def test_shard_allgather_merge(world, cfg):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
