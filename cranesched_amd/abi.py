@@ -14,7 +14,7 @@ from typing import Optional
 
 import numpy as np
 
-CNS_ABI_VERSION = 3
+CNS_ABI_VERSION = 4
 RESV_NONE = 0xFFFFFFFF
 MAX_GRES_CLASSES = 8
 MAX_GRES_NAMES = 4
@@ -23,12 +23,16 @@ NODE_NONE = 0xFFFFFFFF
 
 REASON_NONE, REASON_PRIORITY, REASON_RESOURCE, REASON_RESOURCE_RESERVED, \
     REASON_PARTITION_NOT_FOUND, REASON_SKIPPED, REASON_RESERVATION_NOT_FOUND = range(7)
+REASON_ENGINE_REFUSED = 8   # (7: "Preempted", include/crane_gpu/preempt.h)
+# cns_partition_status (cns_get_partition_status): why a partition's jobs came back with REASON_ENGINE_REFUSED
+PART_SERVED, PART_REFUSED_NODE, PART_REFUSED_CPU, PART_REFUSED_TYPES, PART_REFUSED_WIDTH = range(5)
 # cns_reason <-> the reference's reason strings (JobScheduler.cpp:6750-6831, JobScheduler.h:198)
 REASON_STR = {
     REASON_NONE: "", REASON_PRIORITY: "Priority", REASON_RESOURCE: "Resource",
     REASON_RESOURCE_RESERVED: "Resource Reserved",
     REASON_PARTITION_NOT_FOUND: "Partition Not Found", REASON_SKIPPED: "<caller-set>",
     REASON_RESERVATION_NOT_FOUND: "Reservation Not Found",
+    REASON_ENGINE_REFUSED: "<engine refused the partition: the caller's CPU scheduler takes the job>",
 }
 
 STATUS_STR = {0: "CNS_OK", -1: "CNS_ERR_INVALID_ARG", -2: "CNS_ERR_NO_DEVICE", -3: "CNS_ERR_HIP",
@@ -54,7 +58,7 @@ class CnsNodeSoa(C.Structure):
     _fields_ = [("num_nodes", C.c_uint32), ("num_partitions", C.c_uint32),
                 ("cpu_total_raw", _P), ("mem_total", _P), ("core_lo", _P), ("core_hi", _P),
                 ("gres_slots", _P), ("schedulable", _P), ("part_offsets", _P), ("part_nodes", _P),
-                ("gres", CnsGresLayout), ("core_w2", _P), ("core_w3", _P)]
+                ("gres", CnsGresLayout), ("core_w2", _P), ("core_w3", _P), ("unsupported", _P)]
 
 
 class CnsRunningSoa(C.Structure):
@@ -145,9 +149,12 @@ class Cluster:
     schedulable: Optional[np.ndarray] = None
     core_w2: Optional[np.ndarray] = None    # core ids 128..191 / 192..255 (ABI 3); None = no node has any
     core_w3: Optional[np.ndarray] = None
+    unsupported: Optional[np.ndarray] = None   # [N] uint8 (ABI 4): nodes the caller could not express (core id >= 256, too many GRES slots); None = none
 
     def __post_init__(self):
         n = len(self.cpu_total_raw)
+        if self.unsupported is not None:
+            self.unsupported = _arr(self.unsupported, np.uint8, n)
         if self.core_w2 is not None:
             self.core_w2 = _arr(self.core_w2, np.uint64, n)
         if self.core_w3 is not None:
@@ -184,6 +191,7 @@ class Cluster:
         s.part_offsets, s.part_nodes = _ptr(self.part_offsets), _ptr(self.part_nodes)
         s.gres = self.gres.to_c()
         s.core_w2, s.core_w3 = _ptr(self.core_w2), _ptr(self.core_w3)
+        s.unsupported = _ptr(self.unsupported)
         return s
 
 

@@ -75,6 +75,8 @@ struct cns_engine {
   bool shared = false;                        // some node belongs to several partitions
   u32 num_cus = 0;                            // compute units of the device (0: unknown); k_wide needs one per workgroup, all resident at once
   std::vector<u32> upart_eng, upart_size;     // caller's partition -> engine partition, its schedulable node count
+  std::vector<uint8_t> upart_refused;         // caller's partition -> cns_partition_status: != 0: its group is outside the engine's limits — its jobs get
+                                              // CNS_REASON_ENGINE_REFUSED, every other partition is served (cns_get_partition_status)
   std::vector<uint8_t> upart_tag;             // ... and its member tag inside that engine partition
   std::vector<std::vector<u32>> node_slots;   // node -> all its slots
   std::vector<uint8_t> slot_tag;              // slot -> member tag
@@ -630,6 +632,12 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
   auto find = [&](u32 x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
   std::vector<u32> first_part(N, kNone);
   bool shared = false;
+  // What lies outside the engine's limits refuses ONLY the partitions it touches — the group of partitions connected through shared
+  // nodes that lists the node (the reference bounds none of this: CpuSet is a std::set<uint32_t>, GRES maps are unbounded,
+  // PublicHeader.h:555-573,427-494): a node the caller flags as not expressible in this ABI's formats (cns_node_soa::unsupported:
+  // a core id >= 256, more GRES slots than the 64-bit mask holds), a node whose cpu count does not fit, the 65th distinct res_total
+  // record, a group wider than the widest tile.  Their jobs come back with CNS_REASON_ENGINE_REFUSED; the caller's CPU scheduler takes them.
+  std::vector<uint8_t> part_bad(P, 0);
   for (u32 p = 0; p < P; ++p) {
     if (nd->part_offsets[p + 1] < nd->part_offsets[p]) return fail(h, CNS_ERR_INVALID_ARG, "part_offsets not monotone");
     auto& lst = plist[p];
@@ -637,8 +645,12 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
       u32 n = nd->part_nodes[i];
       if (n >= N) return fail(h, CNS_ERR_INVALID_ARG, "part_nodes entry >= num_nodes");
       if (nd->schedulable && !nd->schedulable[n]) continue;  // JobScheduler.cpp:6595
-      if (total[n].cpu <= 0 || total[n].cpu >= 0x7FFFFFFEll)
-        return fail(h, CNS_ERR_UNSUPPORTED, "node cpu_total_raw must be in (0, 2^31-2)");
+      if ((nd->unsupported && nd->unsupported[n]) || total[n].cpu <= 0 || total[n].cpu >= 0x7FFFFFFEll) {
+        part_bad[p] = (nd->unsupported && nd->unsupported[n]) ? CNS_PART_REFUSED_NODE : CNS_PART_REFUSED_CPU;
+        if (first_part[n] == kNone) first_part[n] = p;   // (the partitions that share this node go with it)
+        else { u32 a = find(first_part[n]), b = find(p); if (a != b) uf[std::max(a, b)] = std::min(a, b); }
+        continue;
+      }
       lst.emplace_back(n, i);
     }
     std::sort(lst.begin(), lst.end());
@@ -665,6 +677,31 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
     }
   }
   const u32 PE = (u32)members.size();
+  // ---- refusals, group by group (in engine-partition order: which group gets the last free node type is deterministic) ----
+  std::vector<uint8_t> upart_refused(P, 0);
+  {
+    std::set<std::tuple<i64, u64, u64, u64, u64, u64, u64>> types;
+    for (u32 e = 0; e < PE; ++e) {
+      uint8_t why = 0;
+      for (u32 p : members[e]) if (part_bad[p] && !why) why = part_bad[p];
+      u32 npe = 0;
+      for (u32 p : members[e]) npe += (u32)plist[p].size();
+      const u32 cap = members[e].size() > 1 ? w8::WideInfo::mem_slots : std::max<u32>(kScan * (u32)CNS_NPL_MAX, w64::WideInfo::lanes * w64::WideInfo::npl_max);
+      if (!why && npe > cap) why = CNS_PART_REFUSED_WIDTH;
+      if (!why) {
+        auto mine = types;
+        for (u32 p : members[e])
+          for (auto& [n, pos] : plist[p]) mine.insert(std::make_tuple(total[n].cpu, total[n].mem, total[n].clo, total[n].chi, total[n].gres, total[n].c2, total[n].c3));
+        if (mine.size() > CNS_MAX_NODE_TYPES) why = CNS_PART_REFUSED_TYPES;
+        else types.swap(mine);
+      }
+      if (why)
+        for (u32 p : members[e]) { upart_refused[p] = why; plist[p].clear(); upart_size[p] = 0; }
+    }
+    bool any_served = false;
+    for (u32 p = 0; p < P; ++p) any_served = any_served || !upart_refused[p];
+    if (!any_served) return fail(h, CNS_ERR_UNSUPPORTED, "every partition of the snapshot is outside the engine's limits (a node flagged unsupported, a cpu count outside (0, 2^31-2), more than 64 distinct res_total records, or a group wider than the widest tile)");
+  }
   std::vector<u32> part_off(PE + 1, 0), slot_node, node_slot(N, kNone);
   std::vector<std::vector<u32>> node_slots(N);
   std::vector<uint8_t> slot_tag;
@@ -705,6 +742,7 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
                                               std::to_string(cap) + " schedulable (partition, node) slots");
   }
   h->Pu = P; h->shared = shared; h->upart_eng = upart_eng; h->upart_size = upart_size; h->upart_tag = upart_tag;
+  h->upart_refused = upart_refused;
   h->eng_members.clear();
   for (const auto& m : members) h->eng_members.push_back((u32)m.size());
   h->node_slots = node_slots; h->slot_tag = slot_tag;
@@ -903,6 +941,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
       p = h->P_real + rsv;
     } else {
       if (jb->partition[j] >= h->Pu) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
+      if (h->upart_refused[jb->partition[j]]) { reason[j] = CNS_REASON_ENGINE_REFUSED; continue; }   // (its group is outside the engine's limits: cns_get_partition_status)
       p = h->upart_eng[jb->partition[j]];   // the engine partition that runs the job's partition (its group, if it shares nodes)
     }
     part_of[j] = p;
@@ -1454,6 +1493,14 @@ int cns_select_preempt(cns_handle* h, int64_t now, const cns_job_soa* jobs, cons
     if (pout->num_preempting >= pout->preempting_capacity) return fail(h, CNS_ERR_INVALID_ARG, "cns_select_preempt: preempting_capacity too small");
     pout->preempting_job_ids[pout->num_preempting++] = id;
   }
+  return CNS_OK;
+}
+
+int cns_get_partition_status(const cns_handle* h, uint8_t* status, uint32_t capacity) {
+  if (!h || !status) return fail(const_cast<cns_handle*>(h), CNS_ERR_INVALID_ARG, "cns_get_partition_status: null argument");
+  if (!h->have_nodes) return fail(const_cast<cns_handle*>(h), CNS_ERR_STATE, "cns_get_partition_status before cns_set_nodes");
+  if (capacity < h->Pu) return fail(const_cast<cns_handle*>(h), CNS_ERR_INVALID_ARG, "cns_get_partition_status: capacity below the number of partitions");
+  for (u32 p = 0; p < h->Pu; ++p) status[p] = h->upart_refused[p];
   return CNS_OK;
 }
 

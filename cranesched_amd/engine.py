@@ -29,6 +29,7 @@ ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy",
                "cns_device_results", "cns_host_alloc", "cns_host_free", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
                "cns_debug_last_kernel", "cns_debug_get_prof",
                # several devices (csrc/group_host.inc)
+               "cns_get_partition_status",
                "cns_results_layout", "cns_comm_unique_id", "cns_comm_init_rank", "cns_comm_destroy", "cns_allgather_results",
                "cns_download_gathered", "cns_gather_timing", "cns_group_create", "cns_group_destroy", "cns_group_last_error",
                "cns_group_size", "cns_group_handle", "cns_group_set_nodes", "cns_group_set_reservations", "cns_group_set_running",
@@ -194,6 +195,13 @@ class GpuNodeSelector:
         c = cluster.to_c()
         self._check(self._L.cns_set_nodes(self._h, C.byref(c)))
         self._cluster = cluster
+
+    def partition_status(self) -> np.ndarray:
+        """[P] cns_partition_status of the snapshot: 0 served; else the partition's group lies outside the engine's limits (its jobs come
+        back with REASON_ENGINE_REFUSED and belong to the caller's CPU scheduler; every other partition is served)."""
+        out = np.zeros(max(self._cluster.num_partitions, 1), np.uint8)
+        self._check(self._L.cns_get_partition_status(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(len(out))))
+        return out[:self._cluster.num_partitions]
 
     def set_reservations(self, reservations: abi.Reservations | None):
         """Reservations of the cycle (JobScheduler.cpp:6619-6679): after set_nodes, before set_running."""

@@ -20,7 +20,9 @@
 namespace crane {
 
 namespace {
-const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", "", "Reservation Not Found", "Preempted"};
+// (8 = CNS_REASON_ENGINE_REFUSED: not a reason of the reference — the job's partition lies outside the engine's limits, nothing was decided
+// for it; RefusedJobs() lists exactly these jobs of the last cycle for the caller's CPU SchedulerAlgo)
+const char* kReasonStr[] = {"", "Priority", "Resource", "Resource Reserved", "Partition Not Found", "", "Reservation Not Found", "Preempted", "GpuEngineRefused"};
 
 // Page-locked storage (cns_host_alloc) for the arrays that cross the C ABI every cycle — the packed job table and the packed
 // placements: kept across cycles (no page faults on a fresh array, no reallocation once they have grown to the queue's size) and
@@ -92,6 +94,8 @@ struct GpuNodeSelectionAlgo::Impl {
   std::vector<int64_t> n_cpu, v_start, v_end, v_cpu;
   std::vector<uint64_t> n_mem, n_lo, n_hi, n_gres, v_mem, v_lo, v_hi, v_g, n_w2, n_w3, v_w2, v_w3;
   std::vector<uint8_t> n_sched;
+  std::vector<uint8_t> n_unsup;   // node -> it cannot be expressed in the ABI's formats (a core id >= 256, GRES slots / classes beyond the 64-bit
+                                  // mask): the engine refuses the partitions that list it (cns_node_soa::unsupported) and serves the others
   std::vector<uint32_t> n_poff, n_pnodes, v_off, v_node;
   int push_tables(std::string& err) {   // cns_set_nodes + cns_set_reservations from the packed arrays
     cns_node_soa nd{};
@@ -102,6 +106,7 @@ struct GpuNodeSelectionAlgo::Impl {
     nd.part_offsets = n_poff.data(); nd.part_nodes = n_pnodes.data();
     nd.gres = layout;
     nd.core_w2 = n_w2.data(); nd.core_w3 = n_w3.data();
+    nd.unsupported = n_unsup.empty() ? nullptr : n_unsup.data();
     int st = grp ? cns_group_set_nodes(grp, &nd) : cns_set_nodes(h, &nd);
     if (st != 0) { err = grp ? cns_group_last_error(grp) : cns_last_error(h); return st; }
     if (!v_start.empty()) {
@@ -290,7 +295,9 @@ struct GpuNodeSelectionAlgo::Impl {
     r.packed.node = it->second;
     r.packed.cpu = r.res.cpu_set.cpu_count.raw;
     r.packed.mem = r.res.memory_bytes;
-    r.packed.ovf = core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi, r.packed.w2, r.packed.w3);
+    // (an id >= 256 on a node the snapshot flags unsupported is no overflow of the cycle: that node's partitions are refused as a group,
+    // and the engine drops allocations on nodes it schedules for nobody)
+    r.packed.ovf = core_masks(r.res.cpu_set.core_ids, r.packed.lo, r.packed.hi, r.packed.w2, r.packed.w3) && !(r.packed.node < n_unsup.size() && n_unsup[r.packed.node]);
     if (r.packed.ovf) ++mirror_ovf;
     r.packed.g = gres_mask(r.res.gres);
   }
@@ -443,7 +450,7 @@ struct GpuNodeSelectionAlgo::Impl {
           a.node = it->second;
           a.cpu = res.cpu_set.cpu_count.raw;
           a.mem = res.memory_bytes;
-          a.ovf = core_masks(res.cpu_set.core_ids, a.lo, a.hi, a.w2, a.w3);
+          a.ovf = core_masks(res.cpu_set.core_ids, a.lo, a.hi, a.w2, a.w3) && !(a.node < n_unsup.size() && n_unsup[a.node]);
           a.g = gres_mask(res.gres);
           d.recs.push_back(a);
         }
@@ -492,6 +499,8 @@ struct GpuNodeSelectionAlgo::Impl {
   std::string snap_error;       // why the last snapshot was refused (kept for the NodeSelect calls that follow it)
   bool run_overflow = false;    // pack_running: some running job of the vector just packed (cached records included) holds one
   size_t mirror_ovf = 0;        // mirrored allocation records that hold one
+  size_t unsupported_nodes = 0; // nodes of the snapshot flagged cns_node_soa::unsupported
+  std::vector<const PdJobInScheduler*> refused;   // jobs of the last cycle the engine refused (CNS_REASON_ENGINE_REFUSED), in the cycle's order
   bool packed_from_mirror = false;
   static bool core_masks(const std::set<uint32_t>& ids, uint64_t& lo, uint64_t& hi, uint64_t& w2, uint64_t& w3) {   // true: an id >= 256
     lo = hi = w2 = w3 = 0;
@@ -808,12 +817,12 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
       for (const auto& [type, slots] : tm) cls[{name, type}].insert(slots.begin(), slots.end());
   memset(&I.layout, 0, sizeof I.layout);
   uint32_t shift = 0;
+  std::set<std::pair<std::string, std::string>> cls_out;   // (name, type) classes the 64-bit slot mask has no room for: the nodes that carry them are
+                                                            // flagged unsupported below — their partitions go to the CPU scheduler, the others stay here
   for (const auto& [key, slots] : cls) {
-    if (I.classes.size() >= CNS_MAX_GRES_CLASSES || shift + slots.size() > 64) {
-      status_ = CNS_ERR_UNSUPPORTED; error_ = "more GRES classes / slots than the 64-bit slot mask holds"; return;
-    }
+    if (I.classes.size() >= CNS_MAX_GRES_CLASSES || shift + slots.size() > 64 ||
+        (!I.name_id.count(key.first) && I.name_id.size() >= CNS_MAX_GRES_NAMES)) { cls_out.insert(key); continue; }
     if (!I.name_id.count(key.first)) {
-      if (I.name_id.size() >= CNS_MAX_GRES_NAMES) { status_ = CNS_ERR_UNSUPPORTED; error_ = "more than 4 GRES names"; return; }
       uint32_t id = (uint32_t)I.name_id.size();
       I.name_id[key.first] = id;
     }
@@ -836,6 +845,8 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   auto &sched = I.n_sched;
   cpu.assign(N, 0); mem.assign(N, 0); lo.assign(N, 0); hi.assign(N, 0); gres.assign(N, 0); sched.assign(N, 0);
   w2.assign(N, 0); w3.assign(N, 0);
+  I.n_unsup.assign(N, 0);
+  size_t n_unsupported = 0;
   for (uint32_t n = 0; n < N; ++n) {
     const CranedMeta& m = snap.craned_metas[n];
     I.node_name.push_back(m.craned_id);
@@ -843,10 +854,14 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
     I.node_idx[m.craned_id] = n;
     cpu[n] = m.res_total.cpu_set.cpu_count.raw;
     mem[n] = m.res_total.memory_bytes;
-    core_overflow |= I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n], w2[n], w3[n]);
+    bool out = I.core_masks(m.res_total.cpu_set.core_ids, lo[n], hi[n], w2[n], w3[n]);   // a core id >= 256
+    for (const auto& [name, tm] : m.res_total.gres)
+      for (const auto& [type, slots] : tm) out = out || (!slots.empty() && cls_out.count({name, type}) != 0);
     gres[n] = I.gres_mask(m.res_total.gres);
     sched[n] = m.alive && !m.drain;  // JobScheduler.cpp:6595
+    if (out) { I.n_unsup[n] = 1; ++n_unsupported; }
   }
+  I.unsupported_nodes = n_unsupported;
   auto &poff = I.n_poff, &pnodes = I.n_pnodes;
   poff.assign(1, 0); pnodes.clear();
   for (const auto& [pid, ids] : snap.partitions) {
@@ -884,7 +899,7 @@ void GpuNodeSelectionAlgo::SetClusterSnapshot(const ClusterSnapshot& snap) {
   I.snap_error.clear();
   if (core_overflow) {
     status_ = CNS_ERR_UNSUPPORTED;
-    error_ = I.snap_error = "a node or reservation lists a core id >= 256 (the engine keeps core ids in four 64-bit masks); keep the CPU SchedulerAlgo";
+    error_ = I.snap_error = "a reservation's share lists a core id >= 256 (the engine keeps core ids in four 64-bit masks); keep the CPU SchedulerAlgo";
     return;
   }
   if (!I.h) return;   // no device: the dictionaries above still serve PackRunningForBench
@@ -1121,6 +1136,8 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
     for (uint32_t i = 0; i < po.num_preempting; ++i) I.preempting.insert(po_set[i]);
   }
   I.last_ord.assign(ord.begin(), ord.end());
+  I.refused.clear();
+  for (size_t j = 0; j < J; ++j) if (out.reason[j] == CNS_REASON_ENGINE_REFUSED) I.refused.push_back(ord[j]);
   S.jobs = J;
   status_ = 0;
   error_.clear();
@@ -1136,6 +1153,18 @@ void GpuNodeSelectionAlgo::SelectPacked_(const TimeSec& now, const std::vector<s
 // ---------------------------------------------------------------------------------------------------------
 const std::vector<const PdJobInScheduler*>& GpuNodeSelectionAlgo::LastOrder() const { return impl_->last_ord; }
 const std::vector<job_id_t>& GpuNodeSelectionAlgo::LastPreemptCancel() const { return impl_->cancelled; }
+const std::vector<const PdJobInScheduler*>& GpuNodeSelectionAlgo::RefusedJobs() const { return impl_->refused; }
+size_t GpuNodeSelectionAlgo::UnsupportedNodes() const { return impl_->unsupported_nodes; }
+std::vector<PartitionId> GpuNodeSelectionAlgo::RefusedPartitions() const {
+  std::vector<PartitionId> out;
+  const Impl& I = *impl_;
+  if (!I.h || !I.have_snapshot || I.grp) return out;   // (several devices: ask the engines, cns_group_handle + cns_get_partition_status)
+  std::vector<uint8_t> st(I.part_idx.size() + 1, 0);
+  if (cns_get_partition_status(I.h, st.data(), (uint32_t)st.size()) != 0) return out;
+  for (const auto& [pid, idx] : I.part_idx) if (idx < st.size() && st[idx]) out.push_back(pid);
+  std::sort(out.begin(), out.end());
+  return out;
+}
 const std::set<job_id_t>& GpuNodeSelectionAlgo::PreemptingSet() const { return impl_->preempting; }
 
 size_t GpuNodeSelectionAlgo::EmitStartedResourcesWire(WireBatch* out) const {

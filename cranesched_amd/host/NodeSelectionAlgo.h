@@ -290,6 +290,14 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // every device runs its shard of the ordered queue on its own host thread, ONE all-gather (RCCL) merges the packed results
   // (include/crane_gpu/node_select.h, "several devices").  {d} is the one-device form.
   explicit GpuNodeSelectionAlgo(const std::vector<int>& devices, uint64_t scheduled_batch_size = 0);
+  // What lies outside the engine's limits (a node with a core id >= 256, GRES classes / slots beyond the 64-bit mask, the 65th distinct
+  // res_total record, a group of partitions wider than the widest tile — the reference bounds none of it, PublicHeader.h:555-573,427-494)
+  // refuses ONLY the group of partitions it touches: their jobs leave NodeSelect with reason "GpuEngineRefused" and nothing else set, every
+  // other partition is served.  RefusedJobs(): exactly those jobs of the last cycle, in its order — the caller's CPU SchedulerAlgo takes
+  // them.  RefusedPartitions(): which partitions of the snapshot, and UnsupportedNodes(): how many nodes caused it.
+  const std::vector<const PdJobInScheduler*>& RefusedJobs() const;
+  std::vector<PartitionId> RefusedPartitions() const;
+  size_t UnsupportedNodes() const;
   size_t NumDevices() const;
   bool LastGroupInfo(cns_group_info* out) const;   // false on one device
   ~GpuNodeSelectionAlgo() override;

@@ -574,6 +574,53 @@ int main(int argc, char** argv) {
     return e2e_bench(argc > 2 ? atoi(argv[2]) : 65536, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 1000000, argc > 5 && !strcmp(argv[5], "deferred"), argc > 6 ? atoi(argv[6]) : 1, dev);
   }
   if (argc > 2 && !strcmp(argv[1], "--license-file")) return license_file(argv[2]);
+  if (argc > 1 && !strcmp(argv[1], "--refusal-check")) {
+    // one node of partition P2 has a core id the engine cannot carry: P2's jobs come back "GpuEngineRefused" (RefusedJobs lists exactly them),
+    // the jobs of P0, P1, P3 are placed exactly as by an adapter whose snapshot has no such node (the partitions are independent)
+    GpuNodeSelectionAlgo algo(0), clean(0);
+    if (!algo.Ok()) { printf("engine: %s\n", algo.LastError().c_str()); return 2; }
+    ClusterSnapshot snap;
+    std::vector<std::vector<CranedId>> ids(4);
+    for (int i = 0; i < 64; ++i) {
+      char name[16];
+      snprintf(name, sizeof name, "cn%03d", i);
+      snap.craned_metas.push_back(node(name, 8, 32));
+      ids[i / 16].push_back(name);
+    }
+    for (int p = 0; p < 4; ++p) snap.partitions.push_back({"P" + std::to_string(p), ids[p]});
+    ClusterSnapshot snap_clean = snap;
+    snap.craned_metas[37].res_total.cpu_set.core_ids.insert(511);   // a 512-core machine in P2
+    algo.SetClusterSnapshot(snap); clean.SetClusterSnapshot(snap_clean);
+    CHECK(algo.Ok() && clean.Ok() && algo.UnsupportedNodes() == 1);
+    const auto rp = algo.RefusedPartitions();
+    CHECK(rp.size() == 1 && rp[0] == "P2" && clean.RefusedPartitions().empty());
+    std::vector<std::unique_ptr<RnJobInScheduler>> running;
+    std::vector<std::unique_ptr<PdJobInScheduler>> pa, pb;
+    for (int j = 0; j < 400; ++j) {
+      const std::string part = "P" + std::to_string((j * 7 + j / 5) % 4);
+      pa.push_back(job((job_id_t)(j + 1), 1 + j % 4, 600 * (1 + j % 5), part));
+      pb.push_back(job((job_id_t)(j + 1), 1 + j % 4, 600 * (1 + j % 5), part));
+    }
+    algo.SetFullWriteBack(true); clean.SetFullWriteBack(true);
+    algo.NodeSelect(1000, running, pa); clean.NodeSelect(1000, running, pb);
+    CHECK(algo.Ok() && clean.Ok());
+    size_t refused = 0, same = 0, other = 0;
+    for (int j = 0; j < 400; ++j) {
+      if (pa[j]->partition_id == "P2") {
+        refused += pa[j]->reason == "GpuEngineRefused" && pa[j]->craned_ids.empty() && pa[j]->start_time == 0;
+      } else {
+        ++other;
+        same += pa[j]->reason == pb[j]->reason && pa[j]->start_time == pb[j]->start_time && pa[j]->craned_ids == pb[j]->craned_ids &&
+                pa[j]->allocated_res.size() == pb[j]->allocated_res.size();
+      }
+    }
+    CHECK(refused == 400 - other && refused > 50 && same == other);
+    CHECK(algo.RefusedJobs().size() == refused && clean.RefusedJobs().empty());
+    for (const PdJobInScheduler* p : algo.RefusedJobs()) CHECK(p->partition_id == "P2");
+    printf("  %zu jobs of P2 refused (a 512-core node), %zu jobs of the other partitions placed as without it\n", refused, same);
+    printf("%s\n", g_fail ? "FAIL" : "ok");
+    return g_fail != 0;
+  }
   if (argc > 1 && !strcmp(argv[1], "--group-check"))
     return group_check(argc > 2 ? atoi(argv[2]) : 8192, argc > 3 ? atoi(argv[3]) : 8, argc > 4 ? atoi(argv[4]) : 60000, parse_devices(argc > 5 ? argv[5] : "0,0"));
   if (argc > 1 && !strcmp(argv[1], "--pack-bench")) return pack_bench(argc > 2 ? atoi(argv[2]) : 16384, argc > 3 ? atoi(argv[3]) : 100000);
@@ -595,9 +642,9 @@ int main(int argc, char** argv) {
     snap.craned_metas[1].res_total.cpu_set.core_ids.insert(130);   // a 192-core node: ids 128..255 are carried (ABI 3)
     algo.SetClusterSnapshot(snap);
     CHECK(algo.LastStatus() != -4 && algo.LastError().find("core id") == std::string::npos);
-    snap.craned_metas[1].res_total.cpu_set.core_ids.insert(300);   // beyond the four mask words: refused, not dropped
-    algo.SetClusterSnapshot(snap);
-    CHECK(algo.LastStatus() == -4 && algo.LastError().find("core id") != std::string::npos);
+    snap.craned_metas[1].res_total.cpu_set.core_ids.insert(300);   // beyond the four mask words: not dropped — the NODE is flagged, the engine
+    algo.SetClusterSnapshot(snap);                                  // then refuses the partitions that list it and serves the others (round 5)
+    CHECK(algo.UnsupportedNodes() == 1 && algo.LastError().find("core id") == std::string::npos);
     // ... and a RUNNING job that holds such an id refuses every cycle it is part of, not only the one that first packed it: the bit
     // lives with the cached / mirrored allocation record (the flag used to be cleared after one refused cycle, and the
     // next cycle served the cached record with the id silently dropped)

@@ -52,8 +52,10 @@
 extern "C" {
 #endif
 
-#define CNS_ABI_VERSION 3u /* 2: reservations (cns_resv_soa, `reservation` on running / pending jobs); 3: core ids 128..255
-                              (core_w2 / core_w3 planes appended to cns_node_soa, cns_running_soa, cns_resv_soa, cns_placement_soa) */
+#define CNS_ABI_VERSION 4u /* 2: reservations (cns_resv_soa, `reservation` on running / pending jobs); 3: core ids 128..255
+                              (core_w2 / core_w3 planes appended to cns_node_soa, cns_running_soa, cns_resv_soa, cns_placement_soa);
+                              4: refusals per group of partitions (cns_node_soa::unsupported appended, CNS_REASON_ENGINE_REFUSED,
+                              cns_get_partition_status) and several devices (cns_group_*, cns_comm_*) */
 #define CNS_MAX_GRES_CLASSES 8u
 #define CNS_MAX_GRES_NAMES 4u
 #define CNS_MAX_NODE_TYPES 64u /* distinct res_total records per cycle */
@@ -80,8 +82,23 @@ typedef enum cns_reason {
   CNS_REASON_RESOURCE_RESERVED = 3,  /* "Resource Reserved" (JobScheduler.cpp:6799-6806) */
   CNS_REASON_PARTITION_NOT_FOUND = 4,/* "Partition Not Found"                        */
   CNS_REASON_SKIPPED = 5,            /* caller pre-set a reason (e.g. "License")     */
-  CNS_REASON_RESERVATION_NOT_FOUND = 6 /* "Reservation Not Found" (JobScheduler.cpp:6756-6758) */
+  CNS_REASON_RESERVATION_NOT_FOUND = 6, /* "Reservation Not Found" (JobScheduler.cpp:6756-6758) */
+  /* 7: CNS_REASON_PREEMPTED, "Preempted" (include/crane_gpu/preempt.h) */
+  CNS_REASON_ENGINE_REFUSED = 8      /* NOT a reason of the reference: the job's partition (its group of partitions connected through
+                                        shared nodes) lies outside the engine's limits — nothing was decided for the job, the caller's
+                                        CPU SchedulerAlgo takes exactly these jobs (cns_get_partition_status says why) */
 } cns_reason;
+
+/* Why a partition is not served (cns_get_partition_status).  The reference bounds none of this (CpuSet is a std::set<uint32_t>, GRES
+ * maps are unbounded: PublicHeader.h:555-573,427-494); what the engine cannot hold refuses the GROUP of partitions that touches it and
+ * nothing else. */
+typedef enum cns_partition_status {
+  CNS_PART_SERVED = 0,
+  CNS_PART_REFUSED_NODE = 1,   /* it (or a partition it shares a node with) lists a schedulable node flagged cns_node_soa::unsupported */
+  CNS_PART_REFUSED_CPU = 2,    /* ... a schedulable node whose cpu_total_raw is outside (0, 2^31-2) */
+  CNS_PART_REFUSED_TYPES = 3,  /* its nodes would bring the snapshot's distinct res_total records above CNS_MAX_NODE_TYPES */
+  CNS_PART_REFUSED_WIDTH = 4   /* more schedulable (partition, node) slots than the widest tile holds */
+} cns_partition_status;
 
 /* Scheduler constants (JobScheduler.h:266-270, CtldPublicDefs.h:82-83). */
 typedef struct cns_config {
@@ -119,6 +136,9 @@ typedef struct cns_node_soa {
   const uint64_t* core_w2;        /* [num_nodes] core ids 128..191 (may be NULL = 0); CpuSet::core_ids is a set of
                                      uint32 ids without a bound, PublicHeader.h:555-573: 256 ids are what the engine carries */
   const uint64_t* core_w3;        /* [num_nodes] core ids 192..255 (may be NULL = 0) */
+  const uint8_t* unsupported;     /* [num_nodes] non-zero: the caller could not express this node in the arrays above (a core id >= 256,
+                                     more GRES slots / classes than the 64-bit mask holds): the partitions that list it — and those
+                                     connected to them through shared nodes — are refused, all others are served.  NULL = none */
 } cns_node_soa;
 
 /* Running jobs' per-node allocations (RnJobInScheduler, JobScheduler.h:57-90;
@@ -278,6 +298,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jobs);
 int cns_run_resident(cns_handle* h, int64_t now_sec);          /* init + select on device, synchronous */
 int cns_download(cns_handle* h, cns_placement_soa* out);
 /* Device pointer + byte size of the packed placement buffer of the last run (for RCCL allgather). */
+int cns_get_partition_status(const cns_handle* h, uint8_t* status /* [num_partitions] cns_partition_status */, uint32_t capacity);
 int cns_device_results(cns_handle* h, void** dptr, uint64_t* bytes);
 int cns_results_layout(const cns_handle* h, cns_results_offsets* out);   /* where the arrays sit in that buffer */
 /* one process per device: a communicator over the ranks' engines, and the all-gather of their packed results */

@@ -24,7 +24,7 @@ def test_header_symbols_exported(built):
         assert hasattr(lib, n), f"{n} declared in node_select.h but not exported"
     assert set(names) == set(engine.ABI_SYMBOLS), "engine.ABI_SYMBOLS out of sync with the header"
     from cranesched_amd import abi
-    assert lib.cns_abi_version() == abi.CNS_ABI_VERSION == 3
+    assert lib.cns_abi_version() == abi.CNS_ABI_VERSION == 4
     # every header under include/crane_gpu/: priority.h (MultiFactorPriority)
     pnames = header_functions("priority.h")
     assert set(pnames) == set(engine.PRIORITY_ABI_SYMBOLS)

@@ -76,3 +76,11 @@ def test_one_algorithm_object_over_several_devices_on_gpu(built, devices):
 def test_whole_cycle_through_the_adapter_on_two_engines(built):
     r = subprocess.run([EXE, "--e2e-bench", "4096", "8", "40000", "lazy", "2", "--devices", "0,0"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_a_node_beyond_the_limits_refuses_only_its_partition_through_the_adapter(built):
+    """a 512-core node in one of four partitions: its jobs leave NodeSelect as "GpuEngineRefused" (RefusedJobs / RefusedPartitions name them
+    for the caller's CPU scheduler), the other partitions' jobs are placed exactly as without that node"""
+    r = subprocess.run([EXE, "--refusal-check"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
