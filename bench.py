@@ -236,6 +236,22 @@ def main():
             pass
         got = eng.download()
         kernel = eng.last_kernel()
+        # SURVEY 8(d) prices a configuration with time slots (C5: T = 256, Q = 675 s) at N_p * (16 * W + 8) + S_job + S_out bytes per decision,
+        # W = ceil(L / Q) slots in the job's window; the engine's own count (cns_timing::algorithmic_bytes) is the T = 1 form N_p * S_node.
+        # The line carries the SURVEY's figure for such a configuration; a fraction above 1 is the reuse the survey announces
+        # (the window minimum is read from a register tile / one node block, not from W slot records per node).
+        algo_bytes, bytes_model = tm["algorithmic_bytes"], "N_p * S_node + 64 + 16 + 24 * k per decision, S_node = 32 (cpu + mem) or 48 (+ GRES / > 64 cores) (SURVEY 8d)"
+        if base_cfg == "C5" and world == 1:
+            Q = synth.CONFIGS["C5"]["Q"]
+            W = (jobs.time_limit_sec.astype(np.int64) + Q - 1) // Q
+            npn = np.diff(cluster.part_offsets.astype(np.int64))[jobs.partition.astype(np.int64)]
+            algo_bytes = int((npn * (16 * W + 8) + 64 + 16 + 24 * jobs.node_num.astype(np.int64)).sum())
+            bytes_model = f"N_p * (16 * W + 8) + 64 + 16 + 24 * k per decision, W = ceil(L / {Q} s) (mean {float(W.mean()):.2f}) (SURVEY 8d, T > 1); the engine's T = 1 count is {tm['algorithmic_bytes']}"
+            achieved = algo_bytes / (avg_sel_ms * 1e-3) / 1e9
+        # the chain: a partition's decisions are strictly sequential (JobScheduler.cpp:6743 ff.), partitions run side by side — the time per
+        # decision ON the busiest partition's chain is what the kernel's latency-bound pipeline delivers, whatever the byte model says
+        per_part = np.bincount(my_jobs.partition[my_jobs.partition < my_cluster.num_partitions].astype(np.int64), minlength=my_cluster.num_partitions)
+        chain_us = 1e3 * avg_sel_ms / max(int(per_part.max()), 1)
         # SURVEY.md 8(d) bracket (the reference's own, JobScheduler.cpp:1439-1447): the whole cns_select call from host
         # buffers — H2D of the job arrays, record packing, the kernels, D2H of the placements.  Median of 5 after the
         # warm-up above; reported beside `value` (which, per the bench contract, starts with the inputs resident in HBM).
@@ -291,7 +307,13 @@ def main():
                        "h2d_job_table_ms": h2d_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_prof,
-                         "kernel": kernel, "algorithmic_bytes_per_launch": tm["algorithmic_bytes"],
+                         # what the kernel really moves: the counter bytes of the committed PMC passes / this run's launch time / peak — the
+                         # honest utilisation next to the model fraction above (the kernel is a latency-bound sequential chain, not a streaming one)
+                         "hbm_util": (traffic_prof["bytes_per_launch"] / (avg_sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_prof else None,
+                         "chain_us_per_decision": chain_us,
+                         "chain_note": f"{int(per_part.max())} decisions on the busiest partition's chain, strictly one after the other; {my_cluster.num_partitions} chains side by side",
+                         "kernel": kernel, "algorithmic_bytes_per_launch": algo_bytes, "bytes_model": bytes_model,
+                         "reuse_factor": (achieved / HBM_PEAK_GBS) if achieved > HBM_PEAK_GBS else None,
                          "avg_launch_ms": avg_sel_ms,
                          "note": "algorithmic bytes = sum over decisions of N_p*48 + 64 + 16 + 24*k (SURVEY 8d); the node "
                                  "tile is register-resident, so HBM traffic is ~1 % of this: the kernel is bound by the latency "

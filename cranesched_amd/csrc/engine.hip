@@ -433,7 +433,7 @@ int finalize_layout(cns_engine* h, const std::vector<Res>* virt_total = nullptr)
     for (u32 q = h->part_off[h->P_real + v]; q < h->part_off[h->P_real + v + 1]; ++q) h->slot_end[q] = h->resv_end[v];
   // (per partition / group: checked in cns_set_nodes — a partition that shares no node may be as wide as k_wide's widest tile)
   if (h->max_np > std::max<u32>(w8::WideInfo::mem_slots, w64::WideInfo::lanes * w64::WideInfo::npl_max))
-    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(w64::WideInfo::lanes * w64::WideInfo::npl_max) + " schedulable nodes");
+    return fail(h, CNS_ERR_UNSUPPORTED, "partition with more than " + std::to_string(std::max<u32>(w8::WideInfo::mem_slots, w64::WideInfo::lanes * w64::WideInfo::npl_max)) + " schedulable (partition, node) slots");
   std::map<std::tuple<i64, u64, u64, u64, u64, u64, u64>, u32> tmap;
   std::vector<Res> type_total;
   std::vector<uint8_t> slot_type(std::max<u32>(S, 1), 0);
@@ -1121,7 +1121,7 @@ static int run_resident_once(cns_handle* h, int64_t now, u32* fault_code) {
     }
     const u32 held = (u32)pc.size();   // home workgroups of k_mem that hold a CU while the other launches run
     if (pa.empty() && pb.empty()) {
-      h->last_kernel = name_c;
+      h->last_kernel = pc.empty() ? std::string("none (no pending job reaches an ordered loop)") : name_c;   // (never empty: callers parse it)
     } else if (pb.empty() || pa.empty()) {
       // one launch: over all partitions (identity map) when every one is busy, else over the busy ones (part_map)
       const bool plain = pb.empty();

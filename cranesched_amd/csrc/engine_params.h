@@ -203,7 +203,8 @@ struct KParams {
   // ---- the serial-only mode of k_wide (wide groups of partitions that share nodes): compact per-slot map length, kept by
   // k_init_nodes and commit_selection (the only commit path of that mode), and the slot range of every member partition of a
   // group — a job only ever looks at the slots of its own partition: [tag_off[tag_base[part] + tag], ... + 1) relative to the group
-  u32* f_len;              // [S]
+  u32* f_len;              // [S] VALID ONLY for the groups of the serial-only mode: k_init_nodes and commit_selection keep it exact there; the inline
+                           // and parallel commits of k_select update sibling slots only (nobody reads it outside that mode)
   const u32* tag_off;
   const u32* tag_base;     // [P_real]
   PreParams pre;

@@ -28,6 +28,16 @@ def built():
     return g
 
 
+@pytest.fixture
+def gpu(built):
+    """For GPU tests that build their engine themselves: skips on a machine without a GPU instead of failing with CNS_ERR_NO_DEVICE
+    when the whole directory is run without `-m "not gpu"`."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return built
+
+
 @pytest.fixture(params=["legacy", "pipe", "wide", "wide32"])
 def engine_cls(built, request, monkeypatch):
     """The engine class, once per selection kernel: k_select (one worker wave carries test + commit), k_pipe

@@ -87,7 +87,7 @@ def test_shared_nodes_with_reservations_on_gpu(engine_cls):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,lay,J", [(1, "all+subsets", 6000), (2, "random", 6000), (3, "all+subsets", 20000)])
-def test_shared_group_wider_than_k_select_s_register_tile_on_gpu(built, seed, lay, J):
+def test_shared_group_wider_than_k_select_s_register_tile_on_gpu(gpu, seed, lay, J):
     """An "ALL" partition over a cluster of 12 000 nodes next to subsets of it: one group of ~19 000 - 22 000 (partition, node)
     slots, more than k_select's tile holds (16 576).  It runs on k_wide's home workgroup alone (KParams::serial_only: the
     sequential protocol with the tester waves as memory scanners) — round 3 refused it.  Bit-exact vs the oracle incl. every
@@ -109,7 +109,7 @@ def test_shared_group_wider_than_k_select_s_register_tile_on_gpu(built, seed, la
 
 
 @pytest.mark.gpu
-def test_one_cycle_on_three_kernels_wide_group_small_group_plain_partition(built):
+def test_one_cycle_on_three_kernels_wide_group_small_group_plain_partition(gpu):
     """One snapshot, one cycle: a group too wide for k_select (ALL over 12 000 nodes + two subsets -> k_mem), a small group (two
     partitions sharing 1 000 nodes -> k_select) and a plain partition (-> k_wide), launched side by side; every result against
     the oracle."""

@@ -208,7 +208,7 @@ def compare_engine(tag, c, j, ref, eng, pl, po):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("scn", kat_preempt.scenarios(), ids=lambda s: s[0])
-def test_engine_preempt_known_answers(built, scn):
+def test_engine_preempt_known_answers(gpu, scn):
     from oracle import pyoracle
     name, c, j, r, pre, expect = scn
     ref = pyoracle.select(c, j, kat_preempt.NOW, running=r, preempt=pre)
@@ -223,7 +223,7 @@ def test_engine_preempt_known_answers(built, scn):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(40))
-def test_engine_preempt_random_cases(built, seed):
+def test_engine_preempt_random_cases(gpu, seed):
     from oracle import pyoracle
     c, j, now, run, pre = random_preempt_case(500 + seed, N=6 + seed % 7, J=50 + seed % 40, P=1 + seed % 2, running=10 + seed % 11)
     ref = pyoracle.select(c, j, now, running=run, preempt=pre)
@@ -236,7 +236,7 @@ def test_engine_preempt_random_cases(built, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(0, 40, 3))
-def test_engine_preempt_on_the_node_for_node_trees(built, seed, monkeypatch):
+def test_engine_preempt_on_the_node_for_node_trees(gpu, seed, monkeypatch):
     """TryPreempt_'s trees run in a compressed form on the device (tests/seg_compact.py); a call that needs more records than fit
     is redone node for node.  CNS_PREEMPT_TREE=literal sends every call down that path, =tiny leaves the compressed form room for
     a handful of records, so that calls run out of them half way and start again."""
@@ -256,7 +256,7 @@ def test_engine_preempt_on_the_node_for_node_trees(built, seed, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(6))
-def test_engine_preempt_larger_cases(built, seed):
+def test_engine_preempt_larger_cases(gpu, seed):
     """More nodes, multi-partition, many running jobs: long candidate lists, deep trees, several releases per job."""
     from oracle import pyoracle
     c, j, now, run, pre = random_preempt_case(900 + seed, N=48 + 8 * seed, J=500, P=2, running=120)
@@ -271,7 +271,7 @@ def test_engine_preempt_larger_cases(built, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(4))
-def test_engine_preempt_on_nodes_with_192_and_256_cores(built, seed):
+def test_engine_preempt_on_nodes_with_192_and_256_cores(gpu, seed):
     """Preemption (releases, the segment trees' Res records, the placement records read back at a release) with core ids 128..255."""
     from oracle import pyoracle
     from tests import helpers
@@ -290,7 +290,7 @@ def test_engine_preempt_on_nodes_with_192_and_256_cores(built, seed):
 
 
 @pytest.mark.gpu
-def test_engine_preempt_disabled_is_the_plain_cycle(built):
+def test_engine_preempt_disabled_is_the_plain_cycle(gpu):
     from oracle import pyoracle
     c, j, now, run, pre = random_preempt_case(777, N=12, J=80, P=1, running=16)
     pre.enabled = False
@@ -330,7 +330,7 @@ def test_oracle_preempt_with_reservations_lit_vs_mask(built, seed):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(12))
-def test_engine_preempt_with_reservations(built, seed):
+def test_engine_preempt_with_reservations(gpu, seed):
     from oracle import pyoracle
     c, j, now, run, rv, pre = resv_preempt_case(seed)
     ref = pyoracle.select(c, j, now, running=run, reservations=rv, preempt=pre)
@@ -350,7 +350,7 @@ def test_engine_preempt_with_reservations(built, seed):
 
 
 @pytest.mark.gpu
-def test_engine_preempt_enabled_without_lists_runs_the_fast_kernels(built):
+def test_engine_preempt_enabled_without_lists_runs_the_fast_kernels(gpu):
     """PreemptType == QOS but no pending job's qos may preempt anything: TryPreempt_ returns at :6385 every time, the cycle
     is the plain one except for the preempting set (jobs in it end at now + 1) — and it runs on k_wide / k_pipe."""
     from oracle import pyoracle
@@ -412,7 +412,7 @@ def test_python_restatement_on_preemption_with_shared_nodes(built, seed, lay):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,lay", OVERLAP_CASES + [(s, lay) for s in (20, 21) for lay in ("all+subsets", "chain", "random")])
-def test_engine_preempt_with_shared_nodes(built, seed, lay):
+def test_engine_preempt_with_shared_nodes(gpu, seed, lay):
     from oracle import pyoracle
     big = seed >= 20
     c, j, now, run, pre = overlap_preempt_case(seed, N=64 if big else 24, J=500 if big else 120, layout=lay)
@@ -435,7 +435,7 @@ def test_python_restatement_on_preemption_with_reservations(built, seed):
 
 
 @pytest.mark.gpu
-def test_engine_split_preempt_cycle_survives_a_k_wide_retry(built, monkeypatch):
+def test_engine_split_preempt_cycle_survives_a_k_wide_retry(gpu, monkeypatch):
     """A cycle with preemption is split: partitions whose pending jobs may preempt run on k_select, the rest on k_wide.  A
     k_wide protocol fault re-runs the WHOLE cycle — k_select's partitions too — so the mutable preemption state (per-slot job
     lists, hidden candidates, the preempted-pair counter) must start every pass empty, not every call (a second
