@@ -210,6 +210,10 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.wide_window = CNS_WIDE_WINDOW_DEFAULT < w64::kWJ ? CNS_WIDE_WINDOW_DEFAULT : w64::kWJ;
   if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWJ ? v : w64::kWJ; }
   if (K.wide_inject_stall) K.wide_window = 0;
+  K.wide_tester_opt = 1;
+  if (const char* to = getenv("CNS_WIDE_TESTER_OPT")) K.wide_tester_opt = (u32)strtoul(to, nullptr, 10);
+  K.wide_batch_post = 1;
+  if (const char* bp = getenv("CNS_WIDE_BATCH_POST")) K.wide_batch_post = (u32)strtoul(bp, nullptr, 10);
   K.part_off = h->d_part_off.as<u32>();
   K.slot_node = h->d_slot_node.as<u32>();
   K.slot_total = h->d_slot_total.as<Res>();

@@ -146,7 +146,10 @@ struct KParams {
   const Res* rv_res;
   i64* first_resv;         // [S]   earliest start of a non-expired reservation on the node (INF: none), :6635-6642
   const i64* resv_se;      // [2V]  start, end of reservation v (virtual partition num_real_parts + v)
-  u32 num_real_parts, pad_resv;
+  u32 num_real_parts;
+  u32 wide_tester_opt;     // k_wide's testers overlap the record fetch with the node-block load and commit a task that is next to retire straight from
+                           // the registers of its test (on unless CNS_WIDE_TESTER_OPT=0: A/B runs)
+  u32 wide_batch_post;     // k_wide's supervisor posts a run of one-node decisions in one pass (on unless CNS_WIDE_BATCH_POST=0: A/B runs)
   const Res* type_total;   // [T]   distinct res_total records
   char* blocks;            // [S]   one NodeBlock per partition slot: NodeHdr + tl_cap TlEntry
   u64 block_stride;        //       bytes per NodeBlock

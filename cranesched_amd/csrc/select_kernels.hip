@@ -1433,9 +1433,11 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
 // those clusters run the code they ran before ABI 3 (the 4-word Res cost the testers of C4 +26 % per test otherwise).
 template <bool kW> __device__ __forceinline__ Res narrow(Res r) { if (!kW) { r.c2 = 0; r.c3 = 0; } return r; }
 // Loads the node block of slot q the way the fast paths want it: header scalarised, lane i <- entry i.
-template <bool kW = true>
+// kDrain = false: the caller has drained this wave's stores itself and has OTHER loads in flight that the block's loads may overlap
+// (k_wide's tester: the job record) — the initial s_waitcnt vmcnt(0) would serialise the two round trips.
+template <bool kW = true, bool kDrain = true>
 __device__ __forceinline__ void load_block(const KParams& P, u32 q, u32 lane, NodeHdr*& hd, NodeHdr& h, TlEntry& e) {
-  drain_stores();
+  if (kDrain) drain_stores();
   hd = hdr_of(P, q);
   if (kW) {
     h = *hd;
