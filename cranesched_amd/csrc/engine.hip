@@ -201,11 +201,12 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.now = now;
   K.max_window = h->cfg.max_time_window_sec;
   if (const char* inj = getenv("CNS_WIDE_INJECT_STALL")) K.wide_inject_stall = (u32)strtoul(inj, nullptr, 10) + 1u;
-  // jobs per pool exchange of k_wide's 64-wave build at most (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE"); 0 / 1: off.  Off by default
-  // (-DCNS_WIDE_WINDOW_DEFAULT=16 turns it on): bit-exact and 1.8x shorter on the scanners' chain, but the home workgroup — the supervisor's
-  // 2 500 cycles per task, testers 76 % busy — then paces the pipeline: C5 -9 %, C4 +4 %, C2 +6 % (profiles/r05_pool_windows_ab.txt)
+  // jobs per pool exchange of k_wide's 64-wave build at most (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE"); 0 / 1: one job per exchange, as in
+  // rounds 2-4.  On by default: bit-exact on every digest, 2 000 instead of 3 560 cycles per job on the scanners' chain — and since the
+  // home workgroup (seven testers at ~20 000 cycles per task) then paces the pipeline, what reaches the cycle time is C5 -9.5 %, C2 / c5deep /
+  // C4 / C4r unchanged (windows back off where they do not fill: profiles/r05_pool_windows_ab.txt, r05_ab_pool_size_and_window_length.txt)
 #ifndef CNS_WIDE_WINDOW_DEFAULT
-#define CNS_WIDE_WINDOW_DEFAULT 0
+#define CNS_WIDE_WINDOW_DEFAULT 16
 #endif
   K.wide_window = CNS_WIDE_WINDOW_DEFAULT < w64::kWJ ? CNS_WIDE_WINDOW_DEFAULT : w64::kWJ;
   if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWJ ? v : w64::kWJ; }
