@@ -202,11 +202,13 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.max_window = h->cfg.max_time_window_sec;
   if (const char* inj = getenv("CNS_WIDE_INJECT_STALL")) K.wide_inject_stall = (u32)strtoul(inj, nullptr, 10) + 1u;
   // jobs per pool exchange of k_wide's 64-wave build at most (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE"); 0 / 1: one job per exchange, as in
-  // rounds 2-4.  On by default: bit-exact on every digest, 2 000 instead of 3 560 cycles per job on the scanners' chain — and since the
-  // home workgroup (seven testers at ~20 000 cycles per task) then paces the pipeline, what reaches the cycle time is C5 -9.5 %, C2 / c5deep /
-  // C4 / C4r unchanged (windows back off where they do not fill: profiles/r05_pool_windows_ab.txt, r05_ab_pool_size_and_window_length.txt)
+  // rounds 2-4 — and the kernel WITHOUT the window path is launched (k_wide<NPL, false>).  Off by default: bit-exact on every digest and
+  // 2 000 instead of 3 560 cycles per job on the scanners' chain, but the home workgroup (seven testers at ~20 000 cycles per task) then paces the
+  // pipeline: C5 184 against 188.5 ms, C4 280 against 258 (few windows open on its mix of GRES backfills and multi-node jobs, and the
+  // windowed kernel's single-job loops are ~8 % slower): profiles/r05_ab_window_code_presence.txt.  CNS_WIDE_WINDOW=16 (or
+  // -DCNS_WIDE_WINDOW_DEFAULT=16) turns it on.
 #ifndef CNS_WIDE_WINDOW_DEFAULT
-#define CNS_WIDE_WINDOW_DEFAULT 16
+#define CNS_WIDE_WINDOW_DEFAULT 0
 #endif
   K.wide_window = CNS_WIDE_WINDOW_DEFAULT < w64::kWJ ? CNS_WIDE_WINDOW_DEFAULT : w64::kWJ;
   if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWJ ? v : w64::kWJ; }
@@ -294,7 +296,7 @@ template <class W>
 int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string* name) {
   const u32 np = L.max_np;
   const char* kname = "";
-  const void* fn = W::pick(np, &kname);
+  const void* fn = W::pick(np, &kname, K.wide_window >= 2u);
   if (!fn) return 2;
   const unsigned groups = (L.nparts + 7u) / 8u;
   const unsigned grid = 8u * groups * W::group;
@@ -334,7 +336,7 @@ int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string
 // no workgroup waits for another one, so no co-residency is needed.  Slow — every job reads every slot of its group — and exact.
 int launch_mem(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string* name) {
   using W = w8::WideInfo;
-  const void* fn = (const void*)w8::k_wide<1>;
+  const void* fn = (const void*)w8::k_wide<1, false>;
   const unsigned groups = (L.nparts + 7u) / 8u;
   const unsigned grid = 8u * groups * W::group;
   const size_t need = (size_t)h->P * W::ctl_bytes;

@@ -66,6 +66,9 @@ def lib():
         L.cns_destroy.argtypes = [C.c_void_p]
         L.cns_debug_last_kernel.restype = C.c_char_p
         L.cns_debug_last_kernel.argtypes = [C.c_void_p]
+        if not hasattr(L, "cns_group_create"):   # (an older build of the engine, loaded through CNS_ENGINE_LIB for an A/B run: tools/var_bench.py)
+            _LIB = L
+            return _LIB
         L.cns_group_last_error.restype = C.c_char_p
         L.cns_group_last_error.argtypes = [C.c_void_p]
         L.cns_group_destroy.restype = None

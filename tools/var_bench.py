@@ -5,7 +5,9 @@ import hashlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
-from cranesched_amd import synth
+from cranesched_amd import abi, synth
+if os.environ.get("CNS_VAR_ABI"):   # an older build of the engine (its cns_create checks the version; the structs only grew at the end)
+    abi.CNS_ABI_VERSION = int(os.environ["CNS_VAR_ABI"])
 from cranesched_amd.engine import GpuNodeSelector
 
 tag = os.path.basename(os.environ.get("CNS_ENGINE_LIB", "default"))
