@@ -42,7 +42,7 @@ STATUS_STR = {0: "CNS_OK", -1: "CNS_ERR_INVALID_ARG", -2: "CNS_ERR_NO_DEVICE", -
 class CnsConfig(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32),
                 ("scheduled_batch_size", C.c_uint64), ("max_job_num_per_node", C.c_uint32),
-                ("reserved0", C.c_uint32), ("max_time_window_sec", C.c_int64)]
+                ("kernel_pin", C.c_uint32), ("max_time_window_sec", C.c_int64)]
 
 
 class CnsGresLayout(C.Structure):

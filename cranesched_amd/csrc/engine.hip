@@ -380,6 +380,7 @@ u32 use_wide_kernel(const cns_engine* h, const LaunchCtx& L) {
   if (e && !strcmp(e, "wide16")) cap = 16;
   if (e && !strcmp(e, "wide8")) cap = 8;
   if (e && (!strcmp(e, "wide") || cap != 64)) want = true;
+  if (!e && h->cfg.kernel_pin != CNS_KERNEL_AUTO) want = false;   // (cns_config::kernel_pin: a controller that shares its GPU; the environment variable, an A/B and test switch, wins)
   if (!want || h->wide_off) return 0;
   // every workgroup of the launch must be resident at once, one per CU (a partitioned or smaller device falls to k_pipe)
   const u32 groups = (L.nparts + 7u) / 8u;
@@ -396,6 +397,7 @@ bool use_pipe_kernel(const cns_engine* h, const LaunchCtx& L) {
   bool want = CNS_DEFAULT_PIPE != 0;
   if (e && !strcmp(e, "legacy")) want = false;
   if (e && (!strcmp(e, "pipe") || !strncmp(e, "wide", 4))) want = true;
+  if (!e && h->cfg.kernel_pin == CNS_KERNEL_SELECT) want = false;
   return want && L.max_np <= kPScan * (u32)kPNplMax;
 }
 // One launch: k_wide / k_pipe where the partitions allow it (`plain`: none of them shares nodes or runs with preemption), else

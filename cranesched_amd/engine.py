@@ -87,10 +87,12 @@ class GpuNodeSelector:
     """One engine handle on one MI355X (one process per GPU)."""
 
     def __init__(self, device: int = 0, scheduled_batch_size: int = 0, max_job_num_per_node: int = 0,
-                 max_time_window_sec: int = 0):
+                 max_time_window_sec: int = 0, kernel_pin: int = 0):
+        """kernel_pin: cns_kernel_pin — 0 the engine chooses per launch; 1 k_select, 2 k_pipe (one workgroup per partition: for a controller
+        that shares its GPU with other processes, since k_wide's workgroups must all be resident at once)."""
         self._L = lib()
         self._h = C.c_void_p()
-        cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, device, scheduled_batch_size, max_job_num_per_node, 0,
+        cfg = abi.CnsConfig(abi.CNS_ABI_VERSION, device, scheduled_batch_size, max_job_num_per_node, kernel_pin,
                             max_time_window_sec)
         rc = self._L.cns_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:

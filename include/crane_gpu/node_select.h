@@ -106,9 +106,15 @@ typedef struct cns_config {
   int32_t device;                 /* HIP device ordinal                               */
   uint64_t scheduled_batch_size;  /* g_config.ScheduledBatchSize; 0 = unlimited       */
   uint32_t max_job_num_per_node;  /* kAlgoMaxJobNumPerNode; 0 -> 1000                 */
-  uint32_t reserved0;
+  uint32_t kernel_pin;            /* cns_kernel_pin: 0 = the engine chooses per launch (k_wide where every workgroup of the launch is
+                                     resident at once, else k_pipe / k_select).  k_wide's workgroups spin on each other: it wants the GPU to
+                                     itself — a second process on the device turns it into the bounded-wait + retry path — so a
+                                     controller that SHARES its GPU pins CNS_KERNEL_PIPE                            */
   int64_t max_time_window_sec;    /* kAlgoMaxTimeWindow; 0 -> 7*24*3600               */
 } cns_config;
+
+typedef enum cns_kernel_pin { CNS_KERNEL_AUTO = 0, CNS_KERNEL_SELECT = 1 /* one workgroup per partition, one wave carries test + commit */,
+                               CNS_KERNEL_PIPE = 2 /* one workgroup per partition, decoupled test / commit */ } cns_kernel_pin;
 
 /* (name,type) -> slot-bit layout of the 64-bit GRES mask; fixed per handle cycle. */
 typedef struct cns_gres_layout {

@@ -190,3 +190,24 @@ def test_page_locked_caller_buffers(built, monkeypatch):
             eng.free_pinned(pj3.partition)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pin,expect", [(0, "k_wide"), (2, "k_pipe"), (1, "k_select")])
+def test_kernel_pin_of_the_config(gpu, monkeypatch, pin, expect):
+    """cns_config::kernel_pin: a controller that shares its GPU keeps the engine off k_wide (whose workgroups must all be resident at once);
+    the placements are the same under every pin"""
+    monkeypatch.delenv("CNS_SELECT_KERNEL", raising=False)
+    from cranesched_amd import synth
+    from cranesched_amd.engine import GpuNodeSelector
+    from oracle import pyoracle
+    c, j, now = synth.make_config("C4", J=20000, N=2048, P=8)
+    ref = pyoracle.select(c, j, now)
+    eng = GpuNodeSelector(device=0, kernel_pin=pin)
+    try:
+        eng.set_nodes(c)
+        got = eng.node_select(now, j)
+        assert eng.last_kernel().startswith(expect), eng.last_kernel()
+        assert got.diff(ref.placements) is None
+    finally:
+        eng.close()
