@@ -103,6 +103,7 @@ struct cns_engine {
   DevBuf d_raw[16];  // the caller's job arrays as uploaded (k_pack_jobs reads them; d_raw[14] = place offsets)
   // job table
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
+  u64 window_shaped = 0;   // jobs of the uploaded queue that a window of k_wide can decide: one node, one task per node, no GRES, no node lists, not exclusive
   std::vector<u64> place_off;
   struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, c2, c3, total; } ro{};
   bool wide_cores = false;   // a node of the snapshot has a core id above 127: the results carry the core_w2 / core_w3 planes
@@ -202,15 +203,12 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   K.max_window = h->cfg.max_time_window_sec;
   if (const char* inj = getenv("CNS_WIDE_INJECT_STALL")) K.wide_inject_stall = (u32)strtoul(inj, nullptr, 10) + 1u;
   // jobs per pool exchange of k_wide's 64-wave build at most (wide_kernel.inc, "A WINDOW OF JOBS PER EXCHANGE"); 0 / 1: one job per exchange, as in
-  // rounds 2-4 — and the kernel WITHOUT the window path is launched (k_wide<NPL, false>).  Off by default: bit-exact on every digest and
-  // 2 000 instead of 3 560 cycles per job on the scanners' chain, but the home workgroup (seven testers at ~20 000 cycles per task) then paces the
-  // pipeline: C5 184 against 188.5 ms, C4 280 against 258 (few windows open on its mix of GRES backfills and multi-node jobs, and the
-  // windowed kernel's single-job loops are ~8 % slower): profiles/r05_ab_window_code_presence.txt.  CNS_WIDE_WINDOW=16 (or
-  // -DCNS_WIDE_WINDOW_DEFAULT=16) turns it on.
-#ifndef CNS_WIDE_WINDOW_DEFAULT
-#define CNS_WIDE_WINDOW_DEFAULT 0
-#endif
-  K.wide_window = CNS_WIDE_WINDOW_DEFAULT < w64::kWJ ? CNS_WIDE_WINDOW_DEFAULT : w64::kWJ;
+  // rounds 2-4 — and the kernel WITHOUT the window path is launched (k_wide<NPL, false>: the path's presence costs the single-job loops 8 %).
+  // Unless CNS_WIDE_WINDOW says otherwise the QUEUE decides: windows for a queue that is (almost) all one-node jobs without GRES and node lists
+  // (>= 95 %: C5 190 -> 185 ms, C2 / c5deep unchanged — where most jobs are backfilled the windows back off), none for a mix like C4's,
+  // whose GRES backfills and multi-node jobs would close every window after two or three jobs (258 against 273 ms):
+  // profiles/r05_ab_window_code_presence.txt, DESIGN.md 5.8.
+  K.wide_window = (h->jobs_ordered != 0 && h->window_shaped * 100 >= h->jobs_ordered * 95) ? w64::kWJ : 0u;
   if (const char* ww = getenv("CNS_WIDE_WINDOW")) { const u32 v = (u32)strtoul(ww, nullptr, 10); K.wide_window = v < w64::kWJ ? v : w64::kWJ; }
   if (K.wide_inject_stall) K.wide_window = 0;
   K.wide_tester_opt = 1;
@@ -929,7 +927,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   h->job_part.assign((size_t)J, kNone);
   std::vector<u32> part_of(std::max<u64>(J, 1), 0);  // (virtual) partition of every job that reaches the ordered loop
   h->place_off.assign(J + 1, 0);
-  u64 places = 0, algo = 0;
+  u64 places = 0, algo = 0, n_shaped = 0;
   const u64 s_node = h->big_nodes ? 48 : 32;
   for (u64 j = 0; j < J; ++j) {
     h->place_off[j] = places;
@@ -956,6 +954,15 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
     part_of[j] = p;
     h->job_part[(size_t)j] = p;
     pj_cnt[p + 1]++;
+    {
+      bool shaped = k == 1 && jb->ntasks[j] == 1 && jb->ntasks_per_node_min[j] == 1 && !(jb->exclusive && jb->exclusive[j]) &&
+                    !(jb->incl_offsets && jb->incl_offsets[j + 1] != jb->incl_offsets[j]) && !(jb->excl_offsets && jb->excl_offsets[j + 1] != jb->excl_offsets[j]);
+      if (shaped && jb->gres_total)
+        for (u32 x = 0; x < CNS_MAX_GRES_NAMES; ++x) shaped = shaped && jb->gres_total[j * CNS_MAX_GRES_NAMES + x] == 0;
+      if (shaped && jb->gres_spec)
+        for (u32 x = 0; x < CNS_MAX_GRES_CLASSES; ++x) shaped = shaped && jb->gres_spec[j * CNS_MAX_GRES_CLASSES + x] == 0;
+      n_shaped += shaped ? 1u : 0u;
+    }
     const u64 np = rsv != CNS_RESV_NONE ? (u64)(h->part_off[p + 1] - h->part_off[p]) : (u64)h->upart_size[jb->partition[j]];
     algo += np * s_node + 64 + 16 + 24ull * k;
   }
@@ -1049,7 +1056,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
   h->timing = cns_timing{};
   h->timing.h2d_ms = ms;
-  h->J = J; h->Jg = Jg; h->places = places; h->jobs_ordered = batch; h->algo_bytes = algo;
+  h->J = J; h->Jg = Jg; h->places = places; h->jobs_ordered = batch; h->algo_bytes = algo; h->window_shaped = n_shaped;
   h->have_jobs = true;
   return CNS_OK;
 }
