@@ -22,5 +22,5 @@ for name in sys.argv[1:] or ["C4"]:
     h = hashlib.sha1()
     for a in (got.start_sec, got.reason, got.node_idx, got.ntasks, got.cpu_raw, got.mem, got.core_lo, got.core_hi, got.gres):
         h.update(np.ascontiguousarray(a).tobytes())
-    print(f"{tag:14s} {name}: k_select {min(ms):8.1f} ms  {j.num_jobs/min(ms)/1e3:7.3f} M/s  sha1 {h.hexdigest()[:12]}", flush=True)
+    print(f"{tag:14s} {name}: k_select {min(ms):8.1f} ms  {j.num_jobs/min(ms)/1e3:7.3f} M/s  sha1 {h.hexdigest()[:12]}  {e.last_kernel()}", flush=True)
     e.close()
