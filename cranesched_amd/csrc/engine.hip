@@ -30,6 +30,7 @@
 #include "priority_kernels.hip"
 #include "limits_kernels.hip"
 #include "steps_kernels.hip"
+#include "jobs_host.inc"       // the host pass of cns_upload_jobs (no HIP in there: also compiled by the CPU tests)
 
 using namespace cns;
 
@@ -49,6 +50,24 @@ struct DevBuf {
     return e;
   }
   void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Page-locked host staging for what cns_upload_jobs computes on the host (pre-set reasons, placement offsets, the grouped queue):
+// a copy from a std::vector is a bounce through the runtime's own pinned buffer ON the calling thread; from here it is a DMA the
+// thread does not wait for.  Grows by a quarter beyond the request (a queue that gains a few jobs per cycle re-pins nothing).
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap && p) return hipSuccess;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    const size_t want = bytes ? bytes + bytes / 4 : 64;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; } }
   template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -104,7 +123,8 @@ struct cns_engine {
   // job table
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
   u64 window_shaped = 0;   // jobs of the uploaded queue that a window of k_wide can decide: one node, one task per node, no GRES, no node lists, not exclusive
-  std::vector<u64> place_off;
+  PinBuf h_place, h_grouped, h_reason, h_jtag;   // host staging of cns_upload_jobs (page-locked)
+  const u64* place_off = nullptr;               // [J + 1] first placement record per job (in h_place)
   struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, c2, c3, total; } ro{};
   bool wide_cores = false;   // a node of the snapshot has a core id above 127: the results carry the core_w2 / core_w3 planes
   cns_timing timing{};
@@ -586,6 +606,7 @@ void cns_destroy(cns_handle* h) {
                     &h->d_first_resv, &h->d_resv_se})
     b->release();
   for (DevBuf* b : {&h->d_slot_block, &h->d_sib_off, &h->d_sib, &h->d_type_tag, &h->d_jtag, &h->d_params2, &h->d_pmap_a, &h->d_pmap_b, &h->d_wide_last, &h->d_params3, &h->d_pmap_c, &h->d_wide_mem, &h->d_flen, &h->d_tag_off, &h->d_tag_base}) b->release();
+  for (PinBuf* b : {&h->h_place, &h->h_grouped, &h->h_reason, &h->h_jtag}) b->release();
   for (void* p : h->host_bufs) (void)hipHostFree(p);   // cns_host_alloc
   h->host_bufs.clear();
   for (DevBuf& b : h->d_prio) b.release();
@@ -921,72 +942,35 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   HIPCHK(h, hipEventRecord(e0, h->stream));
   h->have_jobs = h->have_run = false;
   const u64 batch = h->cfg.scheduled_batch_size ? std::min<u64>(h->cfg.scheduled_batch_size, J) : J;
-  // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761)
-  std::vector<uint8_t> reason(std::max<u64>(J, 1), CNS_REASON_NONE);
-  std::vector<u64> pj_cnt(h->P + 1, 0);
-  h->job_part.assign((size_t)J, kNone);
-  std::vector<u32> part_of(std::max<u64>(J, 1), 0);  // (virtual) partition of every job that reaches the ordered loop
-  h->place_off.assign(J + 1, 0);
-  u64 places = 0, algo = 0, n_shaped = 0;
-  const u64 s_node = h->big_nodes ? 48 : 32;
-  for (u64 j = 0; j < J; ++j) {
-    h->place_off[j] = places;
-    const u32 k = jb->node_num[j];
-    if (k == 0 || jb->ntasks[j] < k || jb->ntasks_per_node_min[j] == 0 ||
-        jb->ntasks_per_node_max[j] < jb->ntasks_per_node_min[j] || jb->time_limit_sec[j] <= 0 ||
-        jb->task_cpu_raw[j] < 0 || (jb->node_cpu_raw && jb->node_cpu_raw[j] < 0))
-      return fail(h, CNS_ERR_INVALID_ARG, "job " + std::to_string(j) + ": invalid node_num/ntasks/time_limit/cpu");
-    places += k;
-    if (j >= batch) { reason[j] = CNS_REASON_PRIORITY; continue; }
-    if (jb->skip && jb->skip[j]) { reason[j] = CNS_REASON_SKIPPED; continue; }
-    // a job submitted to a reservation is scheduled by that reservation's scheduler, its partition is not looked
-    // at (JobScheduler.cpp:6525-6527,6746-6761); whether the reservation is ACTIVE is decided on the device (needs `now`)
-    const u32 rsv = jb->reservation ? jb->reservation[j] : CNS_RESV_NONE;
-    u32 p;
-    if (rsv != CNS_RESV_NONE) {
-      if (rsv >= h->V) { reason[j] = CNS_REASON_RESERVATION_NOT_FOUND; continue; }
-      p = h->P_real + rsv;
-    } else {
-      if (jb->partition[j] >= h->Pu) { reason[j] = CNS_REASON_PARTITION_NOT_FOUND; continue; }
-      if (h->upart_refused[jb->partition[j]]) { reason[j] = CNS_REASON_ENGINE_REFUSED; continue; }   // (its group is outside the engine's limits: cns_get_partition_status)
-      p = h->upart_eng[jb->partition[j]];   // the engine partition that runs the job's partition (its group, if it shares nodes)
-    }
-    part_of[j] = p;
-    h->job_part[(size_t)j] = p;
-    pj_cnt[p + 1]++;
-    {
-      bool shaped = k == 1 && jb->ntasks[j] == 1 && jb->ntasks_per_node_min[j] == 1 && !(jb->exclusive && jb->exclusive[j]) &&
-                    !(jb->incl_offsets && jb->incl_offsets[j + 1] != jb->incl_offsets[j]) && !(jb->excl_offsets && jb->excl_offsets[j + 1] != jb->excl_offsets[j]);
-      if (shaped && jb->gres_total)
-        for (u32 x = 0; x < CNS_MAX_GRES_NAMES; ++x) shaped = shaped && jb->gres_total[j * CNS_MAX_GRES_NAMES + x] == 0;
-      if (shaped && jb->gres_spec)
-        for (u32 x = 0; x < CNS_MAX_GRES_CLASSES; ++x) shaped = shaped && jb->gres_spec[j * CNS_MAX_GRES_CLASSES + x] == 0;
-      n_shaped += shaped ? 1u : 0u;
-    }
-    const u64 np = rsv != CNS_RESV_NONE ? (u64)(h->part_off[p + 1] - h->part_off[p]) : (u64)h->upart_size[jb->partition[j]];
-    algo += np * s_node + 64 + 16 + 24ull * k;
+  // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761): jobs_host.inc, pass 1 — on a few
+  // host threads; nothing has been handed to the DMA engines yet, so an invalid queue returns with the caller's arrays untouched
+  namespace jh = cns_jobs_host;
+  HIPCHK(h, h->h_reason.ensure(std::max<u64>(J, 1)));
+  HIPCHK(h, h->h_place.ensure((J + 1) * 8));
+  if (h->shared) HIPCHK(h, h->h_jtag.ensure(std::max<u64>(J, 1)));
+  h->job_part.resize((size_t)J);
+  jh::Route R;
+  R.P = h->P; R.Pu = h->Pu; R.P_real = h->P_real; R.V = h->V;
+  R.upart_refused = h->upart_refused.data(); R.upart_eng = h->upart_eng.data(); R.upart_size = h->upart_size.data();
+  R.upart_tag = h->upart_tag.data(); R.part_off = h->part_off.data();
+  R.s_node = h->big_nodes ? 48 : 32; R.gres_classes = h->gres.num_classes; R.batch = batch;
+  jh::Out O;
+  O.reason = h->h_reason.as<uint8_t>(); O.job_part = h->job_part.data(); O.place_off = h->h_place.as<u64>();
+  O.jtag = h->shared ? h->h_jtag.as<uint8_t>() : nullptr;
+  h->place_off = O.place_off;
+  std::vector<jh::Chunk> chunks;
+  {
+    std::string perr;
+    if (const int rc = jh::pass1(jb, R, O, chunks, jh::threads_for(J), &perr)) return fail(h, rc, perr);
   }
-  h->place_off[J] = places;
-  std::vector<u64> pj_off(h->P + 1, 0);
-  for (u32 p = 0; p < h->P; ++p) pj_off[p + 1] = pj_off[p] + pj_cnt[p + 1];
-  const u64 Jg = pj_off[h->P];
-  h->part_jobs.assign(pj_cnt.begin() + 1, pj_cnt.end());
-  // grouped by partition in queue order: one u32 per job on the host; the 64-dword records are packed on the
-  // device from the caller's arrays (k_pack_jobs)
-  std::vector<u64> cur(pj_off.begin(), pj_off.end() - 1);
-  std::vector<u32> grouped((size_t)std::max<u64>(Jg, 1));
-  for (u64 j = 0; j < batch; ++j) {
-    if (reason[j] != CNS_REASON_NONE) continue;
-    grouped[(size_t)cur[part_of[j]]++] = (u32)j;
-  }
-  if (jb->gres_spec)
-    for (u64 i = 0; i < Jg; ++i) {
-      const uint8_t* g = jb->gres_spec + (u64)grouped[(size_t)i] * CNS_MAX_GRES_CLASSES;
-      for (u32 c = h->gres.num_classes; c < CNS_MAX_GRES_CLASSES; ++c)
-        if (g[c]) return fail(h, CNS_ERR_INVALID_ARG, "job requests an undefined GRES class");
-    }
   if ((jb->incl_offsets && !jb->incl_nodes && jb->incl_offsets[J]) || (jb->excl_offsets && !jb->excl_nodes && jb->excl_offsets[J]))
     return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: include / exclude offsets without node lists");
+  const u64 Jg = O.Jg, places = O.places;
+  const std::vector<u64>& pj_off = O.pj_off;
+  h->part_jobs.resize(h->P);
+  for (u32 p = 0; p < h->P; ++p) h->part_jobs[p] = pj_off[p + 1] - pj_off[p];
+  HIPCHK(h, h->h_grouped.ensure(std::max<u64>(Jg, 1) * 4));
+  O.grouped = h->h_grouped.as<u32>();
   auto raw = [&](DevBuf& d, const void* src, size_t bytes) -> int {
     HIPCHK(h, d.ensure(bytes));
     if (src && bytes) HIPCHK(h, hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream));
@@ -1008,19 +992,20 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   if (jb->gres_spec) { if (int rc = raw(rb_[11], jb->gres_spec, J * CNS_MAX_GRES_CLASSES)) return rc; }
   if (jb->incl_offsets) { if (int rc = raw(rb_[12], jb->incl_offsets, (J + 1) * 8)) return rc; }
   if (jb->excl_offsets) { if (int rc = raw(rb_[13], jb->excl_offsets, (J + 1) * 8)) return rc; }
-  if (int rc = raw(rb_[14], h->place_off.data(), (J + 1) * 8)) return rc;
-  if (int rc = upload(h, rb_[15], grouped)) return rc;
-  if (h->shared) {
-    std::vector<uint8_t> jtag((size_t)std::max<u64>(J, 1), 0);
-    for (u64 j = 0; j < J; ++j)
-      if ((!jb->reservation || jb->reservation[j] == CNS_RESV_NONE) && jb->partition[j] < h->Pu) jtag[(size_t)j] = h->upart_tag[jb->partition[j]];
-    if (int rc = upload(h, h->d_jtag, jtag)) return rc;
-  }
   const u64 n_incl = jb->incl_offsets ? jb->incl_offsets[J] : 0, n_excl = jb->excl_offsets ? jb->excl_offsets[J] : 0;
   HIPCHK(h, h->d_incl.ensure(std::max<u64>(n_incl, 1) * 4));
   HIPCHK(h, h->d_excl.ensure(std::max<u64>(n_excl, 1) * 4));
   if (int rc = raw(h->d_incl, jb->incl_nodes, n_incl * 4)) return rc;
   if (int rc = raw(h->d_excl, jb->excl_nodes, n_excl * 4)) return rc;
+  // pass 2 in the shadow of those copies (page-locked caller arrays — cns_host_alloc — are DMA transfers the thread does not wait for):
+  // the offsets of the placement records and the queue grouped by partition in queue order, one u32 per job; the 32-dword records are
+  // packed on the device from the caller's arrays (k_pack_jobs)
+  jh::pass2(jb, O, chunks);
+  if (J == 0) { O.reason[0] = CNS_REASON_NONE; if (O.jtag) O.jtag[0] = 0; }   // (the one-element stand-ins of an empty queue)
+  if (Jg == 0) O.grouped[0] = 0;
+  if (int rc = raw(rb_[14], h->h_place.p, (J + 1) * 8)) return rc;
+  if (int rc = raw(rb_[15], h->h_grouped.p, std::max<u64>(Jg, 1) * 4)) return rc;
+  if (h->shared) { if (int rc = raw(h->d_jtag, h->h_jtag.p, std::max<u64>(J, 1))) return rc; }
   HIPCHK(h, h->d_jobs.ensure((size_t)std::max<u64>(Jg, 1) * kJobRecDwords * 4));
   if (Jg) {
     PackParams K{};
@@ -1038,7 +1023,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   }
 
   if (int rc = upload(h, h->d_pj_off, pj_off)) return rc;
-  if (int rc = upload(h, h->d_reason_init, reason)) return rc;
+  if (int rc = raw(h->d_reason_init, h->h_reason.p, std::max<u64>(J, 1))) return rc;
   // results: one contiguous HBM buffer (also what an RCCL allgather ships)
   cns_engine::ResOff& r = h->ro;
   size_t ro = 0;
@@ -1056,7 +1041,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
   h->timing = cns_timing{};
   h->timing.h2d_ms = ms;
-  h->J = J; h->Jg = Jg; h->places = places; h->jobs_ordered = batch; h->algo_bytes = algo; h->window_shaped = n_shaped;
+  h->J = J; h->Jg = Jg; h->places = places; h->jobs_ordered = batch; h->algo_bytes = O.algo; h->window_shaped = O.n_shaped;
   h->have_jobs = true;
   return CNS_OK;
 }
@@ -1280,8 +1265,8 @@ int cns_download(cns_handle* h, cns_placement_soa* out) {
   HIPCHK(h, get(out->node_idx, h->ro.node, 4 * pl));
   HIPCHK(h, get(out->ntasks, h->ro.ntasks, 4 * pl));
   HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+  memcpy(out->place_offsets, h->place_off, 8 * (J + 1));   // (host to host, in the shadow of the transfers)
   HIPCHK(h, hipStreamSynchronize(h->stream));
-  memcpy(out->place_offsets, h->place_off.data(), 8 * (J + 1));
   float ms = 0;
   HIPCHK(h, hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
   h->timing.d2h_ms = ms;
