@@ -942,35 +942,10 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   HIPCHK(h, hipEventRecord(e0, h->stream));
   h->have_jobs = h->have_run = false;
   const u64 batch = h->cfg.scheduled_batch_size ? std::min<u64>(h->cfg.scheduled_batch_size, J) : J;
-  // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761): jobs_host.inc, pass 1 — on a few
-  // host threads; nothing has been handed to the DMA engines yet, so an invalid queue returns with the caller's arrays untouched
-  namespace jh = cns_jobs_host;
-  HIPCHK(h, h->h_reason.ensure(std::max<u64>(J, 1)));
-  HIPCHK(h, h->h_place.ensure((J + 1) * 8));
-  if (h->shared) HIPCHK(h, h->h_jtag.ensure(std::max<u64>(J, 1)));
-  h->job_part.resize((size_t)J);
-  jh::Route R;
-  R.P = h->P; R.Pu = h->Pu; R.P_real = h->P_real; R.V = h->V;
-  R.upart_refused = h->upart_refused.data(); R.upart_eng = h->upart_eng.data(); R.upart_size = h->upart_size.data();
-  R.upart_tag = h->upart_tag.data(); R.part_off = h->part_off.data();
-  R.s_node = h->big_nodes ? 48 : 32; R.gres_classes = h->gres.num_classes; R.batch = batch;
-  jh::Out O;
-  O.reason = h->h_reason.as<uint8_t>(); O.job_part = h->job_part.data(); O.place_off = h->h_place.as<u64>();
-  O.jtag = h->shared ? h->h_jtag.as<uint8_t>() : nullptr;
-  h->place_off = O.place_off;
-  std::vector<jh::Chunk> chunks;
-  {
-    std::string perr;
-    if (const int rc = jh::pass1(jb, R, O, chunks, jh::threads_for(J), &perr)) return fail(h, rc, perr);
-  }
-  if ((jb->incl_offsets && !jb->incl_nodes && jb->incl_offsets[J]) || (jb->excl_offsets && !jb->excl_nodes && jb->excl_offsets[J]))
-    return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: include / exclude offsets without node lists");
-  const u64 Jg = O.Jg, places = O.places;
-  const std::vector<u64>& pj_off = O.pj_off;
-  h->part_jobs.resize(h->P);
-  for (u32 p = 0; p < h->P; ++p) h->part_jobs[p] = pj_off[p + 1] - pj_off[p];
-  HIPCHK(h, h->h_grouped.ensure(std::max<u64>(Jg, 1) * 4));
-  O.grouped = h->h_grouped.as<u32>();
+  // The caller's arrays go to the device as they are (k_pack_jobs builds the 32-dword job records there); from page-locked arrays
+  // (cns_host_alloc) these are DMA transfers the thread does not wait for, and both host passes below run in their shadow.  A queue
+  // that fails validation returns only after the transfers have drained: the caller owns its arrays again when the call is back.
+  // (offsets without their node list are reported below, after the checks that come first: raw() issues no copy from a null source)
   auto raw = [&](DevBuf& d, const void* src, size_t bytes) -> int {
     HIPCHK(h, d.ensure(bytes));
     if (src && bytes) HIPCHK(h, hipMemcpyAsync(d.p, src, bytes, hipMemcpyHostToDevice, h->stream));
@@ -997,9 +972,37 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   HIPCHK(h, h->d_excl.ensure(std::max<u64>(n_excl, 1) * 4));
   if (int rc = raw(h->d_incl, jb->incl_nodes, n_incl * 4)) return rc;
   if (int rc = raw(h->d_excl, jb->excl_nodes, n_excl * 4)) return rc;
-  // pass 2 in the shadow of those copies (page-locked caller arrays — cns_host_alloc — are DMA transfers the thread does not wait for):
-  // the offsets of the placement records and the queue grouped by partition in queue order, one u32 per job; the 32-dword records are
-  // packed on the device from the caller's arrays (k_pack_jobs)
+  // BasicPriority (JobScheduler.h:185-200) + per-job pre-checks of the ordered loop (cpp:6744-6761): jobs_host.inc, pass 1 — on a few host threads
+  namespace jh = cns_jobs_host;
+  HIPCHK(h, h->h_reason.ensure(std::max<u64>(J, 1)));
+  HIPCHK(h, h->h_place.ensure((J + 1) * 8));
+  if (h->shared) HIPCHK(h, h->h_jtag.ensure(std::max<u64>(J, 1)));
+  h->job_part.resize((size_t)J);
+  jh::Route R;
+  R.P = h->P; R.Pu = h->Pu; R.P_real = h->P_real; R.V = h->V;
+  R.upart_refused = h->upart_refused.data(); R.upart_eng = h->upart_eng.data(); R.upart_size = h->upart_size.data();
+  R.upart_tag = h->upart_tag.data(); R.part_off = h->part_off.data();
+  R.s_node = h->big_nodes ? 48 : 32; R.gres_classes = h->gres.num_classes; R.batch = batch;
+  jh::Out O;
+  O.reason = h->h_reason.as<uint8_t>(); O.job_part = h->job_part.data(); O.place_off = h->h_place.as<u64>();
+  O.jtag = h->shared ? h->h_jtag.as<uint8_t>() : nullptr;
+  h->place_off = O.place_off;
+  std::vector<jh::Chunk> chunks;
+  {
+    std::string perr;
+    if (const int rc = jh::pass1(jb, R, O, chunks, jh::threads_for(J), &perr)) { (void)hipStreamSynchronize(h->stream); return fail(h, rc, perr); }
+  }
+  if ((jb->incl_offsets && !jb->incl_nodes && jb->incl_offsets[J]) || (jb->excl_offsets && !jb->excl_nodes && jb->excl_offsets[J])) {
+    (void)hipStreamSynchronize(h->stream);
+    return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: include / exclude offsets without node lists");
+  }
+  const u64 Jg = O.Jg, places = O.places;
+  const std::vector<u64>& pj_off = O.pj_off;
+  h->part_jobs.resize(h->P);
+  for (u32 p = 0; p < h->P; ++p) h->part_jobs[p] = pj_off[p + 1] - pj_off[p];
+  HIPCHK(h, h->h_grouped.ensure(std::max<u64>(Jg, 1) * 4));
+  O.grouped = h->h_grouped.as<u32>();
+  // pass 2: the offsets of the placement records and the queue grouped by partition in queue order, one u32 per job
   jh::pass2(jb, O, chunks);
   if (J == 0) { O.reason[0] = CNS_REASON_NONE; if (O.jtag) O.jtag[0] = 0; }   // (the one-element stand-ins of an empty queue)
   if (Jg == 0) O.grouped[0] = 0;
