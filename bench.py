@@ -275,10 +275,15 @@ def main():
                 w0 = time.perf_counter()
                 eng.node_select(now, pj, out=pout)
                 pwalls.append(time.perf_counter() - w0)
+            lt = eng.timing()   # (of the last of those cycles)
             incl = {"decisions_per_s": total_jobs / float(np.median(pwalls)), "ms_per_cycle": 1e3 * float(np.median(pwalls)),
-                    "what": "whole cns_select from the caller's host buffers: H2D job arrays + k_pack_jobs + k_prep_jobs + k_init_nodes + "
+                    "what": "whole cns_select from the caller's host buffers: the host pass over the queue (validation, routing, offsets: "
+                            "csrc/jobs_host.inc, on host threads) + H2D job arrays + k_pack_jobs + k_prep_jobs + k_init_nodes + "
                             "selection kernel + D2H placements (SURVEY 8d bracket), median of 5; buffers page-locked (cns_host_alloc) and "
                             "reused across cycles",
+                    "last_cycle_ms": {"host_pass+h2d+k_pack_jobs": float(lt["h2d_ms"]), "k_init_nodes+k_prep_jobs": float(lt["init_ms"]),
+                                      "selection": float(lt["select_ms"]), "d2h": float(lt["d2h_ms"])},
+                    "host_threads": os.environ.get("CNS_HOST_THREADS", "default (up to 16)"),
                     "pageable_fresh_buffers": {"decisions_per_s": total_jobs / float(np.median(walls)), "ms_per_cycle": 1e3 * float(np.median(walls)),
                                                "what": "the same call from pageable numpy arrays, result arrays allocated per call"}}
         r = got.reason[:my_jobs.num_jobs]
