@@ -81,8 +81,15 @@ def main():
     # CNS_BENCH_FORCE_DIST=1 runs the multi-GPU code path (RCCL init, all-gather of the packed placements) on one
     # rank too — a self-test of that path on a 1-GPU box; the reported line is then not a headline number
     use_dist = world > 1 or os.environ.get("CNS_BENCH_FORCE_DIST") == "1"
+    json_fd = 1
     if use_dist:
-        os.environ.setdefault("NCCL_DEBUG", "WARN")   # no RCCL version banner on stdout next to the one JSON line
+        # RCCL writes a version banner ("RCCL version : …", "HIP version : …", …) to the C-level stdout of every process that brings a
+        # communicator up — buffered, so it lands BEHIND whatever Python printed, whatever NCCL_DEBUG says (seen on ROCm 7.0.2 / RCCL
+        # 2.26.6).  The one JSON line must be the only thing on stdout: this process's stdout becomes its stderr from here on, and
+        # rank 0 writes the line to the saved descriptor.
+        sys.stdout.flush()
+        json_fd = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -413,7 +420,12 @@ def main():
                 "sample_identical_to_engine": same, "host_cpus": os.cpu_count()}
             if ref_build is not None:
                 line["cpu_baseline"]["reference_build"] = ref_build
-        print(json.dumps(line), flush=True)
+        if json_fd == 1:
+            print(json.dumps(line), flush=True)
+        else:
+            buf = (json.dumps(line) + "\n").encode()
+            while buf:
+                buf = buf[os.write(json_fd, buf):]
     eng.close()
     if use_dist:
         dist.destroy_process_group()
