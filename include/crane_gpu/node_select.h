@@ -296,7 +296,11 @@ int cns_set_reservations(cns_handle* h, const cns_resv_soa* resv);  /* after cns
 int cns_set_running(cns_handle* h, const cns_running_soa* running); /* NULL or num_jobs==0: none */
 
 /* One scheduling cycle: pack+upload jobs, init node state, select, download placements.
- * Equivalent of SchedulerAlgo::NodeSelect(now, running_jobs, pending_jobs). */
+ * Equivalent of SchedulerAlgo::NodeSelect(now, running_jobs, pending_jobs).
+ * Synchronous; one caller thread per handle (JobScheduler.cpp:1322).  For queues of 32 768 jobs and more the engine's own pass over
+ * the queue (BasicPriority's truncation JobScheduler.h:185-200, the pre-checks JobScheduler.cpp:6744-6761, the split by partition
+ * :6516-6530) runs on up to 16 short-lived host threads inside the call while the job arrays are on their way to the device;
+ * CNS_HOST_THREADS=<n> in the environment sets their number (1: the calling thread only).  The result does not depend on it. */
 int cns_select(cns_handle* h, int64_t now_sec, const cns_job_soa* jobs, cns_placement_soa* out);
 
 /* Split form used by the benchmark so that the timed region starts with inputs resident in HBM. */
