@@ -124,6 +124,7 @@ struct cns_engine {
   u64 J = 0, Jg = 0, places = 0, jobs_ordered = 0, algo_bytes = 0;
   u64 window_shaped = 0;   // jobs of the uploaded queue that a window of k_wide can decide: one node, one task per node, no GRES, no node lists, not exclusive
   PinBuf h_place, h_grouped, h_reason, h_jtag;   // host staging of cns_upload_jobs (page-locked)
+  u32 host_threads = 0;                         // cns_set_host_threads (0: CNS_HOST_THREADS, else up to 16)
   const u64* place_off = nullptr;               // [J + 1] first placement record per job (in h_place)
   struct ResOff { size_t start, cpu, mem, clo, chi, gres, node, ntasks, reason, c2, c3, total; } ro{};
   bool wide_cores = false;   // a node of the snapshot has a core id above 127: the results carry the core_w2 / core_w3 planes
@@ -990,7 +991,7 @@ int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
   std::vector<jh::Chunk> chunks;
   {
     std::string perr;
-    if (const int rc = jh::pass1(jb, R, O, chunks, jh::threads_for(J), &perr)) { (void)hipStreamSynchronize(h->stream); return fail(h, rc, perr); }
+    if (const int rc = jh::pass1(jb, R, O, chunks, jh::threads_for(J, h->host_threads), &perr)) { (void)hipStreamSynchronize(h->stream); return fail(h, rc, perr); }
   }
   if ((jb->incl_offsets && !jb->incl_nodes && jb->incl_offsets[J]) || (jb->excl_offsets && !jb->excl_nodes && jb->excl_offsets[J])) {
     (void)hipStreamSynchronize(h->stream);
@@ -1295,6 +1296,13 @@ int cns_host_free(cns_handle* h, void* p) {
   h->host_bufs.erase(it);
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipHostFree(p));
+  return CNS_OK;
+}
+
+int cns_set_host_threads(cns_handle* h, uint32_t n) {
+  if (!h) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_host_threads: null handle");
+  if (n > 64) return fail(h, CNS_ERR_INVALID_ARG, "cns_set_host_threads: more than 64 threads");
+  h->host_threads = n;
   return CNS_OK;
 }
 

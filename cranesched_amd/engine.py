@@ -25,7 +25,7 @@ _LIB = None
 
 # every symbol include/crane_gpu/node_select.h declares
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
-               "cns_set_reservations", "cns_set_running", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
+               "cns_set_reservations", "cns_set_running", "cns_set_host_threads", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
                "cns_device_results", "cns_host_alloc", "cns_host_free", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
                "cns_debug_last_kernel", "cns_debug_get_prof",
                # several devices (csrc/group_host.inc)
@@ -222,6 +222,10 @@ class GpuNodeSelector:
         else:
             r = running.to_c()
             self._check(self._L.cns_set_running(self._h, C.byref(r)))
+
+    def set_host_threads(self, n: int):
+        """Host threads of the engine's own pass over the queue inside cns_select / cns_upload_jobs (0: CNS_HOST_THREADS, else up to 16)."""
+        self._check(self._L.cns_set_host_threads(self._h, C.c_uint32(n)))
 
     # -- NodeSelect --------------------------------------------------------------------------------
     def node_select(self, now: int, jobs: abi.Jobs, out: "abi.Placements | None" = None) -> abi.Placements:

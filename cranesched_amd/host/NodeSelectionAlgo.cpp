@@ -791,7 +791,12 @@ void GpuNodeSelectionAlgo::LastCycleMs(double* pack_ms, double* engine_ms, doubl
 
 void GpuNodeSelectionAlgo::SetFullWriteBack(bool full) { impl_->lazy_write_back = !full; }
 void GpuNodeSelectionAlgo::SetDeferredWriteBack(bool deferred) { impl_->deferred_write_back = deferred; }
-void GpuNodeSelectionAlgo::SetHostThreads(int n) { impl_->host_threads = n < 1 ? 1 : n; }
+void GpuNodeSelectionAlgo::SetHostThreads(int n) {
+  impl_->host_threads = n < 1 ? 1 : n;
+  const uint32_t e = (uint32_t)std::min(impl_->host_threads, 64);
+  if (impl_->grp) { for (uint32_t d = 0; d < cns_group_size(impl_->grp); ++d) (void)cns_set_host_threads(cns_group_handle(impl_->grp, d), e); }
+  else if (impl_->h) (void)cns_set_host_threads(impl_->h, e);
+}
 
 bool GpuNodeSelectionAlgo::MaterializeAllocation(PdJobInScheduler& job) {
   Impl& I = *impl_;

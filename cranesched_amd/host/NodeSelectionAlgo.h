@@ -326,7 +326,9 @@ class GpuNodeSelectionAlgo final : public INodeSelectionAlgo {
   // from the packed placements the adapter keeps.  0.39 -> 0.1 us per started job in NodeSelect; false: the job was not placed.
   void SetDeferredWriteBack(bool deferred);
   // Host threads for the two per-job loops of a cycle (packing the pending jobs, the write-back): default 1, like the reference's
-  // single ScheduleThread; jobs are independent there, so n threads take n slices of the ordered vector.
+  // single ScheduleThread; jobs are independent there, so n threads take n slices of the ordered vector.  The engine's own pass over the
+  // queue inside cns_select follows the same number (cns_set_host_threads on every device's engine); without a call it keeps its
+  // default (CNS_HOST_THREADS from the environment, else up to 16 threads for queues of 32 768 jobs and more).
   void SetHostThreads(int n);
   bool MaterializeAllocation(PdJobInScheduler& job);
   // The cycle's license table for the pre-pass NodeSelect runs between ordering and selection

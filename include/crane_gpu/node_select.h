@@ -300,7 +300,9 @@ int cns_set_running(cns_handle* h, const cns_running_soa* running); /* NULL or n
  * Synchronous; one caller thread per handle (JobScheduler.cpp:1322).  For queues of 32 768 jobs and more the engine's own pass over
  * the queue (BasicPriority's truncation JobScheduler.h:185-200, the pre-checks JobScheduler.cpp:6744-6761, the split by partition
  * :6516-6530) runs on up to 16 short-lived host threads inside the call while the job arrays are on their way to the device;
- * CNS_HOST_THREADS=<n> in the environment sets their number (1: the calling thread only).  The result does not depend on it. */
+ * cns_set_host_threads(h, n) sets their number (1: the calling thread only; 0, the default: CNS_HOST_THREADS from the environment,
+ * else up to 16).  The result does not depend on it. */
+int cns_set_host_threads(cns_handle* h, uint32_t n);   /* n <= 64; a group: per device, through cns_group_handle */
 int cns_select(cns_handle* h, int64_t now_sec, const cns_job_soa* jobs, cns_placement_soa* out);
 
 /* Split form used by the benchmark so that the timed region starts with inputs resident in HBM. */

@@ -34,6 +34,16 @@ def test_chunked_upload_same_cycle_for_every_thread_count(engine_default, monkey
             pj, pout = eng.pinned_jobs(j), eng.pinned_placements(j)
             assert one.diff(eng.node_select(now, pj, out=pout)) is None, f"CNS_HOST_THREADS={t}, page-locked arrays"
             eng.free_pinned_jobs(pj)
+        # the handle's own setting (cns_set_host_threads) goes before the environment's
+        from cranesched_amd.engine import EngineError
+        monkeypatch.setenv("CNS_HOST_THREADS", "1")
+        eng.set_host_threads(2)
+        assert one.diff(eng.node_select(now, j)) is None, "cns_set_host_threads(2)"
+        with pytest.raises(EngineError) as e:
+            eng.set_host_threads(65)
+        assert e.value.status == -1
+        eng.set_host_threads(0)
+        assert one.diff(eng.node_select(now, j)) is None, "cns_set_host_threads(0)"
     finally:
         eng.close()
 
