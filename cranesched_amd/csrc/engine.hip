@@ -234,6 +234,7 @@ void fill_params(cns_engine* h, KParams& K, i64 now) {
   if (K.wide_inject_stall) K.wide_window = 0;
   K.wide_tester_opt = 1;
   if (const char* to = getenv("CNS_WIDE_TESTER_OPT")) K.wide_tester_opt = (u32)strtoul(to, nullptr, 10);
+  K.wide_aux = 0;   // (sized per launch: launch_wide)
   K.wide_batch_post = 1;
   if (const char* bp = getenv("CNS_WIDE_BATCH_POST")) K.wide_batch_post = (u32)strtoul(bp, nullptr, 10);
   K.part_off = h->d_part_off.as<u32>();
@@ -318,12 +319,21 @@ int launch_wide(cns_engine* h, const KParams& K, const LaunchCtx& L, std::string
   const void* fn = W::pick(np, &kname, K.wide_window >= 2u);
   if (!fn) return 2;
   const unsigned groups = (L.nparts + 7u) / 8u;
-  const unsigned grid = 8u * groups * W::group;
+  // Extra home workgroups per partition (wide_kernel.inc, "MORE THAN ONE HOME WORKGROUP PER PARTITION"): as many as the build allows, as long as
+  // every workgroup of the launch still gets a CU of "its" XCD (32 each, `groups` partitions per XCD) and of the device (other launches of the
+  // cycle hold theirs); none for tiles whose last-task table is not in LDS.  ONE extra home is the default: with two homes the scanners pace every
+  // configuration measured (C5 184.6 -> 146.6 ms, C2 139.4 -> 114.2; a third and a fourth home: 146.3 / 114.2 — profiles/r06_ab_home_workgroups.txt).
+  // CNS_WIDE_AUX=<n> sets the number (0: rounds 2-5's single home; up to the build's maximum: the parity tests run them all).
+  unsigned aux = np > W::lanes * W::last_in_lds_rows ? 0u : (W::aux_max < 1u ? W::aux_max : 1u);
+  if (const char* ea = getenv("CNS_WIDE_AUX")) { const unsigned v = (unsigned)strtoul(ea, nullptr, 10); aux = np > W::lanes * W::last_in_lds_rows ? 0u : (v < W::aux_max ? v : W::aux_max); }
+  while (aux > 0 && (groups * (W::group + aux) > 32u || (u64)8u * groups * (W::group + aux) + L.other_blocks > h->num_cus)) --aux;
+  const unsigned grid = 8u * groups * (W::group + aux);
   const size_t need = (size_t)h->P * W::ctl_bytes;
   if (h->d_wide.ensure(need) != hipSuccess) return 1;
   if (hipMemsetAsync(h->d_wide.p, 0, need, L.stream) != hipSuccess) return 1;
   KParams K2 = K;
   K2.wide_ctl = h->d_wide.as<char>();
+  K2.wide_aux = aux;
   if (np > W::lanes * 4u) {   // 8 / 16 rows per lane: the home workgroup's last-task table does not fit the LDS
     const size_t lb = (size_t)h->P * W::lanes * W::npl_max * sizeof(u32);
     if (h->d_wide_last.ensure(lb) != hipSuccess) return 1;

@@ -149,6 +149,8 @@ struct KParams {
   u32 num_real_parts;
   u32 wide_tester_opt;     // k_wide's testers overlap the record fetch with the node-block load and commit a task that is next to retire straight from
                            // the registers of its test (on unless CNS_WIDE_TESTER_OPT=0: A/B runs)
+  u32 wide_aux;            // k_wide: extra home workgroups per partition in this launch (0 .. the build's CNS_WIDE_AUX_MAX; the host sizes it so that every
+                           // workgroup of the launch is still resident at once; CNS_WIDE_AUX=<n> caps it: A/B runs and the parity tests)
   u32 wide_batch_post;     // k_wide's supervisor posts a run of one-node decisions in one pass (on unless CNS_WIDE_BATCH_POST=0: A/B runs)
   const Res* type_total;   // [T]   distinct res_total records
   char* blocks;            // [S]   one NodeBlock per partition slot: NodeHdr + tl_cap TlEntry

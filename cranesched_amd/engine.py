@@ -392,7 +392,8 @@ class GpuNodeSelector:
 
     WIDE_STATS = ("looks_empty", "looks_consumed", "leader_polls_ring_full", "stops", "flushes", "redo_with_exclusion",
                   "serial_jobs", "resource_verdicts", "partitions_straddling_xcds",
-                  "windows", "jobs_decided_in_windows", "windows_that_decided_nothing", "prefetch_wave_gave_up")   # (round 5: several jobs per exchange, wide_kernel.inc)
+                  "windows", "jobs_decided_in_windows", "windows_that_decided_nothing", "prefetch_wave_gave_up",   # (round 5: several jobs per exchange, wide_kernel.inc)
+                  "home_workgroups")   # (round 6: summed over the partitions — 8 partitions x 3 homes = 24)
 
     def wide_stats(self) -> dict:
         """Always-on protocol counters of k_wide's last run, summed over the partitions (every build; zeros for the other
