@@ -17,33 +17,49 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def _run(tag, monkeypatch, env):
+_CASE = {}
+
+
+def _case(tag):
+    """(reference digest, cluster, jobs, now, running, reservations) — built once per tag (a 1 M-job queue takes seconds to generate)."""
+    if tag not in _CASE:
+        name, J, N, P = CASES[tag]
+        cluster, jobs, now, running, pre = load_case5(name, J, N, P)
+        _CASE[tag] = (dict(np.load(os.path.join(GOLDEN, f"fullrun_{tag}.npz"))), cluster, jobs, now, running, load_resv(name, cluster))
+    return _CASE[tag]
+
+
+def _run(tag, monkeypatch, env, same_as=None):
+    """One cycle under `env`.  same_as=None: the whole digest against the oracle's; else: every result array and every fp64 cost against an
+    earlier run's (which was held to the oracle) — the time maps follow from those and cost a Python call per node to read."""
     monkeypatch.setenv("CNS_SELECT_KERNEL", "wide")
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     from cranesched_amd.engine import GpuNodeSelector
-    ref = dict(np.load(os.path.join(GOLDEN, f"fullrun_{tag}.npz")))
-    name, J, N, P = CASES[tag]
-    cluster, jobs, now, running, pre = load_case5(name, J, N, P)
+    ref, cluster, jobs, now, running, resv = _case(tag)
     eng = GpuNodeSelector(device=0)
     try:
         eng.set_nodes(cluster)
-        resv = load_resv(name, cluster)
         if resv is not None:
             eng.set_reservations(resv)
         if running is not None:
             eng.set_running(running)
         got = eng.node_select(now, jobs)
-        d = fullrun.digest(got, eng.costs().view(np.uint64), eng.timeline, cluster.num_nodes)
-        return fullrun.compare(d, ref), eng.last_kernel(), eng.wide_stats(), eng.timing()["select_ms"], cluster
+        costs = eng.costs().view(np.uint64).copy()
+        if same_as is None:
+            msg = fullrun.compare(fullrun.digest(got, costs, eng.timeline, cluster.num_nodes), ref)
+        else:
+            msg = got.diff(same_as[0])
+            if msg is None and not np.array_equal(costs, same_as[1]):
+                msg = "placements identical but fp64 cost bit patterns differ"
+        return msg, eng.last_kernel(), eng.wide_stats(), eng.timing()["select_ms"], cluster, (got, costs)
     finally:
         eng.close()
 
 
-@pytest.mark.parametrize("aux", ["0", "2", "3"])
-@pytest.mark.parametrize("tag", ["c2", "c4", "c5", "c5deep", "c4r", "c4v", "tile10"])
+@pytest.mark.parametrize("tag,aux", [("c2", "0"), ("c2", "3"), ("c4", "0"), ("c4", "3"), ("c5deep", "2"), ("c4r", "3"), ("c4v", "0"), ("tile10", "2")])
 def test_digest_with_n_homes(gpu, monkeypatch, tag, aux):
-    msg, kernel, ws, ms, cluster = _run(tag, monkeypatch, {"CNS_WIDE_AUX": aux})
+    msg, kernel, ws, ms, cluster, _ = _run(tag, monkeypatch, {"CNS_WIDE_AUX": aux})
     assert kernel.startswith("k_wide"), kernel
     assert msg is None, f"{tag} with CNS_WIDE_AUX={aux}: {msg}"
     assert "retry after" not in kernel
@@ -53,11 +69,11 @@ def test_digest_with_n_homes(gpu, monkeypatch, tag, aux):
     print(f"{tag} CNS_WIDE_AUX={aux}: identical to the oracle; {kernel} {ms:.1f} ms; homes {ws['home_workgroups']} flushes {ws['flushes']}")
 
 
-@pytest.mark.parametrize("tag", ["c4", "c5deep", "c4v"])
+@pytest.mark.parametrize("tag", ["c4", "c4v"])
 def test_protocol_under_perturbation(gpu, monkeypatch, tag):
     """The lock-free protocol of 18 - 20 workgroups per partition must not depend on the instruction schedule or on who is faster
     (a type-punned load reordered by the compiler once made a regime non-deterministic).  The same digest five times
-    in one process under settings that change the timing and nothing else: more / fewer homes, the supervisor's batch posting and the
+    in one process (the first against the oracle's digest, the others against the first) under settings that change the timing and nothing else: more / fewer homes, the supervisor's batch posting and the
     testers' fused commit off, one or many host threads, windows forced on / off, a second engine hammering the same GPU."""
     from cranesched_amd import synth
     from cranesched_amd.engine import GpuNodeSelector
@@ -76,6 +92,7 @@ def test_protocol_under_perturbation(gpu, monkeypatch, tag):
             e.close()
         del monkey_env
 
+    first = None
     settings = [{"CNS_WIDE_AUX": "1"}, {"CNS_WIDE_AUX": "3", "CNS_HOST_THREADS": "1"}, {"CNS_WIDE_AUX": "2", "CNS_WIDE_BATCH_POST": "0", "CNS_WIDE_TESTER_OPT": "0"},
                 {"CNS_WIDE_AUX": "0", "CNS_HOST_THREADS": "64", "CNS_WIDE_WINDOW": "16"}, {"CNS_WIDE_AUX": "3", "CNS_WIDE_WINDOW": "0", "_hammer": "1"}]
     for i, env in enumerate(settings):
@@ -84,7 +101,8 @@ def test_protocol_under_perturbation(gpu, monkeypatch, tag):
             th = threading.Thread(target=hammer, daemon=True)
             th.start()
         try:
-            msg, kernel, ws, ms, _ = _run(tag, monkeypatch, env)
+            msg, kernel, ws, ms, _, res = _run(tag, monkeypatch, env, same_as=first)
+            first = first or res   # (run 0 against the oracle's digest, the others against run 0)
         finally:
             if th is not None:
                 stop.set()
