@@ -65,6 +65,14 @@ def main():
     ap.add_argument("--cpu-partition", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    # --config c5deep: BASELINE config 5's queue (1 M jobs with walltimes in 256 slots of 675 s) on a QUARTER of its nodes.  The frozen C5 (3.75 M
+    # cores of demand on 4.19 M) never fills its cluster — every job starts now, nothing is ever packed into a window —; on 16 384 nodes 72 % of the
+    # jobs are backfilled: the walltime-packing regime the configuration is named after (tests/golden/make_fullrun.py "c5deep": digest vs the oracle).
+    label = args.config
+    if args.config.lower() == "c5deep":
+        args.config, label = "C5", "c5deep = C5's queue on 16 384 nodes"
+        if args.nodes is None:
+            args.nodes = 16384
 
     import torch
     import torch.distributed as dist
@@ -237,8 +245,10 @@ def main():
         try:
             prof = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_hbm.json"))
             if prof and args.config == "C4" and args.jobs is None and args.nodes is None and world == 1:
-                traffic_prof = {"bytes_per_launch": json.load(open(os.path.join(ROOT, "profiles", prof[-1])))["traffic_bytes_per_launch"],
-                                "source": "profiles/" + prof[-1]}
+                pj = json.load(open(os.path.join(ROOT, "profiles", prof[-1])))
+                traffic_prof = {"bytes_per_launch": pj["traffic_bytes_per_launch"], "source": "profiles/" + prof[-1],
+                                "how": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) around this same command on the committed "
+                                       "build; 2 x FETCH_SIZE (gfx950) + WRITE_SIZE, mean per launch of the dominant kernel (tools/gpu_bench.sh)"}
         except (OSError, KeyError):
             pass
         got = eng.download()
@@ -296,12 +306,13 @@ def main():
         r = got.reason[:my_jobs.num_jobs]
         line = {
             "metric": "scheduling decisions/sec at 1M pending x 64k nodes",
-            # `value`: inputs resident in HBM when the timed region starts (the bench contract: a PCIe-inclusive rate is never
-            # `value`).  The reference's own bracket incl. H2D of the job arrays and D2H of the placements: `incl_h2d_d2h`.
+            # `value`: inputs resident in HBM when the timed region starts (the bench contract: "if the boundary hands over host buffers, note the
+            # PCIe-inclusive rate ... it is never `value`").  SURVEY 8(d)'s metric — the reference's own bracket incl. H2D of the job arrays and D2H of
+            # the placements — is `incl_h2d_d2h.decisions_per_s` (1 - 2 % below `value`); both are in every line.
             "value": value, "kernel_resident_decisions_per_s": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "int64", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {jobs.num_jobs} pending jobs x {cluster.num_nodes} nodes, "
+            "config": {"workload": f"{label}: {jobs.num_jobs} pending jobs x {cluster.num_nodes} nodes, "
                                    f"{cluster.num_partitions} disjoint partitions, CPU+mem+GRES(gpu/npu), FIFO, "
                                    f"seed 0x43524E45^{synth.CONFIGS[base_cfg]['idx']}" +
                                    (f"; loaded cluster: {len(running.end_sec)} running jobs, {len(running.alloc_node)} allocations (synth.make_running)" if running is not None else ""),
@@ -318,11 +329,21 @@ def main():
                        "wide_protocol_counters": wide_counters,
                        "h2d_job_table_ms": h2d_ms},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_profiles": traffic_prof,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         # HBM bytes per launch of the dominant kernel from the PMC counters: the committed passes of this same command (a PMC pass needs
+                         # rocprofv3 around the process: not measurable from inside the run); null for a workload no pass was committed for
+                         "traffic": traffic_prof["bytes_per_launch"] if traffic_prof else None, "traffic_from_profiles": traffic_prof,
                          # what the kernel really moves: the counter bytes of the committed PMC passes / this run's launch time / peak — the
                          # honest utilisation next to the model fraction above (the kernel is a latency-bound sequential chain, not a streaming one)
                          "hbm_util": (traffic_prof["bytes_per_launch"] / (avg_sel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic_prof else None,
                          "chain_us_per_decision": chain_us,
+                         # who paces the pipeline of a partition (k_wide's always-on counters): the leader scanner standing in front of a full decision
+                         # ring = the home workgroups (test + commit) are behind; the supervisor finding the ring empty = the scanners' chain is
+                         "paced_by": (None if not wide_counters else
+                                      ("home workgroups (testers)" if wide_counters["leader_polls_ring_full"] > 0.25 * total_jobs else "the scanners' chain")),
+                         "leader_polls_ring_full_per_decision": (wide_counters["leader_polls_ring_full"] / max(total_jobs, 1)) if wide_counters else None,
+                         "supervisor_looks_empty_per_decision": (wide_counters["looks_empty"] / max(total_jobs, 1)) if wide_counters else None,
+                         "home_workgroups_per_partition": (wide_counters.get("home_workgroups", 0) / max(my_cluster.num_partitions, 1)) if wide_counters else None,
                          "chain_note": f"{int(per_part.max())} decisions on the busiest partition's chain, strictly one after the other; {my_cluster.num_partitions} chains side by side",
                          "kernel": kernel, "algorithmic_bytes_per_launch": algo_bytes, "bytes_model": bytes_model,
                          "reuse_factor": (achieved / HBM_PEAK_GBS) if achieved > HBM_PEAK_GBS else None,

@@ -94,6 +94,7 @@ struct cns_engine {
   bool shared = false;                        // some node belongs to several partitions
   u32 num_cus = 0;                            // compute units of the device (0: unknown); k_wide needs one per workgroup, all resident at once
   std::vector<u32> upart_eng, upart_size;     // caller's partition -> engine partition, its schedulable node count
+  std::vector<uint8_t> refused_probe;         // the statuses of the last cns_set_nodes call, also when it failed because EVERY partition was refused
   std::vector<uint8_t> upart_refused;         // caller's partition -> cns_partition_status: != 0: its group is outside the engine's limits — its jobs get
                                               // CNS_REASON_ENGINE_REFUSED, every other partition is served (cns_get_partition_status)
   std::vector<uint8_t> upart_tag;             // ... and its member tag inside that engine partition
@@ -564,6 +565,7 @@ const char* cns_last_error(const cns_handle* h) { return h ? h->err.c_str() : g_
 int cns_create(const cns_config* cfg, cns_handle** out) {
   if (!cfg || !out) return fail(nullptr, CNS_ERR_INVALID_ARG, "cns_create: null argument");
   if (cfg->abi_version != CNS_ABI_VERSION) return fail(nullptr, CNS_ERR_INVALID_ARG, "cns_create: ABI version mismatch");
+  if (cfg->kernel_pin > CNS_KERNEL_PIPE) return fail(nullptr, CNS_ERR_INVALID_ARG, "cns_create: kernel_pin is not a cns_kernel_pin (a field the caller never zeroed?)");
   int ndev = 0;
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0)
@@ -739,6 +741,7 @@ int cns_set_nodes(cns_handle* h, const cns_node_soa* nd) {
     }
     bool any_served = false;
     for (u32 p = 0; p < P; ++p) any_served = any_served || !upart_refused[p];
+    h->refused_probe = upart_refused;   // (why, per partition of THIS call: cns_group_set_nodes reads it when a device's whole share is refused)
     if (!any_served) return fail(h, CNS_ERR_UNSUPPORTED, "every partition of the snapshot is outside the engine's limits (a node flagged unsupported, a cpu count outside (0, 2^31-2), more than 64 distinct res_total records, or a group wider than the widest tile)");
   }
   std::vector<u32> part_off(PE + 1, 0), slot_node, node_slot(N, kNone);
@@ -940,7 +943,20 @@ int cns_set_running(cns_handle* h, const cns_running_soa* rn) {
   return CNS_OK;
 }
 
+static int upload_jobs_impl(cns_handle* h, const cns_job_soa* jb);
+// The caller owns its arrays again when the call is back — on EVERY path: an error behind the first asynchronous copy (a failed allocation, a
+// queue that fails validation) returns only after the copies from the caller's arrays have drained.
 int cns_upload_jobs(cns_handle* h, const cns_job_soa* jb) {
+  const int rc = upload_jobs_impl(h, jb);
+  if (rc != 0 && h && h->have_nodes) {
+    const std::string keep = h->err;            // (the drain must not replace the error it follows)
+    if (hipSetDevice(h->device) == hipSuccess) (void)hipStreamSynchronize(h->stream);
+    (void)hipGetLastError();
+    h->err = keep;
+  }
+  return rc;
+}
+static int upload_jobs_impl(cns_handle* h, const cns_job_soa* jb) {
   if (!h || !jb) return fail(h, CNS_ERR_INVALID_ARG, "cns_upload_jobs: null argument");
   if (!h->have_nodes) return fail(h, CNS_ERR_STATE, "cns_upload_jobs before cns_set_nodes");
   const u64 J = jb->num_jobs;
@@ -1551,6 +1567,8 @@ int cns_debug_get_costs(cns_handle* h, double* out) {
 }
 
 const char* cns_debug_last_kernel(const cns_handle* h) { return h ? h->last_kernel.c_str() : ""; }
+
+uint32_t cns_debug_engine_partitions(const cns_handle* h) { return (h && h->have_nodes) ? h->P : 0u; }
 
 int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity) {
   // cycle counters of the last run, 32 per partition; all zero unless the library was built with -DCNS_PROF

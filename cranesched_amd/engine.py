@@ -27,13 +27,13 @@ _LIB = None
 ABI_SYMBOLS = ("cns_abi_version", "cns_last_error", "cns_create", "cns_destroy", "cns_set_nodes",
                "cns_set_reservations", "cns_set_running", "cns_set_host_threads", "cns_select", "cns_upload_jobs", "cns_run_resident", "cns_download",
                "cns_device_results", "cns_host_alloc", "cns_host_free", "cns_get_timing", "cns_debug_get_costs", "cns_debug_get_timeline", "cns_debug_get_timeline_cores",
-               "cns_debug_last_kernel", "cns_debug_get_prof",
+               "cns_debug_last_kernel", "cns_debug_get_prof", "cns_debug_engine_partitions",
                # several devices (csrc/group_host.inc)
                "cns_get_partition_status",
                "cns_results_layout", "cns_comm_unique_id", "cns_comm_init_rank", "cns_comm_destroy", "cns_allgather_results",
                "cns_download_gathered", "cns_gather_timing", "cns_group_create", "cns_group_destroy", "cns_group_last_error",
                "cns_group_size", "cns_group_handle", "cns_group_set_nodes", "cns_group_set_reservations", "cns_group_set_running",
-               "cns_group_select", "cns_group_get_info", "cns_group_device_of_partition")
+               "cns_group_select", "cns_group_get_info", "cns_group_device_of_partition", "cns_group_get_partition_status")
 # ... and include/crane_gpu/priority.h
 PRIORITY_ABI_SYMBOLS = ("cns_priority_order", "cns_priority_timing")
 # ... and include/crane_gpu/run_limits.h
@@ -399,7 +399,8 @@ class GpuNodeSelector:
         """Always-on protocol counters of k_wide's last run, summed over the partitions (every build; zeros for the other
         kernels): who waited for whom (supervisor looks without / with a decision, leader polls in front of a full ring) and
         how often the chain was broken (stops, flushes) and mended (redo with an excluded candidate, serial jobs, "Resource")."""
-        P = self._cluster.num_partitions
+        self._L.cns_debug_engine_partitions.restype = C.c_uint32
+        P = int(self._L.cns_debug_engine_partitions(self._h)) or self._cluster.num_partitions   # (groups of partitions that share nodes + reservations)
         out = np.zeros(P * 48, np.uint64)
         self._check(self._L.cns_debug_get_prof(self._h, out.ctypes.data_as(C.c_void_p), C.c_uint32(P * 48)))
         st = out[P * 32:].reshape(P, 16).sum(axis=0)
@@ -488,6 +489,12 @@ class GpuNodeSelectorGroup:
 
     def device_of_partition(self, p: int) -> int:
         return int(self._L.cns_group_device_of_partition(self._g, C.c_uint32(p)))
+
+    def partition_status(self) -> np.ndarray:
+        """cns_partition_status per partition of the caller (0: served), whichever device it was dealt to."""
+        st = np.zeros(self._cluster.num_partitions, np.uint8)
+        self._check(self._L.cns_group_get_partition_status(self._g, st.ctypes.data_as(C.c_void_p), C.c_uint32(len(st))))
+        return st
 
     def last_kernels(self):
         n = self._L.cns_group_size(self._g)

@@ -1181,9 +1181,9 @@ size_t GpuNodeSelectionAlgo::UnsupportedNodes() const { return impl_->unsupporte
 std::vector<PartitionId> GpuNodeSelectionAlgo::RefusedPartitions() const {
   std::vector<PartitionId> out;
   const Impl& I = *impl_;
-  if (!I.h || !I.have_snapshot || I.grp) return out;   // (several devices: ask the engines, cns_group_handle + cns_get_partition_status)
+  if (!I.h || !I.have_snapshot) return out;
   std::vector<uint8_t> st(I.part_idx.size() + 1, 0);
-  if (cns_get_partition_status(I.h, st.data(), (uint32_t)st.size()) != 0) return out;
+  if ((I.grp ? cns_group_get_partition_status(I.grp, st.data(), (uint32_t)st.size()) : cns_get_partition_status(I.h, st.data(), (uint32_t)st.size())) != 0) return out;
   for (const auto& [pid, idx] : I.part_idx) if (idx < st.size() && st[idx]) out.push_back(pid);
   std::sort(out.begin(), out.end());
   return out;

@@ -330,7 +330,11 @@ cns_handle* cns_group_handle(cns_group* g, uint32_t device_index);          /* e
 int cns_group_set_nodes(cns_group* g, const cns_node_soa* nodes);          /* deals the groups of partitions: group i -> device i % N */
 int cns_group_set_reservations(cns_group* g, const cns_resv_soa* resv);    /* every device; the jobs of reservation v run on (active) device v % N */
 int cns_group_set_running(cns_group* g, const cns_running_soa* running);   /* every device (allocations on nodes it does not schedule are dropped there) */
-int cns_group_select(cns_group* g, int64_t now_sec, const cns_job_soa* jobs, cns_placement_soa* out);   /* = cns_select, merged in queue order */
+int cns_group_select(cns_group* g, int64_t now_sec, const cns_job_soa* jobs, cns_placement_soa* out);   /* = cns_select, merged in queue order: cns_config::
+                                       scheduled_batch_size cuts the ONE ordered queue (JobScheduler.h:185-200), not every device's share of it */
+/* = cns_get_partition_status over the caller's partitions.  A device whose WHOLE share of the partitions is outside the engine's limits serves
+ * nothing (its jobs: CNS_REASON_ENGINE_REFUSED) while the other devices run; cns_group_set_nodes fails only when no device can serve anything. */
+int cns_group_get_partition_status(const cns_group* g, uint8_t* status /* [num_partitions] cns_partition_status */, uint32_t capacity);
 int cns_group_get_info(const cns_group* g, cns_group_info* out);
 uint32_t cns_group_device_of_partition(const cns_group* g, uint32_t partition);
 
@@ -357,6 +361,7 @@ const char* cns_debug_last_kernel(const cns_handle* h);
 
 /* Cycle counters of the last run (32 per partition); zeros unless the library was built with -DCNS_PROF. */
 int cns_debug_get_prof(cns_handle* h, uint64_t* out, uint32_t capacity);
+uint32_t cns_debug_engine_partitions(const cns_handle* h);   /* schedulers of the snapshot as the engine runs them: groups of partitions that share nodes + one per reservation (the rows of cns_debug_get_prof) */
 
 #ifdef __cplusplus
 }

@@ -77,3 +77,22 @@ def test_c4p256_shards_get_the_k_wide_build_the_plan_predicts(built, world, expe
     assert all(expect in k for k in kernels), kernels
     merged = sharding.merge(j, shards) if world > 1 else shards[0][0]
     assert merged.diff(ref.placements) is None
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_bench_under_torch_distributed_run_on_distinct_gpus(built, world):
+    """The driver's launch line on a multi-GPU node (one rank per GPU, RCCL over xGMI): skips on the one-GPU boxes this project has had.
+    Checks what the line must carry: the merged all-gather identical to one engine's run, the engine's own ncclAllGather (not the torch
+    fall-back), the flat C4 line and — same ranks — the C4p64 line on which GPUs add chains."""
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs, this box has {torch.cuda.device_count()}")
+    for config in ("C4", "C4p64"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                            "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+                            "--config", config, "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == world and line["allgather_merged_identical_to_single_gpu"] is True
+        assert line["allgather"].startswith("engine"), line["allgather"]
