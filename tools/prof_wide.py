@@ -61,4 +61,6 @@ if os.environ.get("CNS_PROF_FAST"):   # a -DCNS_PROF_FAST build: the scanners' s
         print(f"  steady-state loop, {what}: {m[0+w]:.0f} wave-jobs; record + rows + argmin + publish {m[2+w]/n:.0f} | publish -> exchange complete {m[4+w]/n:.0f} | "
               f"decision + row write {m[6+w]/n:.0f} cycles")
     n = max(m[0] + m[1], 1)
+    print(f"  inside the first segment: record -> scalars + control words {m[10]/n:.0f} | rows {m[11]/n:.0f} | argmin cascades {m[12]/n:.0f} | "
+          f"payloads + lap guard + publish {(m[2]+m[3]-m[10]-m[11]-m[12])/n:.0f} cycles")
     print(f"  wave-jobs that recomputed the res_total argmin {m[8]/n:.3f}; first poll found the exchange complete {m[9]/n:.3f}")
