@@ -80,8 +80,7 @@ def test_protocol_under_perturbation(gpu, monkeypatch, tag):
     import threading
     stop = threading.Event()
 
-    def hammer():   # another engine of this process keeps the GPU's other CUs busy (C2: one partition, 18 workgroups)
-        monkey_env = dict(os.environ)
+    def hammer():   # another engine of this process keeps the GPU's other CUs busy (C2: one partition, 18 - 20 workgroups)
         c, j, now = synth.make_config("C2")
         e = GpuNodeSelector(device=0)
         try:
@@ -90,7 +89,6 @@ def test_protocol_under_perturbation(gpu, monkeypatch, tag):
                 e.run_resident(now)
         finally:
             e.close()
-        del monkey_env
 
     first = None
     settings = [{"CNS_WIDE_AUX": "1"}, {"CNS_WIDE_AUX": "3", "CNS_HOST_THREADS": "1"}, {"CNS_WIDE_AUX": "2", "CNS_WIDE_BATCH_POST": "0", "CNS_WIDE_TESTER_OPT": "0"},
