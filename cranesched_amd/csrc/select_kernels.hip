@@ -1181,11 +1181,16 @@ struct WorkerShared {
   u32 part;   // engine partition this workgroup serves (k_select / k_pipe: blockIdx.x; k_wide: several workgroups per partition)
 };
 
+#ifdef CNS_PROF_DIP   // (a -DCNS_PROF -DCNS_PROF_DIP build counts k_select's dips in the slots of the multi-node protocols)
+#define PROF_DIP(slot) do { if (lane == 0) P.prof[(size_t)(P.part_map ? P.part_map[blockIdx.x] : blockIdx.x) * 32 + (slot)] += 1; } while (0)
+#else
+#define PROF_DIP(slot) do {} while (0)
+#endif
 #ifdef CNS_PROF
 #define PROF_T(var) const long long var = clock64()
-#define PROF_ADD(slot, a, b) do { if (lane == 0) P.prof[(size_t)blockIdx.x * 32 + (slot)] += (u64)((b) - (a)); } while (0)
-#define PROF_CNT(slot) do { if (lane == 0) P.prof[(size_t)blockIdx.x * 32 + (slot)] += 1; } while (0)
-#define PROF_ADDS(slot, a, b) do { if (lane == 0 && wave == 1) P.prof[(size_t)blockIdx.x * 32 + (slot)] += (u64)((b) - (a)); } while (0)
+#define PROF_ADD(slot, a, b) do { if (lane == 0) P.prof[(size_t)(P.part_map ? P.part_map[blockIdx.x] : blockIdx.x) * 32 + (slot)] += (u64)((b) - (a)); } while (0)
+#define PROF_CNT(slot) do { if (lane == 0) P.prof[(size_t)(P.part_map ? P.part_map[blockIdx.x] : blockIdx.x) * 32 + (slot)] += 1; } while (0)
+#define PROF_ADDS(slot, a, b) do { if (lane == 0 && wave == 1) P.prof[(size_t)(P.part_map ? P.part_map[blockIdx.x] : blockIdx.x) * 32 + (slot)] += (u64)((b) - (a)); } while (0)
 #else
 #define PROF_T(var)
 #define PROF_ADD(slot, a, b)
@@ -1194,6 +1199,42 @@ struct WorkerShared {
 #endif
 
 #include "preempt_dev.inc"
+
+// k_select's scanners keep one dip per node in their tile (NPL <= kSelDipMaxNpl), like k_wide's (KParams::dip_*): the worker posts
+// what a rejected start-now candidate revealed in LDS next to its verdict (fl[4..7]); the node's owner lane takes it after B2 and
+// stops proposing the node to jobs whose windows reach that far and which do not fit it (a second NECESSARY condition for
+// :6274-6285; the candidates still come in cost order, fewer of them).  Posted is
+//   - the first FUTURE entry inside the job's window that by itself cannot host the minimum view (cpu, memory, GRES counts), or
+//   - when every entry can: the WINDOW MINIMUM m itself (res_avail folded with every entry of the window: the GRES slots that are
+//     free THROUGHOUT — on a loaded cluster the running jobs and the backfilled ones hold different slots at different times),
+//     dated at the last entry inside the window: a window that reaches that entry contains all of this one's entries, and entries
+//     only shrink and split within a cycle, so its minimum lies below m in every component.
+// A release by TryPreempt_ is the one thing that invalidates a dip: the owner updates of a preempting job carry kUpdReleased and
+// the owner forgets the row's dip.  Register maps (<= 64 entries) only.
+constexpr int kSelDipMaxNpl = 19;
+constexpr u32 kUpdReleased = 4u;   // UpdRec::has_front bit 2
+// A row's dip time, cpus and memory in ONE register, every field rounded towards "no effect": 16 s units rounded UP (a window
+// in 16 s units rounded DOWN that lies beyond it really contains the entry; 0xFFFF: none / more than 12 days away) | whole cpus,
+// rounded up by dip_cm_of, capped at 255 | GiB likewise (a request is capped the same way before it is compared: a capped dip fits all).
+constexpr u32 kDipNone = 0xFFFF0000u;
+__device__ __forceinline__ u32 pack_dip(u32 dt, u32 dcm) {
+  const u32 t16 = dt >= 0xFFFF0u ? 0xFFFFu : ((dt + 15u) >> 4);
+  const u32 c = dcm >> 16, m = dcm & 0xFFFFu;
+  return (t16 << 16) | ((c > 255u ? 255u : c) << 8) | (m > 255u ? 255u : m);
+}
+__device__ __forceinline__ bool post_dip(const KParams& P, const GresDev& G, int* fl, u32 code, const TlEntry& e, u32 len, const Req& mv, i64 E, u32 lane, const Res& m) {
+  if (len > 64) { if (lane == 0) fl[4] = (int)kNone; return false; }
+  const bool inw = lane == 0 || (lane < len && e.t < E);
+  const bool cand = inw && lane >= 1 && !feasible_counts(mv, e.r.cpu, e.r.mem, 0u, class_counts(e.r.gres, G), G);
+  const u64 b = __ballot(cand);
+  const u32 i = b ? (u32)__builtin_ctzll(b) : 63u - (u32)__builtin_clzll(__ballot(inw));   // the first entry that fails | the last one inside the window
+  const Res r = b ? rl_res(e.r, i) : m;
+  const i64 t = (i64)rl64((u64)e.t, i);
+  const i64 off = t <= P.now ? 0 : t - P.now;
+  if (off >= 0xFFFFFFFFll) { if (lane == 0) fl[4] = (int)kNone; return false; }
+  if (lane == 0) { fl[4] = (int)code; fl[5] = (int)(u32)off; fl[6] = (int)dip_cm_of(r); fl[7] = (int)nibbles_of(class_counts(r.gres, G)); }
+  return b != 0;
+}
 
 // Out-of-line worker path for everything that is not "node_num == 1, ntasks == 1, shared node":
 // multi-node jobs, ntasks > node_num (priority_queue emulation) and exclusive jobs.  Enters after the
@@ -1268,6 +1309,18 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
         commit_selection<kS>(Pm, J, H, qbeg, P.now, lane, s_upd, s_nupd);      // start_time = now (:6326)
         if (lane == 0) { P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
         code = 2;
+      }
+    }
+    if constexpr (kS == kScan) {   // (k_select's scanners alone read the dip words: post_dip)
+      if (!ok && !excl_job && len <= 64) {
+        TlEntry e;
+        e.t = kInf;
+        if (lane < len) e = T[lane];
+        Res f;
+        if (feasible(J.min_view, hd->avail0, f, Pm.gres)) post_dip(P, Pm.gres, sh.flag, wcode, e, len, J.min_view, J.E, lane, m);   // (m: the window minimum)
+        else post_dip(P, Pm.gres, sh.flag, wcode, e, 1u, J.min_view, J.E, lane, hd->avail0);   // res_avail itself cannot host it (:6274): whatever the window
+      } else if (lane == 0) {
+        sh.flag[4] = (int)kNone;
       }
     }
     if (via_hbm) __threadfence_block();  // the owner updates went through HBM (g_upd)
@@ -1354,6 +1407,8 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
         commit_selection<kS>(Pm, J, H, qbeg, P.now, lane, s_upd, s_nupd);   // start_time = now (:6501), h:630-634
         // the scanners' rows of the nodes that were released on (other than the job's own: their records are final)
         u32 nup = (u32)*s_nupd;
+        if (lane == 0)   // every record of this job tells the owner that resources came BACK: a dip it holds for the row is void
+          for (u32 i = 0; i < nup; ++i) s_upd[i].has_front |= kUpdReleased;
         for (u32 x = 0; x < nt; ++x) {
           const u32 q = touched[x];
           bool dup = false;
@@ -1365,7 +1420,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
             const u32 ps = q - qbeg;
             u.p = ((ps / kS) << 10) | (ps % kS);
             u.len = hd->len; u.cost = P.cost[q]; u.fcpu = P.f_cpu[q]; u.fmem = P.f_mem[q]; u.fcnt = P.f_cnt[q];
-            u.has_front = 1u; u.pad = 0;
+            u.has_front = 1u | kUpdReleased; u.pad = 0;
             s_upd[nup] = u;
           }
           ++nup;
@@ -1376,7 +1431,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
                 const u32 ps = P.sib[a] - qbeg;
                 us.p = ((ps / kS) << 10) | (ps % kS);
                 us.len = hd->len; us.cost = 0.0; us.fcpu = P.f_cpu[q]; us.fmem = P.f_mem[q]; us.fcnt = P.f_cnt[q];
-                us.has_front = 3u; us.pad = 0;
+                us.has_front = 3u | kUpdReleased; us.pad = 0;
                 s_upd[nup] = us;
               }
               ++nup;
@@ -1561,6 +1616,12 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
         if (lane == 0) { *sh.nupd = (int)J.k; P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
         code = 2;
       }
+    }
+    if (!ok && h.len <= 64) {
+      if (feasible(J.min_view, h.avail0, f, P.gres)) post_dip(P, P.gres, sh.flag, wcode, e, h.len, J.min_view, J.E, lane, m);
+      else post_dip(P, P.gres, sh.flag, wcode, e, 1u, J.min_view, J.E, lane, h.avail0);
+    } else if (lane == 0) {
+      sh.flag[4] = (int)kNone;
     }
     if (lane == 0) *sh.flag = code;
     wg_barrier();  // B2
@@ -1908,7 +1969,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   __shared__ u32 s_lp[(kWaves - 1) * kMultiK];
   __shared__ i64 s_nf[2 * kMultiK];             // ... and the next-fit exchange of the backfill fixed point
   __shared__ int s_mode;                        // ... worker -> scanners: 1 start-now list complete, 2 need res_total lists, 3 res_total list complete, 0 give up
-  __shared__ int s_flag;
+  __shared__ int s_fl[8];   // [0] the worker's verdict; [4..7] the dip a rejected start-now candidate revealed (post_dip): slot code | seconds after now | cpus, mem | GRES counts
+#define s_flag s_fl[0]
   __shared__ int s_r0;   // worker -> scanners: this job may be followed by the worker-side merge
   __shared__ int s_nupd;
   __shared__ UpdRec s_upd[kMaxUpd];
@@ -2033,6 +2095,21 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, cost_of_key_m(wc, wsmode), f,
                                P.now, 0, lane, s_upd, &s_nupd, cn, PG, qbeg);
             code = 2;
+          } else if (NPL <= kSelDipMaxNpl) {
+            const bool dipped = post_dip(P, P.gres, s_fl, wcode, e, h.len, F.mv, F.E, lane, m);   // what this window tripped over, for the node's owner lane
+            if (dipped) { PROF_DIP(28); }
+#ifdef CNS_PROF_DIP
+            {   // why was it rejected?  front entry fails the exact test: 29 by cpu, 30 by memory, 31 otherwise; 27: front fine, no single entry fails by counts
+              Res ftmp;
+              const bool front_ok = feasible(F.mv, h.avail0, ftmp, P.gres);
+              if (!front_ok) {
+                if (F.mv.cpu > h.avail0.cpu) { PROF_DIP(29); }
+                else if (F.mv.mem > h.avail0.mem) { PROF_DIP(30); }
+                else { PROF_DIP(31); }
+              }
+              if (front_ok && !dipped) { PROF_DIP(27); }
+            }
+#endif
           }
           PROF_T(a3);
           PROF_ADD(3, a2, a3);  // commit
@@ -2267,6 +2344,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
     int fcpu[NPL];
     u32 mw[NPL];   // fmem GiB (16) | len (10) << 16 | type (6) << 26 ; len = 1023 marks "no node"
     u32 gn[NPL];   // per-class free-slot count, 4 bits each
+    // the row's dip (post_dip; KParams::dip_* as k_init_nodes found it): seconds after now (~0: none) | cpus, mem | GRES counts
+    constexpr bool kDip = NPL <= kSelDipMaxNpl;
+    constexpr int kDipRows = kDip ? NPL : 1;
+    u32 dpa[kDipRows], dpg[kDipRows];   // pack_dip(seconds, cpus | mem) and the GRES counts: two registers per row (three cost k_select<19> 16 % on C4)
 #pragma unroll
     for (int r = 0; r < NPL; ++r) {
       const u32 p = (u32)r * kScan + t;
@@ -2277,8 +2358,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         fcpu[r] = P.f_cpu[q];
         mw[r] = mem_gib16(P.f_mem[q]) | (hd->len << 16) | ((u32)P.slot_type[q] << 26);
         gn[r] = nibbles_of(P.f_cnt[q]);
+        if (kDip) { dpa[r] = pack_dip(P.dip_t[q], P.dip_cm[q]); dpg[r] = P.dip_g[q]; }
       } else {
         cost[r] = 0.0; fcpu[r] = 0; mw[r] = 1023u << 16; gn[r] = 0;
+        if (kDip) { dpa[r] = kDipNone; dpg[r] = 0; }
       }
     }
     wg_barrier();  // type / name tables written by the worker
@@ -2324,6 +2407,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       u32 gmode;   // 0 no GRES; bit 0: one specified class, bit 1: one untyped total (1..3 = short tests); 4 general
       u32 gsel;    // nibble shift of that class | index of that name << 8
       u32 gneed;   // its count | the total << 8, both saturated at 15
+      u32 loff;    // time limit in seconds, saturating: an entry t seconds after now lies in a start-now window iff t < loff (:6279)
     };
     auto decode = [&](u32 raw, u64& tyok) {
       ScanJob S;
@@ -2337,6 +2421,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       S.gmode = rl32(raw, kJdGmode);
       S.gsel = rl32(raw, kJdGsel);
       S.gneed = rl32(raw, kJdGneed);
+      {
+        const u64 L = jr64(raw, kJrL);
+        S.loff = L >= 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)L;
+      }
       tyok = jr64(raw, kJdTyok);
       return S;
     };
@@ -2414,28 +2502,40 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         constexpr u32 M = decltype(mode)::value;
         const u32 sh1 = S.gsel & 0xFFu, need1 = S.gneed & 0xFFu, need2 = S.gneed >> 8;
         const u32 rqe = S.rq & 0x0F0F0F0Fu, rqo = (S.rq >> 4) & 0x0F0F0F0Fu;
-#pragma unroll
-        for (int r = 0; r < NPL; ++r) {
-          const bool b = ((bl >> r) & 1u) != 0;
-          bool a = b & (S.rc32 <= fcpu[r]) & (S.rm16 <= (mw[r] & 0xFFFFu));  // the entry at `now` is in every window
+        // the request in pack_dip's units: whole cpus and GiB rounded down, capped like the dip's; the window in 16 s units, rounded down
+        const u32 rcpus = (u32)S.rc32 >> 8;
+        const u32 rc8 = rcpus > 255u ? 255u : rcpus, rm8 = S.rm16 > 255u ? 255u : S.rm16, lq = (S.loff >> 4) > 0xFFFFu ? 0xFFFFu : (S.loff >> 4);
+        // the GRES side of the request against one set of per-class counts (the row's front, the row's dip)
+        auto gfit = [&](u32 g) -> bool {
+          bool ok = true;
           if (M == 1) {
-            const u32 g = gn[r];
-            if (S.gmode & 1u) a = a & (((g >> sh1) & 15u) >= need1);
+            if (S.gmode & 1u) ok = ok & (((g >> sh1) & 15u) >= need1);
             if (S.gmode & 2u) {
               const u32 ce = g & 0x0F0F0F0Fu, co = (g >> 4) & 0x0F0F0F0Fu;
-              a = a & (__builtin_amdgcn_sad_u8(ce & gme, 0u, __builtin_amdgcn_sad_u8(co & gmo, 0u, 0u)) >= need2);
+              ok = ok & (__builtin_amdgcn_sad_u8(ce & gme, 0u, __builtin_amdgcn_sad_u8(co & gmo, 0u, 0u)) >= need2);
             }
           }
           if (M == 4) {
-            const u32 g = gn[r];
             const u32 ce = g & 0x0F0F0F0Fu, co = (g >> 4) & 0x0F0F0F0Fu;
-            a = a & ((((ce | G8) - rqe) & G8) == G8) & ((((co | G8) - rqo) & G8) == G8);
+            ok = ok & ((((ce | G8) - rqe) & G8) == G8) & ((((co | G8) - rqo) & G8) == G8);
 #pragma unroll
             for (int n = 0; n < kMaxNames; ++n) {
               const u32 tot = (S.gtot >> (8 * n)) & 0xFFu;
               const u32 have = __builtin_amdgcn_sad_u8(ce & s_nme[n], 0u, __builtin_amdgcn_sad_u8(co & s_nmo[n], 0u, 0u));
-              a = a & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
+              ok = ok & ((tot == 0) | (have >= (tot > 15u ? 15u : tot)));
             }
+          }
+          return ok;
+        };
+#pragma unroll
+        for (int r = 0; r < NPL; ++r) {
+          const bool b = ((bl >> r) & 1u) != 0;
+          bool a = b & (S.rc32 <= fcpu[r]) & (S.rm16 <= (mw[r] & 0xFFFFu));  // the entry at `now` is in every window
+          if (M != 0) a = a & gfit(gn[r]);
+          if (kDip) {   // a window that reaches the row's dip must fit the dip too: a second necessary condition
+            bool fits = (rc8 <= ((dpa[r] >> 8) & 0xFFu)) & (rm8 <= (dpa[r] & 0xFFu));
+            if (M != 0) fits = fits & gfit(dpg[r]);
+            a = a & (((dpa[r] >> 16) >= lq) | fits);
           }
           const u64 ck = cost_key_m(cost[r], smode);
           const bool ta = a & (ck < ac);
@@ -2495,6 +2595,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       const double ucost = u.cost;
       const u32 ulen = u.len, ufront = u.has_front & 1u;
       const bool keep_cost = (u.has_front & 2u) != 0;   // the slot of another partition on a shared node
+      const bool released = (u.has_front & kUpdReleased) != 0;   // TryPreempt_ gave resources back on this node: the row's dip is void
       const int ucpu = u.fcpu;
       const u32 um16 = mem_gib16(u.fmem), ugn = nibbles_of(u.fcnt);
 #pragma unroll
@@ -2507,7 +2608,22 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           okbits = own ? (RM)((okbits & ~(kOne << r)) | ((RM)(ulen < maxlen ? 1u : 0u) << r)) : okbits;
           fcpu[r] = (own && ufront) ? ucpu : fcpu[r];
           gn[r] = (own && ufront) ? ugn : gn[r];
+#ifndef CNS_SEL_DIP_KEEP_ON_RELEASE   // (defined by a test build only: tests/test_preempt.py's stale-dip case must FAIL on it)
+          if (kDip) dpa[r] = (own && released) ? kDipNone : dpa[r];
+#endif
         }
+    };
+    // the dip the worker found under a rejected candidate (post_dip): the owner lane keeps it for the row
+    auto take_dip = [&]() {
+      if (!kDip) return;
+      const u32 dc = uni32((u32)s_fl[4]);
+      if (dc == kNone || owner_wave(dc) != wave) return;
+      const u32 da = pack_dip((u32)s_fl[5], (u32)s_fl[6]), dg = (u32)s_fl[7];
+      const int rr = (int)(dc >> 10);
+      const bool own = (dc & 1023u) == t;
+#pragma unroll
+      for (int r = 0; r < kDipRows; ++r)
+        if (r == rr) { dpa[r] = own ? da : dpa[r]; dpg[r] = own ? dg : dpg[r]; }
     };
     // One node that the pre-scan of job Sn skipped (a round-0 winner of the job before it): evaluate Sn's
     // filters on its refreshed registers and complete the pre-scanned candidate sets.  `code` is
@@ -2645,6 +2761,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         wg_barrier();  // B2
         verdict = s_flag;
         if (verdict == 2) break;
+        take_dip();
         round0 = false;
         lane_argmin(amask & ~used, ac, ap);
         wave_argmin(ac, ap);
@@ -2716,6 +2833,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
   }
 }
 
+#undef s_flag
 #include "pipe_kernel.inc"
 // k_wide in four builds — scanner workgroups per partition / scanner waves / partitions of one launch it serves (every workgroup of
 // the launch must be resident at once, the workgroups of a partition on one XCD): 16 / 64 / up to 8, 8 / 32 / up to 24,

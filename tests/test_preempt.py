@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from cranesched_amd import abi
-from tests import kat_preempt
+from tests import kat, kat_preempt
 
 
 def check(run, jobs, cluster, expect, name):
@@ -463,5 +463,43 @@ def test_engine_split_preempt_cycle_survives_a_k_wide_retry(gpu, monkeypatch):
         monkeypatch.delenv("CNS_WIDE_INJECT_STALL")
         pl, po = eng.node_select_preempt(now, j, pre)
         compare_engine("split cycle, after", c, j, ref, eng, pl, po)
+    finally:
+        eng.close()
+
+
+def stale_dip_case():
+    """A dip that a release makes void (k_select's scanners keep one dip per node: select_kernels.hip, post_dip).  Node 0 has 6 cores:
+    R0 (qos 0) holds {0,1} until 5000, R1 (qos 1) {2,3} until 2000; node 1 is full until 9000 (node 0 stays the cheaper one: TryPreempt_ works on the nodes phase B picks in cost order).
+      J0 (qos 0, 4 cpus, 100 s)  cannot start now: backfilled on node 0 at 2000 — the entry at 2000 then has 0 cpus free.
+      J1 (qos 0, 2 cpus, 5000 s) passes node 0's front (2 free) and trips over the entry at 2000: rejected, the scanners learn the dip.
+      J2 (qos 1, 3 cpus, 50 s)   cannot start now, preempts R0: node 0 gets R0's 2 cpus back over [now, 5000) — incl. at 2000.
+      J3 (qos 0, 1 cpu, 5000 s)  now fits node 0 at once (1 free now, 2 at 2000); a scanner that kept the dip would not propose node 0."""
+    c = kat.cluster([6, 4], [64, 64])
+    j = kat.jobs([dict(cpu=4, L=100), dict(cpu=2, L=5000), dict(cpu=3, L=50), dict(cpu=1, L=5000), dict(cpu=1, L=5000)])
+    r = kat_preempt.running([dict(end=5000, allocs=[(0, 0x03, 1)]), dict(end=2000, allocs=[(0, 0x0C, 1)]), dict(end=9000, allocs=[(1, 0xF, 1)])])
+    pre = kat_preempt.preempt([[], [0]], [(1, 0, 1, 5.0), (2, 0, 1, 4.0), (3, 1, 10, 3.0), (4, 0, 1, 2.0), (5, 0, 1, 1.0)],
+                              [(50, 0, 1, 900), (51, 1, 10, 800), (52, 1, 10, 700)])
+    return c, j, r, pre
+
+
+def test_oracle_on_the_stale_dip_case(built):
+    from oracle import pyoracle
+    c, j, r, pre = stale_dip_case()
+    ref = pyoracle.select(c, j, kat_preempt.NOW, running=r, preempt=pre)
+    pl = ref.placements
+    assert int(pl.start_sec[0]) == 2000 and int(pl.start_sec[1]) > kat_preempt.NOW, (pl.start_sec, pl.reason)   # J0 backfilled, J1 tripped over it
+    assert ref.preempt_out.lists()[2] == [(False, 0)] and int(pl.start_sec[2]) == kat_preempt.NOW                 # J2 preempted R0
+    assert int(pl.start_sec[3]) == kat_preempt.NOW and int(pl.node_idx[int(pl.place_offsets[3])]) == 0, (pl.start_sec, pl.node_idx)   # J3 at once on node 0
+
+
+@pytest.mark.gpu
+def test_engine_forgets_a_dip_when_preemption_releases_on_the_node(gpu):
+    from oracle import pyoracle
+    c, j, r, pre = stale_dip_case()
+    ref = pyoracle.select(c, j, kat_preempt.NOW, running=r, preempt=pre)
+    eng, pl, po = run_engine_preempt(c, j, kat_preempt.NOW, r, pre)
+    try:
+        compare_engine("stale dip", c, j, ref, eng, pl, po)
+        assert eng.last_kernel().startswith("k_select")
     finally:
         eng.close()

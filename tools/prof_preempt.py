@@ -37,11 +37,14 @@ if m[0]:
           f"({m[13]/max(m[11],1):.0f}), tree nodes {m[9]/max(m[11],1):.0f} ({m[14]/max(m[11],1):.0f}), node fetches + claims that missed the LDS cache {m[17]/max(m[11],1):.0f}; "
           f"calls that ran out of compressed records and were redone node for node {m[18]:.0f}; total in TryPreempt_ {us(m[1]+m[2]+m[3]+m[4]+m[5])/1e3:.0f} ms of {t['select_ms']:.0f}")
 if os.environ.get("CNS_PROF_KSELECT"):   # a -DCNS_PROF build (without CNS_PROF_PRE): k_select's own counters of the preempting partition (block 0)
-    r = e.prof().astype(np.float64)[0]
+    r = e.prof().astype(np.float64)
+    r = r[int(np.argmax(r[:, 13]))]   # (one row of counters per partition: the one whose jobs took the general path)
     mhz = 2370.0
     ms = lambda c: c / mhz / 1e3
-    print(f"  k_select worker, partition 0: inline path done in phase A {r[11]:.0f} jobs, phase B {r[12]:.0f}; general path {r[13]:.0f} jobs in {ms(r[5]):.0f} ms "
+    print(f"  k_select worker of the preempting partition: inline path done in phase A {r[11]:.0f} jobs, phase B {r[12]:.0f}; general path {r[13]:.0f} jobs in {ms(r[5]):.0f} ms "
           f"({ms(r[5])*1e3/max(r[13],1):.0f} us each); multi-node protocols {r[15]:.0f} jobs in {ms(r[6]):.0f} ms; rejected candidates {r[14]:.0f}")
     print(f"  worker ms: wait for the scanners {ms(r[0]):.0f} | phase A block load {ms(r[1]):.0f} | window-min + test {ms(r[2]):.0f} | commit {ms(r[3]):.0f} | "
           f"phase B {ms(r[4]):.0f} | next-job decode + merge {ms(r[7]):.0f} | record -> LDS {ms(r[24]):.0f}")
     print(f"  scanner wave 1 ms: full scan + B1 {ms(r[17]):.0f} | pre-scan {ms(r[18]):.0f} | waiting for the verdict {ms(r[19]):.0f} | owner update {ms(r[20]):.0f} | merge wait {ms(r[21]):.0f}")
+    if os.environ.get("CNS_PROF_DIP"):   # ... built with -DCNS_PROF_DIP too: the dips k_select's worker posted (slots of the multi-node protocols, unused on this partition)
+        print(f"  rejected inline candidates: a dip found {r[28]:.0f}; front fine and no single entry fails by counts {r[27]:.0f}; the exact test fails on the front entry: by cpu {r[29]:.0f}, by memory {r[30]:.0f}, otherwise {r[31]:.0f}")
