@@ -122,7 +122,7 @@ struct PreParams {
   u32* out_cnt;            // [1] pairs appended so far
   u32* out;                // [2 * out_cap] (pending job (orig), reference) in push_back order per job
   u32 out_cap;
-  u32 literal_tree;        // debug / tests: 1 skip the compressed trees (preempt_dev.inc), run every call node for node; 2 give them room for a handful of records only
+  u32 literal_tree;        // debug / tests: 1 skip the compressed trees (preempt_dev.inc), run every call node for node; 2 give them room for a handful of records only (either also orders every call's candidates block by block)
 };
 
 struct KParams {

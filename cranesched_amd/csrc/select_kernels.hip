@@ -2033,6 +2033,10 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       // cycle that can preempt nobody (inline_in_preempt_cycle)
       const bool shared_nodes = general_path_job(P.general_only != 0, P.sib_off != nullptr, F.flags, F.k, F.ntasks != F.k, F.tmin == 1);
       const bool fast = simple && F.k == 1 && F.tmin == 1 && !shared_nodes;
+      // A job of the inline path's shape that MAY preempt (a cycle with preemption): TryPreempt_ only comes after "start now" has
+      // failed (JobScheduler.cpp:6140-6143), so its phase A runs inline as well — the owner update goes where the scanners of a
+      // general-path job look (the HBM list) — and only what is left (TryPreempt_, Backfill_) goes out of line, from the round reached.
+      const bool fast_a = P.general_only && !P.sib_off && simple && F.k == 1 && F.tmin == 1 && (F.flags & kJfMayPreempt) != 0;
       const u64 wsmode = P.general_only ? ~0ull : 0ull;   // (the scanners' keys are in signed form in such a cycle: cost_key_m)
 
       if (!pre_valid) {
@@ -2053,9 +2057,9 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       cn.code = kNone; cn.cost = 0; cn.len = 0; cn.type = 0; cn.fcpu = 0; cn.fmem = 0; cn.fcnt = 0;
       on = cn;
 
-      bool divert = !fast;      // leave the inline path (multi-node / general / exclusive / long time map)
+      bool divert = !fast && !fast_a;   // leave the inline path (multi-node / general / exclusive / long time map)
       bool have_on = false;     // `on` is the T winner: its summary sits in s_on after B2
-      if (fast) {
+      if (fast || fast_a) {
         // The T winner's summary is needed for the merge when this job commits on the A winner; its owner
         // lane posts it in LDS (s_on) before B2 — no HBM round trip on the serial chain.
         have_on = wcode != kNone && tcode != kNone && tcode != wcode;
@@ -2093,7 +2097,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           PROF_ADD(2, a1, a2);  // window-min + feasibility
           if (ok) {  // tpn_min == 1: the minimum view is the 1-task view, f is the allocation (:6312-6320)
             commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, cost_of_key_m(wc, wsmode), f,
-                               P.now, 0, lane, s_upd, &s_nupd, cn, PG, qbeg);
+                               P.now, 0, lane, fast_a ? P.g_upd + qbeg : (UpdRec*)s_upd, &s_nupd, cn, PG, qbeg);
+            if (fast_a) __threadfence_block();   // (the record went through HBM)
             code = 2;
           } else if (NPL <= kSelDipMaxNpl) {
             const bool dipped = post_dip(P, P.gres, s_fl, wcode, e, h.len, F.mv, F.E, lane, m);   // what this window tripped over, for the node's owner lane
@@ -2127,6 +2132,8 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
         }
         if (done) {
           PROF_CNT(11);
+        } else if (fast_a) {
+          divert = true;   // nothing starts it now: TryPreempt_ / Backfill_ out of line (worker_job_slow enters with no start-now candidate left)
         } else if (!divert) {
           // ---- fast path, Phase B: the first node in cost order whose res_total fits (the T argmin of
           // round 0), earliest start on its time map (JobScheduler.cpp:6335-6368, Backfill_ :6371-6376) ----
