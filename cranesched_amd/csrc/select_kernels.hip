@@ -58,11 +58,16 @@ __device__ __forceinline__ double cost_of_key_m(u64 key, u64 smode) {   // the c
 __device__ __forceinline__ bool inline_in_preempt_cycle(u32 flags, u32 k, bool general, bool tmin1) {
   return k == 1 && !general && tmin1 && !(flags & (kJfExclusive | kJfMayPreempt));
 }
+// ... and node_num 2 .. kMultiK of that shape (the parallel protocol of the multi-node jobs: its commits join the nodes' qos_job_map
+// like commit_selection's, pre_join_multi; the owner updates stay in LDS)
+__device__ __forceinline__ bool fast_in_preempt_cycle(u32 flags, u32 k, bool general, bool tmin1) {
+  return k >= 1 && k <= (u32)kMultiK && !general && tmin1 && !(flags & (kJfExclusive | kJfMayPreempt));
+}
 // ... and in a group of partitions that share nodes the jobs of that shape keep the inline path too (the commit then lists the node's
 // other slots among the owner updates: commit_single_shared); everything else of such a group, and all of it in a cycle with
 // preemption, takes the general path.  true = general path ("shared_nodes" in worker and scanners).
 __device__ __forceinline__ bool general_path_job(bool general_only, bool shared_group, u32 flags, u32 k, bool general, bool tmin1) {
-  if (general_only) return shared_group || !inline_in_preempt_cycle(flags, k, general, tmin1);
+  if (general_only) return shared_group || !fast_in_preempt_cycle(flags, k, general, tmin1);
   // (node_num 2 .. kMultiK of that shape: the parallel protocol, whose helper waves list the sibling slots as well)
   return shared_group && !(k >= 1 && k <= (u32)kMultiK && !general && tmin1 && !(flags & kJfExclusive));
 }
@@ -1258,7 +1263,7 @@ __device__ __noinline__ int worker_job_slow(const KParams& Pm, const WorkerShare
   const u32 orig = J.orig;
   HeapEnt* const H = (J.k < (u32)kLdsHeap) ? sh.heap : gheap;
   // (a job of the inline path's shape that can preempt nobody, diverted to here by a long time map: the scanners expect its update in LDS)
-  const bool via_hbm = J.k > (u32)kMaxUpd || P.sib_off || (P.general_only && !inline_in_preempt_cycle(J.flags, J.k, J.general, J.tmin == 1));
+  const bool via_hbm = J.k > (u32)kMaxUpd || P.sib_off || (P.general_only && !fast_in_preempt_cycle(J.flags, J.k, J.general, J.tmin == 1));
   UpdRec* const s_upd = !via_hbm ? sh.upd : P.g_upd + qbeg;  // long lists (sibling slots of shared nodes, releases of a preemption) go through HBM
   int* const s_nupd = sh.nupd;
 
@@ -1575,6 +1580,25 @@ __device__ __forceinline__ void emit_placements(const KParams& P, const JobCtx& 
   }
 }
 
+// UpdateNodeSelectorWithScheduledJob (h:636-642) for a multi-node job committed by the parallel protocol or by worker_job_multi in a
+// cycle with preemption (what commit_selection does for the general path): the job joins the qos_job_map of each of its k nodes, under
+// the placement record it wrote there (poff + rank by node index).  One wave (the worker); H[i].node as the helpers / the commit left it.
+__device__ __noinline__ void pre_join_multi(const KParams& P, const JobCtx& J, const HeapEnt* H, u32 qbeg, i64 end) {
+  const u32 lane = threadIdx.x & 63u;
+  if (lane < J.k) {
+    const HeapEnt me = H[lane];
+    u32 rank = 0;
+    for (u32 m = 0; m < J.k; ++m) rank += H[m].node < me.node ? 1u : 0u;
+    const u64 o = J.poff + rank;
+    const u32 q = qbeg + slot_of_code(me.p);
+    P.pre.rec_orig[o] = J.orig; P.pre.rec_slot[o] = q; P.pre.rec_gone[o] = 0;
+    const u32 hq = P.slot_block ? P.slot_block[q] : q;
+    P.pre.rec_next[o] = P.pre.slot_head[hq];   // (the k nodes are distinct: no two lanes touch one list)
+    P.pre.slot_head[hq] = (u32)o;
+  }
+  if (lane == 0) { P.pre.pj_rec0[J.orig] = (u32)J.poff; P.pre.pj_k[J.orig] = J.k; P.pre.pj_end[J.orig] = end; }
+}
+
 // Out-of-line worker path for multi-node jobs with ntasks == node_num on shared nodes (2 <= k <= kMaxUpd):
 // same barrier schedule as the general path, but every node is handled with the one-read block primitives.
 __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShared sh, const JobCtx* Jp, int par,
@@ -1584,6 +1608,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
   const u32 orig = J.orig;
   HeapEnt* const H = sh.heap;
   const Req one_view = compose(J.node_view, J.tcpu, J.tmem, 1);
+  const u64 smode = P.general_only ? ~0ull : 0ull;   // (a cycle with preemption: the scanners' keys are in signed form, cost_key_m)
 
   // ---- Phase A: the first k nodes in cost order that can start the job now (:6188-6333) ----------
   u32 npick = 0;
@@ -1604,7 +1629,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
       if (J.tmin != 1 && !feasible(one_view, m, alloc, P.gres)) { if (lane == 0) set_fault(P, 2, orig, h.node, 3); }
       if (lane == 0) {
         HeapEnt x; x.ntasks = 1; x.p = wcode; x.node = h.node; x.pad = 0;
-        x.cost = __longlong_as_double((long long)wc); x.res = alloc;
+        x.cost = cost_of_key_m(wc, smode); x.res = alloc;
         H[npick] = x;
       }
       ++npick;
@@ -1613,6 +1638,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
         __threadfence_block();
         for (u32 i = 0; i < J.k; ++i) commit_pick(P, J, H[i], i, qbeg, P.now, lane, sh.upd, orig);
         emit_placements(P, J, H, lane);
+        if (P.pre.enabled) pre_join_multi(P, J, H, qbeg, P.now + J.L);
         if (lane == 0) { *sh.nupd = (int)J.k; P.o_start[orig] = P.now; P.o_reason[orig] = 0; }
         code = 2;
       }
@@ -1643,7 +1669,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
   while (ccode != kNone) {
     if (lane == 0) {
       HeapEnt x; x.ntasks = 1; x.p = ccode; x.node = 0; x.pad = 0;
-      x.cost = __longlong_as_double((long long)cc); x.res = res_zero();
+      x.cost = cost_of_key_m(cc, smode); x.res = res_zero();
       H[nsel] = x;
     }
     ++nsel;
@@ -1695,6 +1721,7 @@ __device__ __noinline__ int worker_job_multi(const KParams& P, const WorkerShare
       if (t != P.now) reason = reserved ? 3 /*Resource Reserved*/ : (notle ? 2 /*Resource*/ : 1 /*Priority*/);  // :6797-6831
       for (u32 i = 0; i < J.k; ++i) commit_pick(P, J, H[i], i, qbeg, t, lane, sh.upd, orig);
       emit_placements(P, J, H, lane);
+      if (P.pre.enabled) pre_join_multi(P, J, H, qbeg, t + J.L);
       if (lane == 0) { *sh.nupd = (int)J.k; P.o_start[orig] = t; P.o_reason[orig] = (uint8_t)reason; }
       code = 2;
     }
@@ -2230,7 +2257,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
               if (pc == kNone) break;
               if (lane == 0) {
                 HeapEnt x; x.ntasks = 0; x.p = pc; x.node = 0; x.pad = 0;
-                x.cost = __longlong_as_double((long long)c); x.res = res_zero();
+                x.cost = cost_of_key_m(c, wsmode); x.res = res_zero();
                 s_heap[i] = x;
               }
               ++n;
@@ -2252,6 +2279,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
           if (n == F.k) {  // k start-now candidates exist (:6294-6297 if their exact tests pass)
             if (multi_verify_commit(PG, &s_gres, &s_job, s_heap, kWaves - 1, (u32)(kWaves - 1) < F.k, qbeg, s_upd, &s_nupd)) {
               if (lane == 0) { P.o_start[F.orig] = P.now; P.o_reason[F.orig] = 0; }  // :6326
+              if (P.pre.enabled) pre_join_multi(PG, s_job, s_heap, qbeg, P.now + F.L);
               PROF_CNT(30);
             } else {
               fallback = true;  // a candidate failed its exact test (rare): redo this job sequentially
@@ -2275,6 +2303,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
                 if (st != kInf) { P.o_start[F.orig] = st; P.o_reason[F.orig] = (uint8_t)reason; }
                 else { P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2; }  // "Resource", :6768
               }
+              if (P.pre.enabled && st != kInf) pre_join_multi(PG, s_job, s_heap, qbeg, st + F.L);
             } else if (lane == 0) {
               P.o_start[F.orig] = 0; P.o_reason[F.orig] = 2;  // not even k nodes fit res_total (:6335-6343)
             }

@@ -26,7 +26,7 @@ if J is None:
     d["preempt_crc"] = fullrun.preempt_crc(np.asarray(pairs, np.int64).reshape(-1, 2), np.asarray(po.cancelled_ids(), np.int64))
     print("  digest:", fullrun.compare(d, ref) or "identical to the oracle's full run")
 m = e.prof().astype(np.float64).sum(axis=0)
-if m[0]:
+if m[0] and not os.environ.get("CNS_PROF_KSELECT"):   # (a -DCNS_PROF_PRE build; under -DCNS_PROF the same slots hold k_select's counters)
     mhz = 2370.0   # clock64() counts shader cycles (k_wide's supervisor loop over the kernel time: 2.37 GHz on these boxes)
     us = lambda c: c / mhz
     print(f"  TryPreempt_ calls {m[0]:.0f} (with candidates {m[11]:.0f}, trees satisfied {m[10]:.0f}, jobs preempted {m[16]:.0f}); "
@@ -36,7 +36,7 @@ if m[0]:
     print(f"  per call with candidates: range operations {m[7]/max(m[11],1):.0f} ({m[12]/max(m[11],1):.0f} for the time maps), node visits {m[8]/max(m[11],1):.0f} "
           f"({m[13]/max(m[11],1):.0f}), tree nodes {m[9]/max(m[11],1):.0f} ({m[14]/max(m[11],1):.0f}), node fetches + claims that missed the LDS cache {m[17]/max(m[11],1):.0f}; "
           f"calls that ran out of compressed records and were redone node for node {m[18]:.0f}; total in TryPreempt_ {us(m[1]+m[2]+m[3]+m[4]+m[5])/1e3:.0f} ms of {t['select_ms']:.0f}")
-if m[0] and (m[19] or m[21]):
+if m[0] and not os.environ.get("CNS_PROF_KSELECT") and (m[19] or m[21]):
     print(f"  ordering: {m[21]:.0f} calls with more than 64 candidates took {us(m[22])/1e3:.0f} ms, {m[19]:.0f} of them past the rank sort's capacity took {us(m[20])/1e3:.0f} ms")
 if os.environ.get("CNS_PROF_KSELECT"):   # a -DCNS_PROF build (without CNS_PROF_PRE): k_select's own counters of the preempting partition (block 0)
     r = e.prof().astype(np.float64)
