@@ -2126,6 +2126,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
             commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, wcode, cost_of_key_m(wc, wsmode), f,
                                P.now, 0, lane, fast_a ? P.g_upd + qbeg : (UpdRec*)s_upd, &s_nupd, cn, PG, qbeg);
             if (fast_a) __threadfence_block();   // (the record went through HBM)
+            cn.cost = cost_key_m(__longlong_as_double((long long)cn.cost), wsmode);   // (the merge below compares it with the scanners' keys)
             code = 2;
           } else if (NPL <= kSelDipMaxNpl) {
             const bool dipped = post_dip(P, P.gres, s_fl, wcode, e, h.len, F.mv, F.E, lane, m);   // what this window tripped over, for the node's owner lane
@@ -2219,6 +2220,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
                 PROF_T(b0c);
                 commit_single_regs(P, F.L, F.orig, F.poff, hd, h, e, q, tcode, cost_of_key_m(tc, wsmode),
                                    alloc, st, reason, lane, s_upd, &s_nupd, cn, PG, qbeg);
+                cn.cost = cost_key_m(__longlong_as_double((long long)cn.cost), wsmode);
                 PROF_T(b0d);
                 PROF_ADD(10, b0c, b0d);  // phase B: commit
                 code = 2;
@@ -2333,7 +2335,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       raw = raw_n;
       raw_n = ji + 2 < jend ? fetch_job(P, ji + 2) : 0u;
       const u32 nflags = rl32(raw, kJrFlags);
-      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl)) && !P.general_only && !P.sib_off;   // (no pre-scan in a cycle with preemption: its merge compares raw keys; nor on shared nodes: a commit changes more rows than the two winners')
+      const bool nv = fast && round0 && !(nflags & (kJfExclusive | kJfIncl | kJfExcl)) && !P.sib_off;   // (no pre-scan on shared nodes: a commit changes more rows than the two winners'; in a cycle with preemption the jobs of the inline path have it — cn / on carry keys in the scanners' signed form)
       if (nv) {
         const FastJob Fn = make_fast_job(P, raw);
         u64 ac = s_pc[lane & (kRed - 1)];
@@ -2730,7 +2732,7 @@ __global__ __launch_bounds__(kBlock) void k_select(const KParams P, const KParam
       u64 typeok_n = typeok;
       const bool have_next = ji + 1 < jend;
       const bool shared_nodes = general_path_job(P.general_only != 0, P.sib_off != nullptr, J.flags, kk, general, (J.shape & 2u) != 0);
-      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes && !P.general_only && !P.sib_off;  // this job touches one node, a round-0 winner
+      const bool spec_ok = !excl_job && !general && kk == 1 && !shared_nodes && !P.sib_off;  // this job touches one node, a round-0 winner
       RM skipm = 0;
       if ((wcode & 1023u) == t && wcode != kNone) skipm |= kOne << (wcode >> 10);
       if ((tcode & 1023u) == t && tcode != kNone) {
