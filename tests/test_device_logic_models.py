@@ -205,3 +205,87 @@ def test_wide_launch_layout(group, max_parts):
         assert max(per_xcd) <= 32, (nparts, per_xcd)              # (c)
         assert grid <= 256                                       # (d) what engine.hip's fits() checks before the launch
     assert (32 // group) * 8 == max_parts                        # kWMaxParts of that build
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# 5. k_select's dips (cranesched_amd/csrc/select_kernels.hip: post_dip, pack_dip, the dip test in the scanners' row loop).
+#    The claim: once the worker has posted, under a rejected start-now candidate, either the first entry of the window that
+#    cannot host the job or the WINDOW MINIMUM dated at the last entry inside the window, the scanners' packed test never drops
+#    a node on which a LATER job would pass the exact test — whatever was committed on the node in between (entries only shrink
+#    and split within a cycle without releases).  Resources here: (cpus, GiB); the GRES counts go through the same comparison.
+# ---------------------------------------------------------------------------------------------------------------------
+def _pack_dip(dt, cpus_up, gib_up):
+    """pack_dip: 16 s units rounded UP (0xFFFF: none / too far), whole cpus and GiB capped at 255"""
+    t16 = 0xFFFF if dt >= 0xFFFF0 else (dt + 15) >> 4
+    return t16, min(cpus_up, 255), min(gib_up, 255)
+
+
+def _packed_drops(packed, L, req_cpu256, req_mib):
+    """the scanners' test: True = the node is NOT proposed to a job with time limit L and this request"""
+    t16, c8, m8 = packed
+    lq = min(L >> 4, 0xFFFF)
+    rc8, rm8 = min(req_cpu256 >> 8, 255), min(req_mib >> 10, 255)       # the request rounded DOWN, capped like the dip
+    fits = rc8 <= c8 and rm8 <= m8
+    return not (t16 >= lq or fits)
+
+
+def _window_min(avail0, tmap, L):
+    m = list(avail0)
+    for t, (c, g) in tmap:
+        if t < L:                                                      # entry t seconds after now lies in the window iff t < L (:6279)
+            m = [min(m[0], c), min(m[1], g)]
+    return m
+
+
+@pytest.mark.parametrize("seed", range(200))
+def test_k_select_dip_never_drops_a_node_that_passes(seed):
+    rng = np.random.default_rng(9000 + seed)
+    # a node's time map: entry 0 at `now`, later entries at increasing offsets (seconds), resources in 1/256 cpus and MiB
+    n = int(rng.integers(1, 12))
+    times = [0] + sorted(int(x) for x in rng.choice(np.arange(1, 400_000), size=n - 1, replace=False)) if n > 1 else [0]
+    tot = (int(rng.integers(1, 300)) * 256, int(rng.integers(1, 600)) * 1024)
+    tmap = [(t, (int(rng.integers(0, tot[0] // 128 + 1)) * 128, int(rng.integers(0, tot[1] // 512 + 1)) * 512)) for t in times]   # (half cpus, half GiB: the rounding edges come up)
+    avail0 = tmap[0][1]
+    exact_ok = lambda L, rc, rm: all(a >= b for a, b in zip(_window_min(avail0, tmap, L), (rc, rm)))
+    for _ in range(40):
+        L = int(rng.integers(1, 500_000)); rc = int(rng.integers(1, tot[0] + 300)); rm = int(rng.integers(1, tot[1] + 2000))
+        if exact_ok(L, rc, rm):
+            continue
+        # post_dip for the rejected job (L, rc, rm)
+        inw = [i for i, (t, _) in enumerate(tmap) if i == 0 or t < L]
+        single = [i for i in inw if i >= 1 and (tmap[i][1][0] < rc or tmap[i][1][1] < rm)]
+        if single:
+            i = single[0]; r = tmap[i][1]
+        else:
+            i = inw[-1]; r = _window_min(avail0, tmap, L)
+        dt = tmap[i][0]
+        packed = _pack_dip(dt, -(-max(r[0], 0) // 256), -(-r[1] // 1024))      # dip_cm_of: cpus and GiB rounded UP
+        # ... later commits: entries shrink, new entries split old ones (a copy of the covering entry, then shrunk)
+        later = list(tmap)
+        for _ in range(int(rng.integers(0, 4))):
+            s = int(rng.integers(0, 400_000)); e = s + int(rng.integers(1, 100_000)); dc = int(rng.integers(0, 3)) * 256
+            for cut in (s, e):
+                if all(t != cut for t, _ in later):
+                    cover = max((x for x in later if x[0] <= cut), key=lambda x: x[0])
+                    later.append((cut, cover[1]))
+            later.sort()
+            later = [(t, (max(c - dc, 0), g)) if s <= t < e else (t, (c, g)) for t, (c, g) in later]
+        a0 = later[0][1] if later[0][0] == 0 else avail0
+        for k in range(60):
+            L2 = int(rng.integers(1, 500_000)); rc2 = int(rng.integers(1, tot[0] + 300)); rm2 = int(rng.integers(1, tot[1] + 2000))
+            if k % 2:   # at the edges: a window that ends around the dip's date, a request that just passes the exact test
+                L2 = max(1, dt + int(rng.integers(-40, 41)))
+                m2 = _window_min(avail0, later, L2)
+                rc2 = max(1, m2[0] - int(rng.integers(0, 2)) * int(rng.integers(0, 600))); rm2 = max(1, m2[1] - int(rng.integers(0, 2)) * int(rng.integers(0, 3000)))
+            passes = all(a >= b for a, b in zip(_window_min(avail0, later, L2), (rc2, rm2)))
+            if _packed_drops(packed, L2, rc2, rm2):
+                assert not passes, (seed, tmap, (L, rc, rm), (dt, r), packed, later, (L2, rc2, rm2))
+        assert _packed_drops(packed, max(L, ((dt + 15) >> 4 << 4) + 16), rc + 256 * 300, rm) or packed[1] == 255 or packed[0] == 0xFFFF
+
+
+def test_pack_dip_none_and_caps():
+    assert _pack_dip(0xFFFFFFFF, 0, 0)[0] == 0xFFFF                       # "no dip" is never inside a window
+    assert not _packed_drops(_pack_dip(0xFFFFFFFF, 0, 0), 10**9, 10**6, 10**6)
+    assert not _packed_drops(_pack_dip(100, 300, 1), 10**6, 400 * 256, 512)   # a dip with >= 255 cpus fits any cpu request (capped both sides)
+    assert _packed_drops(_pack_dip(100, 3, 1), 10**6, 4 * 256, 512)
+    assert not _packed_drops(_pack_dip(100, 3, 1), 112, 4 * 256, 512)         # window [0, 112) in 16 s units = 7 = the dip's unit: may not contain it
