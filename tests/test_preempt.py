@@ -473,7 +473,8 @@ def stale_dip_case():
       J0 (qos 0, 4 cpus, 100 s)  cannot start now: backfilled on node 0 at 2000 — the entry at 2000 then has 0 cpus free.
       J1 (qos 0, 2 cpus, 5000 s) passes node 0's front (2 free) and trips over the entry at 2000: rejected, the scanners learn the dip.
       J2 (qos 1, 3 cpus, 50 s)   cannot start now, preempts R0: node 0 gets R0's 2 cpus back over [now, 5000) — incl. at 2000.
-      J3 (qos 0, 1 cpu, 5000 s)  now fits node 0 at once (1 free now, 2 at 2000); a scanner that kept the dip would not propose node 0."""
+      J3 (qos 0, 1 cpu, 5000 s)  now fits node 0 at once (1 free now, 2 at 2000); a scanner that kept the dip would not propose node 0.
+    (A library built with -DCNS_SEL_DIP_KEEP_ON_RELEASE keeps it: the engine test below fails on that build, profiles/r06_k_select_dips_c4rp.txt.)"""
     c = kat.cluster([6, 4], [64, 64])
     j = kat.jobs([dict(cpu=4, L=100), dict(cpu=2, L=5000), dict(cpu=3, L=50), dict(cpu=1, L=5000), dict(cpu=1, L=5000)])
     r = kat_preempt.running([dict(end=5000, allocs=[(0, 0x03, 1)]), dict(end=2000, allocs=[(0, 0x0C, 1)]), dict(end=9000, allocs=[(1, 0xF, 1)])])
