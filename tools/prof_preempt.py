@@ -38,6 +38,14 @@ if m[0] and not os.environ.get("CNS_PROF_KSELECT"):   # (a -DCNS_PROF_PRE build;
           f"calls that ran out of compressed records and were redone node for node {m[18]:.0f}; total in TryPreempt_ {us(m[1]+m[2]+m[3]+m[4]+m[5])/1e3:.0f} ms of {t['select_ms']:.0f}")
 if m[0] and not os.environ.get("CNS_PROF_KSELECT") and (m[19] or m[21]):
     print(f"  ordering: {m[21]:.0f} calls with more than 64 candidates took {us(m[22])/1e3:.0f} ms, {m[19]:.0f} of them past the rank sort's capacity took {us(m[20])/1e3:.0f} ms")
+if m[0] and not os.environ.get("CNS_PROF_KSELECT") and m[23:29].any():   # record visits of the compressed trees by kind (count in the low 24 bits, cycles above)
+    pr = e.prof().astype(np.uint64)
+    names = ("push_up", "outside the range", "covered completely", "a leaf split into a chain", "range end inserted into a chain", "(every partial visit, whole)")
+    for k, nm in enumerate(names):
+        col = pr[:, 23 + k]
+        n = int((col & np.uint64(0xFFFFFF)).sum()); cyc = int((col >> np.uint64(24)).sum())
+        if n: print(f"  record visits, {nm}: {n} x {cyc / n:.0f} cycles = {cyc / 2370.0 / 1e3:.0f} ms")
+    print(f"  range operations on the compressed trees: the calls of pre_crange_v as the caller sees them {us(m[30])/1e3:.0f} ms; apply() of the forward pass, whole {us(m[31])/1e3:.0f} ms")
 if os.environ.get("CNS_PROF_KSELECT"):   # a -DCNS_PROF build (without CNS_PROF_PRE): k_select's own counters of the preempting partition (block 0)
     r = e.prof().astype(np.float64)
     r = r[int(np.argmax(r[:, 13]))]   # (one row of counters per partition: the one whose jobs took the general path)
